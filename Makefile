@@ -1,0 +1,46 @@
+# Builds the product library roki-fd_amd/librkfd_amd.so (host C + HIP for gfx950),
+# the CPU oracle (test infrastructure) and the lane-emulator harness (test infrastructure).
+HIPCC   ?= /opt/rocm/bin/hipcc
+CC      ?= gcc
+CXX     ?= g++
+ARCH    ?= gfx950
+PKG      = roki-fd_amd
+CSRC     = $(PKG)/csrc
+BUILD    = $(PKG)/build
+INC      = -Iinclude -I$(CSRC) -I$(CSRC)/host
+CFLAGS   = -O2 -Wall -fPIC $(INC)
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -fPIC $(INC) -Wno-unused-value
+
+HOST_OBJS = $(BUILD)/rkfd_ztk.o $(BUILD)/rkfd_world.o $(BUILD)/rkfd_sim.o $(BUILD)/rkfd_devmodel.o
+LIB = $(PKG)/librkfd_amd.so
+
+all: $(LIB) oracle emu
+
+$(BUILD):
+	mkdir -p $(BUILD)
+
+$(BUILD)/%.o: $(CSRC)/host/%.c include/*.h $(CSRC)/host/*.h | $(BUILD)
+	$(CC) $(CFLAGS) -c $< -o $@
+
+$(BUILD)/rkfd_devmodel.o: $(CSRC)/rkfd_devmodel.cpp $(CSRC)/*.h include/*.h | $(BUILD)
+	$(CXX) -std=c++17 $(CFLAGS) -c $< -o $@
+
+$(BUILD)/rkfd_capi.o: $(CSRC)/rkfd_capi.hip $(CSRC)/*.h include/*.h | $(BUILD)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(HOST_OBJS) $(BUILD)/rkfd_capi.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm
+
+oracle:
+	$(MAKE) -C oracle
+
+emu: tests/emu/librkfd_emu.so
+
+tests/emu/librkfd_emu.so: tests/emu/rkfd_emu.cpp $(CSRC)/rkfd_device.h $(CSRC)/rkfd_devmodel.cpp $(CSRC)/*.h include/*.h
+	$(CXX) -std=c++20 -O2 -Wall -Wno-unknown-pragmas -fPIC -shared -pthread $(INC) -o $@ tests/emu/rkfd_emu.cpp $(CSRC)/rkfd_devmodel.cpp
+
+clean:
+	rm -rf $(BUILD) $(LIB) tests/emu/librkfd_emu.so
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle emu clean

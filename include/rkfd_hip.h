@@ -1,0 +1,83 @@
+/* rkfd_hip.h - C ABI of the MI355X (gfx950) batched rkFDUpdate path.
+ *
+ * Plain C: pointers, sizes and an opaque handle only (no torch / C++ types), so the
+ * reference's C host code - or any FFI - can bind it.  Each entry point names the
+ * reference interface it stands in for.  One process drives one GPU; a batch holds B
+ * independent copies ("instances") of one world (all chains registered in one rkFD).
+ *
+ * Layout of every per-instance array handed across this boundary: instance-major,
+ * x[b*stride + j] (b = instance).  Host pointers unless the name says "Dev".
+ *
+ * Every function returns 0 on success and a negative value on failure;
+ * rkfdHipLastError() then describes the failure.  Without a usable GPU / kernel image
+ * the calls FAIL (there is no CPU fallback).
+ */
+#ifndef RKFD_HIP_H
+#define RKFD_HIP_H
+
+#include "rkfd_model.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rkfdBatch rkfdBatch;
+
+/* number of visible HIP devices (0 when none) */
+int rkfdHipDeviceCount(void);
+const char *rkfdHipLastError(void);
+
+/* Creates device state for `batch` instances of world `m` on `device`.
+ * Replaces, for the whole batch: rkFDCreate + rkFDChainReg* + rkFDUpdateInit's allocations
+ * (reference src/rkfd_sim.c:32-54,188-235,552-558; rkFDCDUpdateInit src/rkfd_cd.c:22-31;
+ * plugin _init src/rkfd_mlcp.c:312-325).  max_rigid = capacity of rigid contact vertices
+ * solved per instance (3*max_rigid <= 64); exceeding it at run time is reported as an error
+ * by rkfdBatchStatus. */
+rkfdBatch *rkfdBatchCreate(const rkfdModel *m, int batch, int device, int max_rigid);
+void rkfdBatchDestroy(rkfdBatch *b);
+
+int rkfdBatchSize(const rkfdBatch *b);
+int rkfdBatchDof(const rkfdBatch *b);
+
+/* rkFDChainSetDis / rkFDChainSetVel (reference src/rkfd_sim.c:277-287), all instances at once:
+ * dis, vel are [batch][ndof] */
+int rkfdBatchSetState(rkfdBatch *b, const double *dis, const double *vel);
+/* fd->dis, fd->vel, fd->acc after rkFDUpdate (reference include/roki_fd/rkfd_sim.h:49-50); any may be NULL */
+int rkfdBatchGetState(rkfdBatch *b, double *dis, double *vel, double *acc);
+/* rkJointMotorSetInput on every link (reference example/chain/arm_box_test.c:21): [batch][nlink] */
+int rkfdBatchSetMotorInput(rkfdBatch *b, const double *input);
+/* contact-vertex state rkCDVert{type,_ref} and force f per candidate vertex
+ * (consumed at reference src/rkfd_util.c:256-263, src/rkfd_mlcp.c:263-279): [batch][ncand], [batch][ncand*3] */
+int rkfdBatchGetContact(rkfdBatch *b, int *active, int *type, double *ref, double *f);
+int rkfdBatchSetContact(rkfdBatch *b, const int *active, const int *type, const double *ref);
+/* joint friction pivots rkJointFrictionPivot{type,prev_trq} (reference src/rkfd_util.c:289-311): [batch][nlink] */
+int rkfdBatchGetPivot(rkfdBatch *b, int *type, double *prev_trq);
+int rkfdBatchSetPivot(rkfdBatch *b, const int *type, const double *prev_trq);
+
+/* rkFDUpdateInit's committing evaluation _rkFDUpdateRef (reference src/rkfd_sim.c:542-549,556).
+ * stream: hipStream_t (NULL = default stream).  Asynchronous. */
+int rkfdBatchUpdateInit(rkfdBatch *b, void *stream);
+/* nsteps x rkFDUpdate (reference src/rkfd_sim.c:560-566) for every instance, fused in one launch.
+ * Asynchronous. */
+int rkfdBatchUpdate(rkfdBatch *b, int nsteps, void *stream);
+/* one evaluation _rkFDUpdate (doUpRef=0) or _rkFDUpdateRef (doUpRef=1) at the current state
+ * (reference src/rkfd_sim.c:533-549): fills acc and the contact forces.  Asynchronous. */
+int rkfdBatchEval(rkfdBatch *b, int doUpRef, void *stream);
+/* waits for the stream-ordered work, then reports device-side conditions:
+ * 0 ok, 1 rigid contact met with a solver that has no device path (Vert QP / Volume),
+ * 2 rigid-contact capacity exceeded; negative: HIP error */
+int rkfdBatchStatus(rkfdBatch *b, void *stream);
+
+/* device pointers to the live state ([batch][ndof] doubles), for zero-copy consumers
+ * (e.g. an RCCL all-gather of final states) */
+double *rkfdBatchDevDis(rkfdBatch *b);
+double *rkfdBatchDevVel(rkfdBatch *b);
+double *rkfdBatchDevAcc(rkfdBatch *b);
+
+/* kernel resource facts for measurement: LDS bytes per instance, grid size */
+int rkfdBatchLdsBytes(const rkfdBatch *b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""Generate the ZTK model files used by tests and bench (committed under models/).
+
+Provenance:
+  * box.ztk, box_small.ztk, floor.ztk, floor_hardsoft.ztk, contactinfo.ztk restate the
+    physical parameters of the reference's example models (reference example/model/*.ztk).
+  * chain30.ztk is SYNTHETIC (config 2): fixed base + 30 revolute links.
+  * humanoid26.ztk keeps the inertial parameters, frames, motors and the two sole shapes of
+    the reference's mighty.ztk (reference example/model/mighty.ztk:1690-1738,1766-2399) and
+    drops the visual meshes.  humanoid30.ztk is SYNTHETIC (config 3/4): humanoid26 plus a
+    4-link waist/neck branch whose inertial parameters are those of left_elbow_rotation.
+  * contact_elastic.ztk / contact_rigid.ztk: the single "ground body" entry of configs 3 / 4.
+The humanoid files need the reference checkout to regenerate (it only exists in the build
+container); all other files are generated from the constants below.
+
+usage: python models/gen_models.py [/root/reference]
+"""
+import os
+import re
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def w(name, text):
+    with open(os.path.join(HERE, name), "w") as f:
+        f.write(text)
+
+
+def box(name, d, wd, h, mass, inertia, stuff="body"):
+    return f"""[roki::chain]
+name : {name}
+
+[zeo::shape]
+type : box
+name : shape
+depth : {d}
+width : {wd}
+height : {h}
+
+[roki::link]
+name : link#00
+jointtype : float
+mass : {mass}
+stuff : {stuff}
+inertia : {{
+ {inertia}, 0, 0
+ 0, {inertia}, 0
+ 0, 0, {inertia}
+}}
+shape : shape
+"""
+
+
+FLOOR = """[roki::chain]
+name : floor
+
+[zeo::shape]
+type : box
+name : shape
+center : 0, 0, -0.2
+depth : 5.0
+width : 5.0
+height : 0.4
+
+[roki::link]
+name : link#00
+jointtype : fixed
+mass : 99.9
+stuff : ground
+inertia : {
+ 0.999, 0, 0
+ 0, 0.999, 0
+ 0, 0, 0.999
+}
+shape : shape
+"""
+
+FLOOR_HARDSOFT = """[roki::chain]
+name : floor
+
+[zeo::shape]
+type : box
+name : shape
+center : 0, 0, -0.2
+depth : 5.0
+width : 2.5
+height : 0.4
+
+[zeo::shape]
+type : box
+name : shape2
+center : 0, 0, -0.2
+depth : 5.0
+width : 2.5
+height : 0.4
+
+[roki::link]
+name : link#00
+jointtype : fixed
+mass : 99.9
+stuff : ground
+COM : { 0, 0, 0 }
+inertia : {
+ 0.999, 0, 0
+ 0, 0.999, 0
+ 0, 0, 0.999
+}
+frame : {
+ 1, 0, 0, 0
+ 0, 1, 0, 1.25
+ 0, 0, 1, 0
+}
+shape : shape
+
+[roki::link]
+name : link#01
+jointtype : fixed
+mass : 99.9
+stuff : soft
+COM : { 0, 0, 0 }
+inertia : {
+ 0.999, 0, 0
+ 0, 0.999, 0
+ 0, 0, 0.999
+}
+frame : {
+ 1, 0, 0, 0
+ 0, 1, 0, -2.5
+ 0, 0, 1, 0
+}
+parent : link#00
+shape : shape2
+"""
+
+
+def contact(entries):
+    out = []
+    for e in entries:
+        s = f"[roki::contact]\nbind : {e['bind']}\nstaticfriction : {e['sf']}\nkineticfriction : {e['kf']}\n"
+        if "k" in e:
+            s += f"compensation : {e['k']}\nrelaxation : {e['l']}\n"
+        else:
+            s += f"elasticity : {e['e']}\nviscosity : {e['v']}\n"
+        out.append(s)
+    return "\n".join(out)
+
+
+CONTACTINFO = [
+    dict(bind="ground body", sf=0.5, kf=0.3, k=1000.0, l=0.0001),
+    dict(bind="body body", sf=0.5, kf=0.3, k=1000.0, l=0.05),
+    dict(bind="wall wall", sf=0.5, kf=0.3, k=500.0, l=0.001),
+    dict(bind="wall ground", sf=0.5, kf=0.3, k=500.0, l=0.001),
+    dict(bind="ground crawler", sf=10.0, kf=7.0, k=100.0, l=10.0),
+    dict(bind="soft body", sf=0.5, kf=0.3, e=100.0, v=1.0),
+    dict(bind="soft crawler", sf=10.0, kf=7.0, e=1000.0, v=10.0),
+]
+
+
+def chain30():
+    """config 2: fixed base + 30 revolute links, axis alternating z / y, 0.1 m links along x."""
+    s = "[roki::chain]\nname : chain30\n\n"
+    s += "[roki::link]\nname : base\njointtype : fixed\nmass : 1.0\nstuff : body\n"
+    s += "inertia : {\n 1e-3, 0, 0\n 0, 1e-3, 0\n 0, 0, 1e-3\n}\n\n"
+    # a frame whose local z is the parent's y flips the rotation axis; applying it on every
+    # link alternates the world axis z, y, z, y ... at the zero configuration
+    for i in range(30):
+        parent = "base" if i == 0 else f"link#{i:02d}"
+        px = 0.0 if i == 0 else 0.1
+        if i == 0:
+            frame = f" 1, 0, 0, {px}\n 0, 1, 0, 0\n 0, 0, 1, 0\n"
+        elif i % 2 == 1:
+            frame = f" 1, 0, 0, {px}\n 0, 0, 1, 0\n 0, -1, 0, 0\n"
+        else:
+            frame = f" 1, 0, 0, {px}\n 0, 0, -1, 0\n 0, 1, 0, 0\n"
+        s += f"[roki::link]\nname : link#{i+1:02d}\njointtype : revolute\nmass : 1.0\nstuff : body\n"
+        s += "COM : { 0.05, 0, 0 }\n"
+        s += "inertia : {\n 1e-3, 0, 0\n 0, 8.8e-3, 0\n 0, 0, 8.8e-3\n}\n"
+        s += "frame : {\n" + frame + "}\n"
+        s += f"parent : {parent}\n\n"
+    return s
+
+
+def humanoid(ref_root):
+    src = os.path.join(ref_root, "example", "model", "mighty.ztk")
+    text = open(src).read()
+    # split into tagged sections
+    parts = re.split(r"(?m)^(?=\[)", text)
+    keep = []
+    for p in parts:
+        tag = p.split("]", 1)[0].strip("[") if p.startswith("[") else ""
+        if tag == "roki::chain":
+            keep.append("[roki::chain]\nname : humanoid26\n\n")
+        elif tag == "zeo::shape":
+            m = re.search(r"(?m)^name\s*:\s*(\S+)", p)
+            if m and m.group(1) in ("left_sole", "right_sole"):
+                body = "\n".join(l for l in p.splitlines() if not l.strip().startswith("optic") and not l.strip().startswith("%"))
+                keep.append(body.rstrip() + "\n\n")
+        elif tag == "roki::motor":
+            keep.append("\n".join(l for l in p.splitlines() if not l.strip().startswith("%")).rstrip() + "\n\n")
+        elif tag == "roki::link":
+            lines = []
+            for l in p.splitlines():
+                t = l.strip()
+                if t.startswith("%"):
+                    continue
+                if t.startswith("shape"):
+                    nm = t.split(":", 1)[1].strip()
+                    if nm not in ("left_sole", "right_sole"):
+                        continue
+                lines.append(l)
+            keep.append("\n".join(lines).rstrip() + "\n\n")
+        elif tag == "roki::chain::init":
+            keep.append("\n".join(l for l in p.splitlines() if not l.strip().startswith("%")).rstrip() + "\n")
+    h26 = "".join(keep)
+    header = ("% humanoid26: inertial parameters, frames, motors and sole shapes of the reference's\n"
+              "% example/model/mighty.ztk (visual meshes dropped).  Generated by models/gen_models.py.\n")
+    w("humanoid26.ztk", header + h26)
+
+    # humanoid30: + waist_yaw, waist_pitch, neck_yaw, neck_pitch (serial branch off body)
+    elbow = re.search(r"(?s)\[roki::link\]\nname: left_elbow_rotation.*?(?=\[roki::link\])", text).group(0)
+    mass = re.search(r"mass:\s*(\S+)", elbow).group(1)
+    com = re.search(r"COM:\s*(\{.*?\})", elbow).group(1)
+    inertia = re.search(r"(?s)inertia:\s*(\{.*?\})", elbow).group(1)
+    extra = []
+    frames = {
+        "waist_yaw":   (" 1, 0, 0, 0\n 0, 1, 0, 0\n 0, 0, 1, 0.05\n", "body"),
+        "waist_pitch": (" 1, 0, 0, 0\n 0, 0, 1, 0\n 0, -1, 0, 0.03\n", "waist_yaw"),
+        "neck_yaw":    (" 1, 0, 0, 0\n 0, 0, -1, 0.05\n 0, 1, 0, 0\n", "waist_pitch"),
+        "neck_pitch":  (" 1, 0, 0, 0\n 0, 0, 1, 0\n 0, -1, 0, 0.03\n", "neck_yaw"),
+    }
+    for nm, (fr, par) in frames.items():
+        extra.append(
+            f"[roki::link]\nname: {nm}\njointtype: revolute\nmax: 90\nmin:-90\nstiffness: 0.0\nviscosity: 0.0\n"
+            f"coulomb: 1.0\nstaticfriction: 1.2\nmotor: RE-max17\nmass: {mass}\nstuff: body\nCOM: {com}\n"
+            f"inertia: {inertia}\nframe: {{\n{fr}}}\nparent: {par}\n\n")
+    h30 = h26.replace("name : humanoid26", "name : humanoid30")
+    idx = h30.index("[roki::chain::init]")
+    h30 = h30[:idx] + "".join(extra) + h30[idx:]
+    header30 = ("% humanoid30 (SYNTHETIC, SURVEY.md 8d config 3): humanoid26 plus a 4-link waist/neck branch\n"
+                "% (inertial parameters of left_elbow_rotation).  Generated by models/gen_models.py.\n")
+    w("humanoid30.ztk", header30 + h30)
+
+
+def main():
+    w("box.ztk", box("box", 0.1, 0.1, 0.1, 0.5, "8.33e-4"))
+    w("box_small.ztk", box("box_small", 0.05, 0.10, 0.05, 0.125, "5.208333333e-05"))
+    w("floor.ztk", FLOOR)
+    w("floor_hardsoft.ztk", FLOOR_HARDSOFT)
+    w("contactinfo.ztk", contact(CONTACTINFO))
+    w("contact_elastic.ztk", contact([dict(bind="ground body", sf=0.5, kf=0.3, e=1000.0, v=10.0)]))
+    w("contact_rigid.ztk", contact([dict(bind="ground body", sf=0.5, kf=0.3, k=1000.0, l=0.0001)]))
+    w("chain30.ztk", chain30())
+    ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+    if os.path.isdir(ref):
+        humanoid(ref)
+    else:
+        print("reference checkout not found: humanoid26/30.ztk left untouched")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,134 @@
+"""ctypes wrapper of the CPU oracle (oracle/rkfd_oracle.c).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the
+product package."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_build", "librkfd_oracle.so")
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-C", HERE], check=True, stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        L.rkfdOracleCreate.argtypes = [vp]; L.rkfdOracleCreate.restype = vp
+        L.rkfdOracleDestroy.argtypes = [vp]
+        L.rkfdOracleSetState.argtypes = [vp, vp, vp]
+        L.rkfdOracleGetState.argtypes = [vp, vp, vp, vp]
+        L.rkfdOracleSetMotorInput.argtypes = [vp, vp]
+        L.rkfdOracleTime.argtypes = [vp]; L.rkfdOracleTime.restype = C.c_double
+        L.rkfdOracleGetContact.argtypes = [vp, vp, vp, vp, vp]
+        L.rkfdOracleSetContact.argtypes = [vp, vp, vp, vp]
+        L.rkfdOracleGetPivot.argtypes = [vp, vp, vp]
+        L.rkfdOracleSetPivot.argtypes = [vp, vp, vp]
+        L.rkfdOracleUpdateInit.argtypes = [vp]
+        L.rkfdOracleUpdate.argtypes = [vp]
+        L.rkfdOracleEval.argtypes = [vp, C.c_int]
+        L.rkfdOracleGetLinkFrames.argtypes = [vp, vp, vp]
+        L.rkfdOracleGetLinkVelAcc.argtypes = [vp, vp, vp]
+        L.rkfdOracleGetMLCP.argtypes = [vp, vp, vp, vp, C.c_int]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    """One simulated world (= one rkFD of the reference) on the CPU."""
+
+    def __init__(self, model_ptr):
+        self._L = lib()
+        self._model = model_ptr            # keep the owner alive
+        m = model_ptr.contents
+        self.ndof, self.nlink, self.ncand = m.ndof, m.nlink, m.ncand
+        self._o = self._L.rkfdOracleCreate(C.cast(model_ptr, C.c_void_p))
+
+    def close(self):
+        if getattr(self, "_o", None):
+            self._L.rkfdOracleDestroy(self._o)
+            self._o = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_state(self, dis, vel):
+        dis = np.ascontiguousarray(dis, dtype=np.float64); vel = np.ascontiguousarray(vel, dtype=np.float64)
+        assert dis.size == self.ndof and vel.size == self.ndof
+        self._L.rkfdOracleSetState(self._o, _p(dis), _p(vel))
+
+    def get_state(self):
+        d = np.empty(self.ndof); v = np.empty(self.ndof); a = np.empty(self.ndof)
+        self._L.rkfdOracleGetState(self._o, _p(d), _p(v), _p(a))
+        return d, v, a
+
+    def set_motor_input(self, inp):
+        inp = np.ascontiguousarray(inp, dtype=np.float64)
+        assert inp.size == self.nlink
+        self._L.rkfdOracleSetMotorInput(self._o, _p(inp))
+
+    def get_contact(self):
+        act = np.empty(self.ncand, dtype=np.int32); typ = np.empty(self.ncand, dtype=np.int32)
+        ref = np.empty((self.ncand, 3)); f = np.empty((self.ncand, 3))
+        self._L.rkfdOracleGetContact(self._o, _p(act), _p(typ), _p(ref), _p(f))
+        return act, typ, ref, f
+
+    def set_contact(self, act, typ, ref):
+        act = np.ascontiguousarray(act, dtype=np.int32); typ = np.ascontiguousarray(typ, dtype=np.int32)
+        ref = np.ascontiguousarray(ref, dtype=np.float64)
+        self._L.rkfdOracleSetContact(self._o, _p(act), _p(typ), _p(ref))
+
+    def get_pivot(self):
+        typ = np.empty(self.nlink, dtype=np.int32); prev = np.empty(self.nlink)
+        self._L.rkfdOracleGetPivot(self._o, _p(typ), _p(prev))
+        return typ, prev
+
+    def set_pivot(self, typ, prev):
+        typ = np.ascontiguousarray(typ, dtype=np.int32); prev = np.ascontiguousarray(prev, dtype=np.float64)
+        self._L.rkfdOracleSetPivot(self._o, _p(typ), _p(prev))
+
+    def update_init(self):
+        self._L.rkfdOracleUpdateInit(self._o)
+
+    def update(self):
+        return self._L.rkfdOracleUpdate(self._o)
+
+    def eval(self, do_up_ref=False):
+        return self._L.rkfdOracleEval(self._o, 1 if do_up_ref else 0)
+
+    @property
+    def time(self):
+        return self._L.rkfdOracleTime(self._o)
+
+    def link_frames(self):
+        R = np.empty((self.nlink, 3, 3)); p = np.empty((self.nlink, 3))
+        self._L.rkfdOracleGetLinkFrames(self._o, _p(R), _p(p))
+        return R, p
+
+    def link_vel_acc(self):
+        v = np.empty((self.nlink, 6)); a = np.empty((self.nlink, 6))
+        self._L.rkfdOracleGetLinkVelAcc(self._o, _p(v), _p(a))
+        return v, a
+
+    def mlcp(self):
+        cap = 3 * max(self.ncand, 1)
+        a = np.zeros(cap * cap); b = np.zeros(cap); f = np.zeros(cap)
+        nc = self._L.rkfdOracleGetMLCP(self._o, _p(a), _p(b), _p(f), cap)
+        n3 = 3 * nc
+        return nc, a[:n3 * n3].reshape(n3, n3).copy(), b[:n3].copy(), f[:n3].copy()

@@ -1,0 +1,1056 @@
+/* rkfd_oracle.c - CPU restatement of the rkFDUpdate hot path (see rkfd_oracle.h:
+ * TEST INFRASTRUCTURE ONLY, PARITY UNPINNED).
+ *
+ * Control flow follows the reference file by file:
+ *   step driver ............ reference src/rkfd_sim.c:290-302,445-566
+ *   contact bucketing ...... reference src/rkfd_cd.c:33-49
+ *   relative vel/acc, friction cone clamp, wrench push, joint friction
+ *                            reference src/rkfd_util.c (all)
+ *   penalty force .......... reference src/rkfd_penalty.c:11-31
+ *   MLCP / PGS ............. reference src/rkfd_mlcp.c (all)
+ * Arithmetic the reference delegates to un-vendored RoKi / ZM / Zeo is restated
+ * from the published algorithms, in RoKi's conventions (link-local frames,
+ * (linear, angular) 6-D ordering, classical link accelerations, revolute /
+ * prismatic axis = local z, float joint = position + angle-axis in the joint
+ * origin frame).  Every such choice is tagged [UNVERIFIED-DEP] in DESIGN.md.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include "rkfd_oracle.h"
+
+#define TOL RKFD_TOL
+#define is_tiny(x) ( fabs(x) < TOL )
+
+/* ------------------------------------------------------------------------ */
+/* small vector / matrix helpers (3-D, row-major 3x3) */
+static void v3_zero(double *a){ a[0]=a[1]=a[2]=0; }
+static void v3_copy(const double *a, double *b){ b[0]=a[0]; b[1]=a[1]; b[2]=a[2]; }
+static void v3_add(const double *a, const double *b, double *c){ c[0]=a[0]+b[0]; c[1]=a[1]+b[1]; c[2]=a[2]+b[2]; }
+static void v3_sub(const double *a, const double *b, double *c){ c[0]=a[0]-b[0]; c[1]=a[1]-b[1]; c[2]=a[2]-b[2]; }
+static void v3_cat(double *a, double k, const double *b){ a[0]+=k*b[0]; a[1]+=k*b[1]; a[2]+=k*b[2]; }
+static void v3_mul(const double *a, double k, double *c){ c[0]=k*a[0]; c[1]=k*a[1]; c[2]=k*a[2]; }
+static double v3_dot(const double *a, const double *b){ return a[0]*b[0]+a[1]*b[1]+a[2]*b[2]; }
+static double v3_norm(const double *a){ return sqrt( v3_dot(a,a) ); }
+static void v3_cross(const double *a, const double *b, double *c)
+{
+  double x = a[1]*b[2]-a[2]*b[1], y = a[2]*b[0]-a[0]*b[2], z = a[0]*b[1]-a[1]*b[0];
+  c[0]=x; c[1]=y; c[2]=z;
+}
+static void m3_mulv(const double *m, const double *v, double *r)
+{
+  double x = m[0]*v[0]+m[1]*v[1]+m[2]*v[2], y = m[3]*v[0]+m[4]*v[1]+m[5]*v[2], z = m[6]*v[0]+m[7]*v[1]+m[8]*v[2];
+  r[0]=x; r[1]=y; r[2]=z;
+}
+static void m3_tmulv(const double *m, const double *v, double *r)
+{
+  double x = m[0]*v[0]+m[3]*v[1]+m[6]*v[2], y = m[1]*v[0]+m[4]*v[1]+m[7]*v[2], z = m[2]*v[0]+m[5]*v[1]+m[8]*v[2];
+  r[0]=x; r[1]=y; r[2]=z;
+}
+static void m3_mul(const double *a, const double *b, double *c)
+{
+  double t[9]; int i, j;
+  for( i=0; i<3; i++ ) for( j=0; j<3; j++ )
+    t[3*i+j] = a[3*i]*b[j] + a[3*i+1]*b[3+j] + a[3*i+2]*b[6+j];
+  memcpy( c, t, sizeof(t) );
+}
+static void m3_ident(double *m){ memset( m, 0, sizeof(double)*9 ); m[0]=m[4]=m[8]=1; }
+
+/* rotation matrix from an angle-axis vector (Zeo zMat3DFromAA) */
+static void m3_from_aa(const double *aa, double *m)
+{
+  double th = v3_norm( aa ), s, c, k, x, y, z;
+  if( is_tiny( th ) ){ m3_ident( m ); return; }
+  s = sin(th); c = cos(th); k = 1-c;
+  x = aa[0]/th; y = aa[1]/th; z = aa[2]/th;
+  m[0] = c+k*x*x;   m[1] = k*x*y-s*z; m[2] = k*x*z+s*y;
+  m[3] = k*x*y+s*z; m[4] = c+k*y*y;   m[5] = k*y*z-s*x;
+  m[6] = k*x*z-s*y; m[7] = k*y*z+s*x; m[8] = c+k*z*z;
+}
+/* angle-axis vector of a rotation matrix (Zeo zMat3DToAA) */
+static void m3_to_aa(const double *m, double *aa)
+{
+  double l[3], a, th;
+  l[0] = m[7]-m[5]; l[1] = m[2]-m[6]; l[2] = m[3]-m[1];
+  a = v3_norm( l );
+  th = atan2( a, m[0]+m[4]+m[8]-1.0 );
+  if( is_tiny( a ) ){ v3_zero( aa ); return; }
+  v3_mul( l, th/a, aa );
+}
+
+/* orthonormal complement of a unit normal: tangent 1 from the coordinate axis with the
+ * smallest |component| (first on ties), tangent 2 = n x t1.  [UNVERIFIED-DEP] */
+static void ortho_space(const double *n, double *t1, double *t2)
+{
+  int k = 0; double e[3] = {0,0,0}, d, l;
+  if( fabs(n[1]) < fabs(n[k]) ) k = 1;
+  if( fabs(n[2]) < fabs(n[k]) ) k = 2;
+  e[k] = 1.0;
+  d = v3_dot( e, n );
+  t1[0] = e[0]-d*n[0]; t1[1] = e[1]-d*n[1]; t1[2] = e[2]-d*n[2];
+  l = v3_norm( t1 );
+  t1[0] /= l; t1[1] /= l; t1[2] /= l;
+  v3_cross( n, t1, t2 );
+}
+
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  double Ra[9], pa[3];   /* adjacent frame: link w.r.t. parent */
+  double Rj[9];          /* float joint: rotation of the joint displacement */
+  double R[9], p[3];     /* world frame */
+  double v[6];           /* velocity, link frame (lin, ang) */
+  double a[6];           /* classical acceleration, link frame (lin, ang) */
+  double gam[6];         /* velocity-product acceleration */
+  double M6[36];         /* spatial inertia about link origin, link frame */
+  double IA[36];         /* articulated inertia */
+  double U[6], D;        /* 1-DoF joints: IA S, S'IA S + motor inertia */
+  double L6[36];         /* float joints: Cholesky factor of IA */
+  double tau, tf, jm;    /* joint torque, friction torque, motor inertia (1-DoF) */
+  double qd, q;          /* 1-DoF joint rate / displacement */
+  double qdf[6];         /* float joint rate */
+} Link;
+
+struct rkfdOracle {
+  const rkfdModel *m;
+  int nl, n, ncand;
+  double t;
+  double *dis, *vel, *acc, *motor_in;
+  int *piv_type; double *piv_prev;
+  int *cv_active, *cv_type; double *cv_ref, *cv_f;
+  Link *lk;
+  /* bias arrays (SoA so that save / restore are memcpy) */
+  double *beta0, *ext, *pA, *u, *contrib, *csum;      /* u: 6 per link (1-DoF uses [0]) */
+  double *s_beta0, *s_pA, *s_u, *s_contrib, *s_csum;  /* saved by "SaveABIAccBias" */
+  /* per-candidate evaluation data */
+  double *cx, *crefw, *cnorm, *caxis, *cpro, *cvel;
+  int *clinkA, *clinkB, *cci;
+  int nel, nrg; int *el, *rg;
+  /* MLCP workspace */
+  int mcap; double *ma, *mb, *mt, *mf;
+  int last_nc;
+  /* RKG workspace */
+  double *k_v[4], *k_a[4], *xd, *xv, *tv, *ta;
+};
+
+/* ------------------------------------------------------------------------ */
+static void *zalloc(size_t n){ return calloc( n ? n : 1, 1 ); }
+
+rkfdOracle *rkfdOracleCreate(const rkfdModel *m)
+{
+  rkfdOracle *o = (rkfdOracle *)zalloc( sizeof(rkfdOracle) );
+  int i, j, nl = m->nlink, n = m->ndof, nc = m->ncand, k;
+
+  o->m = m; o->nl = nl; o->n = n; o->ncand = nc;
+  o->dis = zalloc( sizeof(double)*n ); o->vel = zalloc( sizeof(double)*n ); o->acc = zalloc( sizeof(double)*n );
+  o->motor_in = zalloc( sizeof(double)*nl );
+  o->piv_type = zalloc( sizeof(int)*nl ); o->piv_prev = zalloc( sizeof(double)*nl );
+  o->cv_active = zalloc( sizeof(int)*nc ); o->cv_type = zalloc( sizeof(int)*nc );
+  o->cv_ref = zalloc( sizeof(double)*3*nc ); o->cv_f = zalloc( sizeof(double)*3*nc );
+  o->lk = zalloc( sizeof(Link)*nl );
+  o->beta0 = zalloc( sizeof(double)*6*nl ); o->ext = zalloc( sizeof(double)*6*nl );
+  o->pA = zalloc( sizeof(double)*6*nl ); o->u = zalloc( sizeof(double)*6*nl );
+  o->contrib = zalloc( sizeof(double)*6*nl ); o->csum = zalloc( sizeof(double)*6*nl );
+  o->s_beta0 = zalloc( sizeof(double)*6*nl ); o->s_pA = zalloc( sizeof(double)*6*nl ); o->s_u = zalloc( sizeof(double)*6*nl );
+  o->s_contrib = zalloc( sizeof(double)*6*nl ); o->s_csum = zalloc( sizeof(double)*6*nl );
+  o->cx = zalloc( sizeof(double)*3*nc ); o->crefw = zalloc( sizeof(double)*3*nc ); o->cnorm = zalloc( sizeof(double)*3*nc );
+  o->caxis = zalloc( sizeof(double)*9*nc ); o->cpro = zalloc( sizeof(double)*3*nc ); o->cvel = zalloc( sizeof(double)*3*nc );
+  o->clinkA = zalloc( sizeof(int)*nc ); o->clinkB = zalloc( sizeof(int)*nc ); o->cci = zalloc( sizeof(int)*nc );
+  o->el = zalloc( sizeof(int)*nc ); o->rg = zalloc( sizeof(int)*nc );
+  o->mcap = nc;
+  o->ma = zalloc( sizeof(double)*9*nc*nc ); o->mb = zalloc( sizeof(double)*3*nc );
+  o->mt = zalloc( sizeof(double)*3*nc ); o->mf = zalloc( sizeof(double)*3*nc );
+  for( k=0; k<4; k++ ){ o->k_v[k] = zalloc( sizeof(double)*n ); o->k_a[k] = zalloc( sizeof(double)*n ); }
+  o->xd = zalloc( sizeof(double)*n ); o->xv = zalloc( sizeof(double)*n );
+  o->tv = zalloc( sizeof(double)*n ); o->ta = zalloc( sizeof(double)*n );
+
+  /* constant spatial inertia about the link origin, (lin, ang) ordering:
+   *   [ m 1      -m [c]x ]
+   *   [ m [c]x    Ic - m [c]x [c]x ]                                            */
+  for( i=0; i<nl; i++ ){
+    double ms = m->mass[i]; const double *c = &m->com[3*i], *Ic = &m->inertia[9*i];
+    double cx[9] = { 0,-c[2],c[1], c[2],0,-c[0], -c[1],c[0],0 }, cc[9];
+    double *M = o->lk[i].M6;
+    m3_mul( cx, cx, cc );
+    for( j=0; j<3; j++ ) for( k=0; k<3; k++ ){
+      M[6*j+k]       = ( j==k ? ms : 0.0 );
+      M[6*j+3+k]     = -ms*cx[3*j+k];
+      M[6*(3+j)+k]   =  ms*cx[3*j+k];
+      M[6*(3+j)+3+k] = Ic[3*j+k] - ms*cc[3*j+k];
+    }
+    /* friction pivots start sticking (reference src/rkfd_sim.c:157-175) */
+    o->piv_type[i] = RKFD_SF; o->piv_prev[i] = 0;
+  }
+  return o;
+}
+
+void rkfdOracleDestroy(rkfdOracle *o)
+{
+  int k;
+  if( !o ) return;
+  free( o->dis ); free( o->vel ); free( o->acc ); free( o->motor_in ); free( o->piv_type ); free( o->piv_prev );
+  free( o->cv_active ); free( o->cv_type ); free( o->cv_ref ); free( o->cv_f ); free( o->lk );
+  free( o->beta0 ); free( o->ext ); free( o->pA ); free( o->u ); free( o->contrib ); free( o->csum );
+  free( o->s_beta0 ); free( o->s_pA ); free( o->s_u ); free( o->s_contrib ); free( o->s_csum );
+  free( o->cx ); free( o->crefw ); free( o->cnorm ); free( o->caxis ); free( o->cpro ); free( o->cvel );
+  free( o->clinkA ); free( o->clinkB ); free( o->cci ); free( o->el ); free( o->rg );
+  free( o->ma ); free( o->mb ); free( o->mt ); free( o->mf );
+  for( k=0; k<4; k++ ){ free( o->k_v[k] ); free( o->k_a[k] ); }
+  free( o->xd ); free( o->xv ); free( o->tv ); free( o->ta );
+  free( o );
+}
+
+void rkfdOracleSetState(rkfdOracle *o, const double *dis, const double *vel)
+{
+  memcpy( o->dis, dis, sizeof(double)*o->n );
+  memcpy( o->vel, vel, sizeof(double)*o->n );
+}
+void rkfdOracleGetState(const rkfdOracle *o, double *dis, double *vel, double *acc)
+{
+  if( dis ) memcpy( dis, o->dis, sizeof(double)*o->n );
+  if( vel ) memcpy( vel, o->vel, sizeof(double)*o->n );
+  if( acc ) memcpy( acc, o->acc, sizeof(double)*o->n );
+}
+void rkfdOracleSetMotorInput(rkfdOracle *o, const double *input){ memcpy( o->motor_in, input, sizeof(double)*o->nl ); }
+double rkfdOracleTime(const rkfdOracle *o){ return o->t; }
+
+void rkfdOracleGetContact(const rkfdOracle *o, int *active, int *type, double *ref, double *f)
+{
+  if( active ) memcpy( active, o->cv_active, sizeof(int)*o->ncand );
+  if( type ) memcpy( type, o->cv_type, sizeof(int)*o->ncand );
+  if( ref ) memcpy( ref, o->cv_ref, sizeof(double)*3*o->ncand );
+  if( f ) memcpy( f, o->cv_f, sizeof(double)*3*o->ncand );
+}
+void rkfdOracleSetContact(rkfdOracle *o, const int *active, const int *type, const double *ref)
+{
+  memcpy( o->cv_active, active, sizeof(int)*o->ncand );
+  memcpy( o->cv_type, type, sizeof(int)*o->ncand );
+  memcpy( o->cv_ref, ref, sizeof(double)*3*o->ncand );
+}
+void rkfdOracleGetPivot(const rkfdOracle *o, int *type, double *prev_trq)
+{
+  if( type ) memcpy( type, o->piv_type, sizeof(int)*o->nl );
+  if( prev_trq ) memcpy( prev_trq, o->piv_prev, sizeof(double)*o->nl );
+}
+void rkfdOracleSetPivot(rkfdOracle *o, const int *type, const double *prev_trq)
+{
+  memcpy( o->piv_type, type, sizeof(int)*o->nl );
+  memcpy( o->piv_prev, prev_trq, sizeof(double)*o->nl );
+}
+void rkfdOracleGetLinkFrames(const rkfdOracle *o, double *R, double *p)
+{
+  int i;
+  for( i=0; i<o->nl; i++ ){ memcpy( R+9*i, o->lk[i].R, sizeof(double)*9 ); memcpy( p+3*i, o->lk[i].p, sizeof(double)*3 ); }
+}
+void rkfdOracleGetLinkVelAcc(const rkfdOracle *o, double *vel, double *acc)
+{
+  int i;
+  for( i=0; i<o->nl; i++ ){
+    if( vel ) memcpy( vel+6*i, o->lk[i].v, sizeof(double)*6 );
+    if( acc ) memcpy( acc+6*i, o->lk[i].a, sizeof(double)*6 );
+  }
+}
+int rkfdOracleGetMLCP(const rkfdOracle *o, double *a, double *b, double *f, int cap)
+{
+  int n3 = 3*o->last_nc;
+  if( n3 > cap ) return -1;
+  if( a ) memcpy( a, o->ma, sizeof(double)*n3*n3 );
+  if( b ) memcpy( b, o->mb, sizeof(double)*n3 );
+  if( f ) memcpy( f, o->mf, sizeof(double)*n3 );
+  return o->last_nc;
+}
+
+/* ------------------------------------------------------------------------ */
+/* _rkFDConnectJointState (reference src/rkfd_sim.c:290-302):
+ * rkChainFK + rkChainSetJointVelAll + rkChainUpdateVel [RoKi, restated] */
+static void connect_state(rkfdOracle *o, const double *dis, const double *vel)
+{
+  const rkfdModel *m = o->m;
+  int i;
+  for( i=0; i<o->nl; i++ ){
+    Link *l = &o->lk[i];
+    const double *Ro = &m->org[12*i], *po = Ro+9;
+    const double *q = dis + m->dofoff[i], *qd = vel + m->dofoff[i];
+    int par = m->parent[i];
+    double wp[3], vp[3], t[3];
+
+    /* adjacent frame = org frame * joint transform */
+    switch( m->jtype[i] ){
+    case RKFD_JOINT_REVOL: {
+      double s = sin(q[0]), c = cos(q[0]);
+      double Rz[9] = { c,-s,0, s,c,0, 0,0,1 };
+      m3_mul( Ro, Rz, l->Ra ); v3_copy( po, l->pa );
+      l->q = q[0]; l->qd = qd[0];
+    } break;
+    case RKFD_JOINT_PRISM: {
+      double z[3] = { Ro[2], Ro[5], Ro[8] };
+      memcpy( l->Ra, Ro, sizeof(double)*9 );
+      v3_copy( po, l->pa ); v3_cat( l->pa, q[0], z );
+      l->q = q[0]; l->qd = qd[0];
+    } break;
+    case RKFD_JOINT_FLOAT: {
+      m3_from_aa( q+3, l->Rj );
+      m3_mul( Ro, l->Rj, l->Ra );
+      m3_mulv( Ro, q, t ); v3_add( po, t, l->pa );
+      memcpy( l->qdf, qd, sizeof(double)*6 );
+    } break;
+    default:
+      memcpy( l->Ra, Ro, sizeof(double)*9 ); v3_copy( po, l->pa );
+    }
+    /* world frame and link-frame velocity from the parent */
+    if( par < 0 ){
+      memcpy( l->R, l->Ra, sizeof(double)*9 ); v3_copy( l->pa, l->p );
+      memset( l->v, 0, sizeof(double)*6 );
+      v3_zero( wp );
+    } else {
+      Link *pl = &o->lk[par];
+      m3_mul( pl->R, l->Ra, l->R );
+      m3_mulv( pl->R, l->pa, t ); v3_add( pl->p, t, l->p );
+      /* v = Ra'( v_p + w_p x pa ), w = Ra' w_p */
+      v3_cross( pl->v+3, l->pa, t ); v3_add( pl->v, t, vp );
+      m3_tmulv( l->Ra, vp, l->v );
+      m3_tmulv( l->Ra, pl->v+3, l->v+3 );
+      v3_copy( pl->v+3, wp );
+    }
+    /* velocity-product acceleration (classical accelerations):
+     *   lin: Ra'( w_p x ( w_p x pa ) ) (+ joint Coriolis), ang: w' x (joint angular rate) */
+    {
+      double wpa[3], cen[3], wl[3];
+      v3_cross( wp, l->pa, wpa ); v3_cross( wp, wpa, cen );
+      m3_tmulv( l->Ra, cen, l->gam );
+      v3_zero( l->gam+3 );
+      v3_copy( l->v+3, wl ); /* w' = Ra' w_p, before the joint's own rate is added */
+      switch( m->jtype[i] ){
+      case RKFD_JOINT_REVOL: {
+        double zq[3] = { 0, 0, l->qd };
+        v3_cross( wl, zq, l->gam+3 );
+        l->v[5] += l->qd;
+      } break;
+      case RKFD_JOINT_PRISM: {
+        double zq[3] = { 0, 0, l->qd }, c2[3];
+        v3_cross( wl, zq, c2 ); v3_cat( l->gam, 2.0, c2 );
+        l->v[2] += l->qd;
+      } break;
+      case RKFD_JOINT_FLOAT: {
+        /* joint rate (v_j, w_j) is expressed in the org frame; w_p in org frame = Ro' w_p */
+        double wo[3], c2[3], c3[3], vj[3], wj[3];
+        m3_tmulv( Ro, wp, wo );
+        v3_cross( wo, l->qdf, c2 );   m3_tmulv( l->Rj, c2, c3 ); v3_cat( l->gam, 2.0, c3 );
+        v3_cross( wo, l->qdf+3, c2 ); m3_tmulv( l->Rj, c2, l->gam+3 );
+        m3_tmulv( l->Rj, l->qdf, vj );   v3_add( l->v, vj, l->v );
+        m3_tmulv( l->Rj, l->qdf+3, wj ); v3_add( l->v+3, wj, l->v+3 );
+      } break;
+      default: break;
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* motor model [RoKi rk_motor_dc / rk_motor_trq, restated; UNVERIFIED-DEP] */
+static double clampd(double x, double lo, double hi){ return x < lo ? lo : ( x > hi ? hi : x ); }
+static double motor_inertia(const rkfdModel *m, int i)
+{
+  return m->mtype[i] == RKFD_MOTOR_DC ? m->mot_inertia[i]*m->mot_gear[i]*m->mot_gear[i] : 0.0;
+}
+static double motor_input_trq(const rkfdModel *m, int i, double in)
+{
+  switch( m->mtype[i] ){
+  case RKFD_MOTOR_DC:  return m->mot_admit[i]*m->mot_gear[i]*m->mot_k[i]*clampd( in, m->mot_vmin[i], m->mot_vmax[i] );
+  case RKFD_MOTOR_TRQ: return clampd( in, m->mot_vmin[i], m->mot_vmax[i] );
+  default: return 0.0;
+  }
+}
+static double motor_registance(const rkfdModel *m, int i, double qd)
+{
+  double gk = m->mot_gear[i]*m->mot_k[i];
+  return m->mtype[i] == RKFD_MOTOR_DC ? m->mot_admit[i]*gk*gk*qd : 0.0;
+}
+static double sgn(double x){ return x > 0 ? 1.0 : ( x < 0 ? -1.0 : 0.0 ); }
+
+/* rkFDKineticFrictionWeight (reference src/rkfd_util.c:193-196) */
+static double kf_weight(double w, double fs){ return 1.0 - exp( -1.0*w*fs ); }
+
+/* rkFDJointFriction / rkFDJointFrictionRevolDC (reference src/rkfd_util.c:318-387) */
+static void joint_friction(rkfdOracle *o, int doUpRef)
+{
+  const rkfdModel *m = o->m;
+  int i;
+  for( i=0; i<o->nl; i++ ){
+    Link *l = &o->lk[i];
+    int dof = rkfd_joint_dof( m->jtype[i] );
+    if( dof != 1 ) continue; /* rkFDJointFrictionAll on float/fixed joints: their kinetic friction is zero */
+    if( m->mtype[i] != RKFD_MOTOR_DC ) continue; /* 1-DoF non-DC joints: friction is left untouched (0) */
+    {
+      double tf, fmax;
+      tf = motor_inertia( m, i ) * ( -l->qd / m->dt );
+      tf -= motor_input_trq( m, i, o->motor_in[i] );
+      tf += motor_registance( m, i, l->qd );
+      tf += o->piv_prev[i];
+      if( o->piv_type[i] == RKFD_SF )
+        fmax = m->sfric[i];
+      else /* rkJointGetKFriction: rest torque -k q - c qd - coulomb sgn(qd) */
+        fmax = -m->stiff[i]*l->q - m->visc[i]*l->qd - m->coulomb[i]*sgn( l->qd );
+      fmax = fabs( fmax );
+      if( fabs( tf ) > fmax ){
+        tf = tf > 0 ? fmax : -fmax;
+        if( doUpRef ) o->piv_type[i] = RKFD_KF;
+      } else {
+        if( doUpRef ) o->piv_type[i] = RKFD_SF;
+      }
+      l->tf = tf;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* 6-D transforms between a link and its parent, classical accelerations:
+ *   X a  = ( Ra'( a_lin + a_ang x pa ), Ra' a_ang )
+ *   X' f = ( Ra f_lin, Ra f_ang + pa x ( Ra f_lin ) )                          */
+static void xform_acc(const Link *l, const double *ap, double *r)
+{
+  double t[3], s[3];
+  v3_cross( ap+3, l->pa, t ); v3_add( ap, t, s );
+  m3_tmulv( l->Ra, s, r );
+  m3_tmulv( l->Ra, ap+3, r+3 );
+}
+static void xform_force_T(const Link *l, const double *f, double *r)
+{
+  double fl[3], fa[3], t[3];
+  m3_mulv( l->Ra, f, fl ); m3_mulv( l->Ra, f+3, fa );
+  v3_cross( l->pa, fl, t );
+  v3_copy( fl, r ); v3_add( fa, t, r+3 );
+}
+static void m6_mulv(const double *M, const double *v, double *r)
+{
+  int i, j; double t[6];
+  for( i=0; i<6; i++ ){ t[i] = 0; for( j=0; j<6; j++ ) t[i] += M[6*i+j]*v[j]; }
+  memcpy( r, t, sizeof(t) );
+}
+/* Y += X' A X */
+static void congruence_add(const Link *l, const double *A, double *Y)
+{
+  double X[36], T[36];
+  int i, j, k;
+  memset( X, 0, sizeof(X) );
+  /* X = [ Ra'  -Ra'[pa]x ; 0  Ra' ] */
+  {
+    const double *R = l->Ra, *p = l->pa;
+    double px[9] = { 0,-p[2],p[1], p[2],0,-p[0], -p[1],p[0],0 }, Rt[9], B[9];
+    for( i=0; i<3; i++ ) for( j=0; j<3; j++ ) Rt[3*i+j] = R[3*j+i];
+    m3_mul( Rt, px, B );
+    for( i=0; i<3; i++ ) for( j=0; j<3; j++ ){
+      X[6*i+j] = Rt[3*i+j]; X[6*i+3+j] = -B[3*i+j]; X[6*(3+i)+3+j] = Rt[3*i+j];
+    }
+  }
+  for( i=0; i<6; i++ ) for( j=0; j<6; j++ ){
+    double s = 0; for( k=0; k<6; k++ ) s += A[6*i+k]*X[6*k+j];
+    T[6*i+j] = s;
+  }
+  for( i=0; i<6; i++ ) for( j=0; j<6; j++ ){
+    double s = 0; for( k=0; k<6; k++ ) s += X[6*k+i]*T[6*k+j];
+    Y[6*i+j] += s;
+  }
+}
+/* Cholesky A = L L' (6x6), and solve */
+static void chol6(const double *A, double *L)
+{
+  int i, j, k;
+  memset( L, 0, sizeof(double)*36 );
+  for( j=0; j<6; j++ ){
+    double s = A[6*j+j];
+    for( k=0; k<j; k++ ) s -= L[6*j+k]*L[6*j+k];
+    L[6*j+j] = sqrt( s );
+    for( i=j+1; i<6; i++ ){
+      s = A[6*i+j];
+      for( k=0; k<j; k++ ) s -= L[6*i+k]*L[6*j+k];
+      L[6*i+j] = s / L[6*j+j];
+    }
+  }
+}
+static void chol6_solve(const double *L, const double *b, double *x)
+{
+  int i, k; double y[6];
+  for( i=0; i<6; i++ ){ double s = b[i]; for( k=0; k<i; k++ ) s -= L[6*i+k]*y[k]; y[i] = s / L[6*i+i]; }
+  for( i=5; i>=0; i-- ){ double s = y[i]; for( k=i+1; k<6; k++ ) s -= L[6*k+i]*x[k]; x[i] = s / L[6*i+i]; }
+}
+
+/* velocity-dependent bias + gravity, joint torques: the per-link inputs of the ABA */
+static void aba_prepare(rkfdOracle *o)
+{
+  const rkfdModel *m = o->m;
+  int i;
+  for( i=0; i<o->nl; i++ ){
+    Link *l = &o->lk[i];
+    const double *c = &m->com[3*i];
+    double ms = m->mass[i], *b = &o->beta0[6*i];
+    double wc[3], wwc[3], Iw[3], wIw[3], g[3] = { 0, 0, -RKFD_G }, fg[3], ng[3];
+    const double *w = l->v+3;
+    /* beta = ( m w x ( w x c ), w x ( Io w ) ) - gravity wrench */
+    v3_cross( w, c, wc ); v3_cross( w, wc, wwc );
+    Iw[0] = l->M6[6*3+3]*w[0] + l->M6[6*3+4]*w[1] + l->M6[6*3+5]*w[2];
+    Iw[1] = l->M6[6*4+3]*w[0] + l->M6[6*4+4]*w[1] + l->M6[6*4+5]*w[2];
+    Iw[2] = l->M6[6*5+3]*w[0] + l->M6[6*5+4]*w[1] + l->M6[6*5+5]*w[2];
+    v3_cross( w, Iw, wIw );
+    m3_tmulv( l->R, g, fg ); v3_mul( fg, ms, fg );
+    v3_cross( c, fg, ng );
+    b[0] = ms*wwc[0] - fg[0]; b[1] = ms*wwc[1] - fg[1]; b[2] = ms*wwc[2] - fg[2];
+    b[3] = wIw[0] - ng[0];    b[4] = wIw[1] - ng[1];    b[5] = wIw[2] - ng[2];
+    if( rkfd_joint_dof( m->jtype[i] ) == 1 ){
+      l->jm  = motor_inertia( m, i );
+      l->tau = motor_input_trq( m, i, o->motor_in[i] ) - motor_registance( m, i, l->qd ) + l->tf;
+    }
+  }
+}
+
+/* bias recursion for one link given beta0, ext and csum: pA, u, contribution to the parent */
+static void aba_bias_link(rkfdOracle *o, int i, double *newcontrib)
+{
+  const rkfdModel *m = o->m;
+  Link *l = &o->lk[i];
+  double *pA = &o->pA[6*i], *u = &o->u[6*i], pa[6], t[6];
+  int k;
+  for( k=0; k<6; k++ ) pA[k] = o->beta0[6*i+k] - o->ext[6*i+k] + o->csum[6*i+k];
+  switch( m->jtype[i] ){
+  case RKFD_JOINT_REVOL: case RKFD_JOINT_PRISM: {
+    int ax = m->jtype[i] == RKFD_JOINT_REVOL ? 5 : 2;
+    double ud;
+    u[0] = l->tau - pA[ax];
+    ud = u[0] / l->D;
+    /* pa = pA + Ia gam + U u / D, Ia = IA - U U'/D */
+    m6_mulv( l->IA, l->gam, t );
+    {
+      double ug = 0; for( k=0; k<6; k++ ) ug += l->U[k]*l->gam[k];
+      for( k=0; k<6; k++ ) pa[k] = pA[k] + t[k] - l->U[k]*( ug/l->D ) + l->U[k]*ud;
+    }
+  } break;
+  case RKFD_JOINT_FLOAT:
+    /* a free joint transmits only its own generalized force (zero) */
+    for( k=0; k<6; k++ ){ u[k] = 0; pa[k] = 0; }
+    break;
+  default:
+    m6_mulv( l->IA, l->gam, t );
+    for( k=0; k<6; k++ ) pa[k] = pA[k] + t[k];
+  }
+  xform_force_T( l, pa, newcontrib );
+}
+
+/* rkChainUpdateABI [RoKi rk_abi, restated]: sweep 2 (articulated inertia + bias, leaf to
+ * root) and sweep 3 (accelerations, root to leaf).  Call sites: reference
+ * src/rkfd_sim.c:509-521, src/rkfd_util.c:156 */
+static void aba_backward_full(rkfdOracle *o)
+{
+  const rkfdModel *m = o->m;
+  int i, k, j;
+  for( i=0; i<o->nl; i++ ){
+    memcpy( o->lk[i].IA, o->lk[i].M6, sizeof(double)*36 );
+    memset( &o->csum[6*i], 0, sizeof(double)*6 );
+  }
+  for( i=o->nl-1; i>=0; i-- ){
+    Link *l = &o->lk[i];
+    double Ia[36], nc[6];
+    int par = m->parent[i];
+    switch( m->jtype[i] ){
+    case RKFD_JOINT_REVOL: case RKFD_JOINT_PRISM: {
+      int ax = m->jtype[i] == RKFD_JOINT_REVOL ? 5 : 2;
+      for( k=0; k<6; k++ ) l->U[k] = l->IA[6*k+ax];
+      l->D = l->IA[6*ax+ax] + l->jm;
+      for( k=0; k<6; k++ ) for( j=0; j<6; j++ ) Ia[6*k+j] = l->IA[6*k+j] - l->U[k]*l->U[j]/l->D;
+    } break;
+    case RKFD_JOINT_FLOAT:
+      chol6( l->IA, l->L6 );
+      memset( Ia, 0, sizeof(Ia) );
+      break;
+    default:
+      memcpy( Ia, l->IA, sizeof(Ia) );
+    }
+    aba_bias_link( o, i, nc );
+    memcpy( &o->contrib[6*i], nc, sizeof(nc) );
+    if( par >= 0 ){
+      if( m->jtype[i] != RKFD_JOINT_FLOAT ) congruence_add( l, Ia, o->lk[par].IA );
+      for( k=0; k<6; k++ ) o->csum[6*par+k] += nc[k];
+    }
+  }
+}
+
+/* re-propagate the bias from link i to its root after ext[i] changed
+ * (the bias-only part of rkChainUpdateCachedABI / ...CachedABIPair) */
+static void aba_bias_path(rkfdOracle *o, int i)
+{
+  const rkfdModel *m = o->m;
+  double nc[6]; int k;
+  while( i >= 0 ){
+    int par = m->parent[i];
+    aba_bias_link( o, i, nc );
+    if( par >= 0 )
+      for( k=0; k<6; k++ ) o->csum[6*par+k] += nc[k] - o->contrib[6*i+k];
+    memcpy( &o->contrib[6*i], nc, sizeof(nc) );
+    i = par;
+  }
+}
+
+static void aba_forward(rkfdOracle *o, double *acc)
+{
+  const rkfdModel *m = o->m;
+  static const double zero6[6] = { 0,0,0,0,0,0 };
+  int i, k;
+  for( i=0; i<o->nl; i++ ){
+    Link *l = &o->lk[i];
+    int par = m->parent[i];
+    double y[6];
+    xform_acc( l, par < 0 ? zero6 : o->lk[par].a, y );
+    for( k=0; k<6; k++ ) y[k] += l->gam[k];
+    switch( m->jtype[i] ){
+    case RKFD_JOINT_REVOL: case RKFD_JOINT_PRISM: {
+      int ax = m->jtype[i] == RKFD_JOINT_REVOL ? 5 : 2;
+      double uy = 0, qdd;
+      for( k=0; k<6; k++ ) uy += l->U[k]*y[k];
+      qdd = ( o->u[6*i] - uy ) / l->D;
+      memcpy( l->a, y, sizeof(y) );
+      l->a[ax] += qdd;
+      acc[m->dofoff[i]] = qdd;
+    } break;
+    case RKFD_JOINT_FLOAT: {
+      double rhs[6], d[6];
+      for( k=0; k<6; k++ ) rhs[k] = -o->pA[6*i+k];
+      chol6_solve( l->L6, rhs, l->a );
+      for( k=0; k<6; k++ ) d[k] = l->a[k] - y[k];
+      m3_mulv( l->Rj, d, acc + m->dofoff[i] );
+      m3_mulv( l->Rj, d+3, acc + m->dofoff[i] + 3 );
+    } break;
+    default:
+      memcpy( l->a, y, sizeof(y) );
+    }
+  }
+}
+
+/* rkChainSaveABIAccBias / rkChainRestoreABIAccBiasPair [RoKi]: call sites reference
+ * src/rkfd_util.c:157,173-181 */
+static void aba_save_bias(rkfdOracle *o)
+{
+  size_t n6 = sizeof(double)*6*o->nl;
+  int k;
+  /* the wrenches applied so far stay part of the saved bias; the wrench lists are then
+   * emptied (rkFDChainExtWrenchDestroy, reference src/rkfd_util.c:158) */
+  for( k=0; k<6*o->nl; k++ ){ o->beta0[k] -= o->ext[k]; o->ext[k] = 0; }
+  memcpy( o->s_beta0, o->beta0, n6 ); memcpy( o->s_pA, o->pA, n6 ); memcpy( o->s_u, o->u, n6 );
+  memcpy( o->s_contrib, o->contrib, n6 ); memcpy( o->s_csum, o->csum, n6 );
+}
+static void aba_restore_bias(rkfdOracle *o)
+{
+  size_t n6 = sizeof(double)*6*o->nl;
+  memcpy( o->pA, o->s_pA, n6 ); memcpy( o->u, o->s_u, n6 );
+  memcpy( o->contrib, o->s_contrib, n6 ); memcpy( o->csum, o->s_csum, n6 );
+  memset( o->ext, 0, n6 );
+}
+
+/* ------------------------------------------------------------------------ */
+/* point kinematics on a link, world frame */
+/* rkFDLinkPointWldVel (reference src/rkfd_util.c:14-24) */
+static void link_point_vel(const Link *l, const double *x, double *v)
+{
+  double vw[3], ww[3], r[3], t[3];
+  m3_mulv( l->R, l->v, vw ); m3_mulv( l->R, l->v+3, ww );
+  v3_sub( x, l->p, r ); v3_cross( ww, r, t ); v3_add( vw, t, v );
+}
+/* rkFDLinkPointWldAcc (reference src/rkfd_util.c:92-101) with RoKi's rkLinkPointAcc:
+ * a_lin + alpha x p + w x ( w x p ) in the link frame */
+static void link_point_acc(const Link *l, const double *x, double *a)
+{
+  double r[3], vp[3], t[3], s[3], al[3];
+  v3_sub( x, l->p, r ); m3_tmulv( l->R, r, vp );
+  v3_cross( l->a+3, vp, t );
+  v3_cross( l->v+3, vp, s ); v3_cross( l->v+3, s, s );
+  al[0] = l->a[0]+t[0]+s[0]; al[1] = l->a[1]+t[1]+s[1]; al[2] = l->a[2]+t[2]+s[2];
+  m3_mulv( l->R, al, a );
+}
+/* rkFDChainPointRelativeVel / ...Acc (reference src/rkfd_util.c:42-60,103-118): owner minus other;
+ * every cell is RK_CD_CELL_MOVE (reference src/rkfd_sim.c:198); slide mode is not modelled */
+static void rel_vel(const rkfdOracle *o, int j, double *v)
+{
+  double a[3], b[3];
+  link_point_vel( &o->lk[o->clinkA[j]], &o->cx[3*j], a );
+  link_point_vel( &o->lk[o->clinkB[j]], &o->cx[3*j], b );
+  v3_sub( a, b, v );
+}
+static void rel_acc(const rkfdOracle *o, int j, double *r)
+{
+  double a[3], b[3];
+  link_point_acc( &o->lk[o->clinkA[j]], &o->cx[3*j], a );
+  link_point_acc( &o->lk[o->clinkB[j]], &o->cx[3*j], b );
+  v3_sub( a, b, r );
+}
+
+/* add a world force fw acting at world point x on link i to the link's wrench buffer
+ * (link frame, about the link origin); sign = +1 / -1 */
+static void ext_add(rkfdOracle *o, int i, const double *x, const double *fw, double sign)
+{
+  const Link *l = &o->lk[i];
+  double r[3], pos[3], f[3], n[3]; int k;
+  v3_sub( x, l->p, r ); m3_tmulv( l->R, r, pos );
+  m3_tmulv( l->R, fw, f ); v3_mul( f, sign, f );
+  v3_cross( pos, f, n );
+  for( k=0; k<3; k++ ){ o->ext[6*i+k] += f[k]; o->ext[6*i+3+k] += n[k]; }
+}
+/* rkFDContactForcePushWrench (reference src/rkfd_util.c:268-282) */
+static void push_wrench(rkfdOracle *o, int j)
+{
+  ext_add( o, o->clinkA[j], &o->cx[3*j], &o->cv_f[3*j],  1.0 );
+  ext_add( o, o->clinkB[j], &o->cx[3*j], &o->cv_f[3*j], -1.0 );
+}
+
+/* ------------------------------------------------------------------------ */
+/* rkCDColChkVert [RoKi rk_cd, restated for convex shapes; UNVERIFIED-DEP] followed by
+ * rkFDCDUpdate (reference src/rkfd_cd.c:33-49): a candidate vertex of one shape is in contact
+ * when it lies inside the other shape; the contact normal is the outward normal of the face
+ * of least penetration; the stick anchor _ref (other link's frame) is set at first contact. */
+static void collision(rkfdOracle *o)
+{
+  const rkfdModel *m = o->m;
+  int j, f;
+  o->nel = o->nrg = 0;
+  for( j=0; j<o->ncand; j++ ){
+    int pr = m->cand_pair[j], sd = m->cand_side[j];
+    int shA = m->pair_shape[2*pr+sd], shB = m->pair_shape[2*pr+1-sd];
+    int la = m->shape_link[shA], lb = m->shape_link[shB];
+    const Link *A = &o->lk[la], *B = &o->lk[lb];
+    double x[3], y[3], r[3], smax = -HUGE_VAL; int fbest = -1;
+    m3_mulv( A->R, &m->verts[3*m->cand_vert[j]], x ); v3_add( x, A->p, x );
+    v3_sub( x, B->p, r ); m3_tmulv( B->R, r, y );
+    for( f=m->shape_foff[shB]; f<m->shape_foff[shB+1]; f++ ){
+      double s = v3_dot( &m->planes[4*f], y ) - m->planes[4*f+3];
+      if( s > smax ){ smax = s; fbest = f; }
+    }
+    o->clinkA[j] = la; o->clinkB[j] = lb; o->cci[j] = m->pair_ci[pr];
+    v3_copy( x, &o->cx[3*j] );
+    v3_zero( &o->cv_f[3*j] );
+    if( fbest < 0 || !( smax < TOL ) ){
+      o->cv_active[j] = 0;
+      continue;
+    }
+    {
+      const double *pl = &m->planes[4*fbest];
+      double pro[3];
+      v3_copy( y, pro ); v3_cat( pro, -smax, pl );
+      v3_copy( pro, &o->cpro[3*j] );
+      m3_mulv( B->R, pl, &o->cnorm[3*j] );
+      if( !o->cv_active[j] ){
+        o->cv_active[j] = 1;
+        o->cv_type[j] = RKFD_SF;
+        v3_copy( pro, &o->cv_ref[3*j] );
+      }
+      m3_mulv( B->R, &o->cv_ref[3*j], &o->crefw[3*j] ); v3_add( &o->crefw[3*j], B->p, &o->crefw[3*j] );
+      v3_copy( &o->cnorm[3*j], &o->caxis[9*j] );
+      ortho_space( &o->cnorm[3*j], &o->caxis[9*j+3], &o->caxis[9*j+6] );
+    }
+    if( m->ci_type[o->cci[j]] == RKFD_CONTACT_ELASTIC ) o->el[o->nel++] = j;
+    else if( m->ci_type[o->cci[j]] == RKFD_CONTACT_RIGID ) o->rg[o->nrg++] = j;
+  }
+}
+
+/* rkFDContactForceModifyFriction (reference src/rkfd_util.c:239-266) */
+static void modify_friction(rkfdOracle *o, int j, const double *vr, int doUpRef)
+{
+  const rkfdModel *m = o->m;
+  double *f = &o->cv_f[3*j], *ax = &o->caxis[9*j], v[3];
+  double fn, fs, vs, mu;
+  int ci = o->cci[j];
+  fn = v3_dot( f, ax );
+  fs = sqrt( v3_dot( f, ax+3 )*v3_dot( f, ax+3 ) + v3_dot( f, ax+6 )*v3_dot( f, ax+6 ) );
+  mu = o->cv_type[j] == RKFD_SF ? m->ci_sf[ci] : m->ci_kf[ci];
+  if( !is_tiny( fs ) && fs > mu*fn ){
+    v3_copy( vr, v );
+    v3_cat( v, -v3_dot( v, ax ), ax );
+    vs = v3_norm( v );
+    v3_mul( ax, fn, f );
+    if( !is_tiny( vs ) ){
+      v3_mul( v, 1.0/vs, v );
+      v3_cat( f, -kf_weight( m->friction_weight, vs )*m->ci_kf[ci]*fn, v );
+    }
+    if( doUpRef ){
+      o->cv_type[j] = RKFD_KF;
+      v3_copy( &o->cpro[3*j], &o->cv_ref[3*j] );
+    }
+  } else {
+    if( doUpRef ) o->cv_type[j] = RKFD_SF; /* rkFDUpdateRefSlide: no slide-mode cells */
+  }
+}
+
+/* rkFDSolverPenalty (reference src/rkfd_penalty.c:11-31) */
+static void penalty(rkfdOracle *o, int doUpRef)
+{
+  const rkfdModel *m = o->m;
+  int e;
+  for( e=0; e<o->nel; e++ ){
+    int j = o->el[e], ci = o->cci[j];
+    double d[3], vr[3], *f = &o->cv_f[3*j];
+    v3_sub( &o->cx[3*j], &o->crefw[3*j], d );
+    rel_vel( o, j, vr );
+    v3_mul( d, -m->ci_e[ci], f );
+    v3_cat( f, -1.0*( m->ci_v[ci] + m->ci_e[ci]*m->dt ), vr );
+    if( v3_dot( f, &o->caxis[9*j] ) < 0.0 ){ v3_zero( f ); continue; }
+    modify_friction( o, j, vr, doUpRef );
+    push_wrench( o, j );
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* MLCP plugin, rigid branch: _rkFDSolverConstraint (reference src/rkfd_mlcp.c:287-297) */
+static int mlcp(rkfdOracle *o, int doUpRef)
+{
+  const rkfdModel *m = o->m;
+  int nc = o->nrg, n3 = 3*nc, c, i, r, cnt;
+  double *A = o->ma, *b = o->mb, *t = o->mt, *f = o->mf;
+  double dt = m->dt;
+  (void)doUpRef;
+
+  o->last_nc = nc;
+  /* _rkFDSolverRelationAccForce (reference src/rkfd_mlcp.c:124-142) */
+  /* rkFDUpdateAccBias (reference src/rkfd_util.c:149-161): full ABA, save bias, drop wrenches */
+  aba_backward_full( o );
+  aba_forward( o, o->acc );
+  aba_save_bias( o );
+  /* _rkFDSolverBiasAcc (reference src/rkfd_mlcp.c:58-74) */
+  for( c=0; c<nc; c++ ){
+    double av[3];
+    rel_acc( o, o->rg[c], av );
+    for( i=0; i<3; i++ ) b[3*c+i] = v3_dot( &o->caxis[9*o->rg[c]+3*i], av );
+  }
+  /* probe every contact axis with a unit wrench (reference src/rkfd_mlcp.c:104-122,135-141) */
+  for( c=0; c<nc; c++ ){
+    int j = o->rg[c];
+    for( i=0; i<3; i++ ){
+      const double *axis = &o->caxis[9*j+3*i];
+      ext_add( o, o->clinkA[j], &o->cx[3*j], axis,  1.0 );
+      ext_add( o, o->clinkB[j], &o->cx[3*j], axis, -1.0 );
+      aba_bias_path( o, o->clinkA[j] );
+      aba_bias_path( o, o->clinkB[j] );
+      aba_forward( o, o->acc );
+      /* _rkFDSolverRelativeAcc (reference src/rkfd_mlcp.c:76-102) */
+      for( r=0; r<nc; r++ ){
+        int jr = o->rg[r], k;
+        int chA = m->chain[o->clinkA[jr]], chB = m->chain[o->clinkB[jr]];
+        int pA = m->chain[o->clinkA[j]], pB = m->chain[o->clinkB[j]];
+        if( chA != pA && chA != pB && chB != pA && chB != pB ){
+          for( k=0; k<3; k++ ) t[3*r+k] = 0;
+        } else {
+          double av[3];
+          rel_acc( o, jr, av );
+          for( k=0; k<3; k++ ) t[3*r+k] = v3_dot( &o->caxis[9*jr+3*k], av ) - b[3*r+k];
+        }
+      }
+      for( r=0; r<n3; r++ ) A[n3*r+3*c+i] = t[r];
+      aba_restore_bias( o );
+    }
+  }
+  /* _rkFDSolverBiasVel (reference src/rkfd_mlcp.c:146-162) */
+  for( r=0; r<n3; r++ ) b[r] *= dt;
+  for( c=0; c<nc; c++ ){
+    int j = o->rg[c];
+    rel_vel( o, j, &o->cvel[3*j] );
+    for( i=0; i<3; i++ ) b[3*c+i] += v3_dot( &o->cvel[3*j], &o->caxis[9*j+3*i] );
+  }
+  /* _rkFDSolverRelaxationCompensation (reference src/rkfd_mlcp.c:164-188) */
+  for( c=0; c<nc; c++ ){
+    int j = o->rg[c], ci = o->cci[j];
+    double d[3], k;
+    v3_sub( &o->cx[3*j], &o->crefw[3*j], d );
+    for( i=0; i<3; i++ ) A[n3*(3*c+i)+3*c+i] += m->ci_l[ci];
+    k = o->cv_type[j] == RKFD_SF ? m->ci_sf[ci] : m->ci_kf[ci];
+    b[3*c  ] += m->ci_k[ci]     * v3_dot( d, &o->caxis[9*j] );
+    b[3*c+1] += m->ci_k[ci] * k * v3_dot( d, &o->caxis[9*j+3] );
+    b[3*c+2] += m->ci_k[ci] * k * v3_dot( d, &o->caxis[9*j+6] );
+  }
+  /* _rkFDSolverMLCP (reference src/rkfd_mlcp.c:190-249): fixed max_iter sweeps, no warm start */
+  for( r=0; r<n3; r++ ) f[r] = 0;
+  for( cnt=0; cnt<m->max_iter; cnt++ ){
+    for( c=0; c<nc; c++ ){
+      int off = 3*c; double dot = 0, ff;
+      for( r=0; r<n3; r++ ) dot += A[n3*off+r]*f[r];
+      ff = -( b[off] + dot - A[n3*off+off]*f[off] ) / A[n3*off+off];
+      f[off] = ff < TOL ? 0.0 : ff;
+    }
+    for( c=0; c<nc; c++ ){
+      int off = 3*c, j = o->rg[c], ci = o->cci[j];
+      double ff[2], fnorm, fs;
+      for( i=0; i<2; i++ ){
+        int ro = off+1+i;
+        if( fabs( A[n3*ro+ro] ) < TOL ) ff[i] = 0;
+        else {
+          double dot = 0;
+          for( r=0; r<n3; r++ ) dot += A[n3*ro+r]*f[r];
+          ff[i] = -( b[ro] + dot - A[n3*ro+ro]*f[ro] ) / A[n3*ro+ro];
+        }
+      }
+      fnorm = ff[0]*ff[0] + ff[1]*ff[1];
+      fs = o->cv_type[j] == RKFD_SF ? m->ci_sf[ci]*f[off] : m->ci_kf[ci]*f[off];
+      fs = fs*fs;
+      if( fnorm < TOL || fs < TOL ){
+        f[off+1] = 0.0; f[off+2] = 0.0;
+      } else if( fnorm > fs ){
+        fs /= fnorm;
+        f[off+1] = ff[0]*fs; f[off+2] = ff[1]*fs;
+      } else {
+        f[off+1] = ff[0]; f[off+2] = ff[1];
+      }
+    }
+  }
+  for( r=0; r<n3; r++ ) f[r] /= dt;
+  /* _rkFDSolverSetForce (reference src/rkfd_mlcp.c:252-284); quirks Q1 (world components
+   * e[0] / e[1],e[2] used as normal / tangential) and Q2 (state updated on every evaluation) */
+  for( c=0; c<nc; c++ ){
+    int j = o->rg[c], ci = o->cci[j];
+    double *fw = &o->cv_f[3*j], fn, fs, mu;
+    v3_zero( fw );
+    for( i=0; i<3; i++ ) v3_cat( fw, f[3*c+i], &o->caxis[9*j+3*i] );
+    push_wrench( o, j );
+    fn = fw[0];
+    fs = sqrt( fw[1]*fw[1] + fw[2]*fw[2] );
+    mu = o->cv_type[j] == RKFD_SF ? m->ci_sf[ci] : m->ci_kf[ci];
+    if( fs > mu*fn - TOL ){
+      o->cv_type[j] = RKFD_KF;
+      v3_copy( &o->cpro[3*j], &o->cv_ref[3*j] );
+    } else {
+      o->cv_type[j] = RKFD_SF;
+    }
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* _rkFDUpdate / _rkFDUpdateRef (reference src/rkfd_sim.c:533-549) */
+static int evaluate(rkfdOracle *o, const double *dis, const double *vel, double *acc, int doUpRef)
+{
+  const rkfdModel *m = o->m;
+  int i, cached = 0;
+
+  memset( acc, 0, sizeof(double)*o->n );
+  o->last_nc = 0;
+  connect_state( o, dis, vel );
+  /* _rkFDUpdateReset (reference src/rkfd_sim.c:445-453) */
+  memset( o->ext, 0, sizeof(double)*6*o->nl );
+  for( i=0; i<o->nl; i++ ) o->lk[i].tf = 0; /* friction is re-derived below for DC joints */
+  /* _rkFDUpdateCD (reference src/rkfd_sim.c:466-471) */
+  collision( o );
+  /* rkFDSolverUpdate_<plugin> (reference src/rkfd_mlcp.c:335-343, src/rkfd_vert.c:380-388) */
+  joint_friction( o, doUpRef );
+  aba_prepare( o );
+  if( o->nel != 0 ) penalty( o, doUpRef );
+  if( o->nrg != 0 ){
+    if( m->solver != RKFD_SOLVER_MLCP ) return -1; /* Vert QP / Volume rigid branches: not restated */
+    if( mlcp( o, doUpRef ) < 0 ) return -1;
+    cached = 1;
+  }
+  /* _rkFDUpdateAcc (reference src/rkfd_sim.c:502-523) */
+  if( cached ){
+    /* rkChainUpdateCachedABI: saved bias + the wrenches pushed since, then sweep 3 */
+    for( i=o->nl-1; i>=0; i-- ){
+      int k, any = 0;
+      for( k=0; k<6; k++ ) if( o->ext[6*i+k] != 0.0 ) any = 1;
+      if( any ) aba_bias_path( o, i );
+    }
+    aba_forward( o, acc );
+  } else {
+    aba_backward_full( o );
+    aba_forward( o, acc );
+  }
+  return 0;
+}
+
+/* rkFDUpdateJointPrevDrivingTrq (reference src/rkfd_util.c:289-311) */
+static void update_prev_trq(rkfdOracle *o)
+{
+  const rkfdModel *m = o->m;
+  int i;
+  for( i=0; i<o->nl; i++ ){
+    if( rkfd_joint_dof( m->jtype[i] ) != 1 ) continue;
+    {
+      Link *l = &o->lk[i];
+      double drv = motor_input_trq( m, i, o->motor_in[i] ) - motor_registance( m, i, l->qd )
+                 - motor_inertia( m, i ) * o->acc[m->dofoff[i]];
+      o->piv_prev[i] = drv + l->tf;
+    }
+  }
+}
+
+static int eval_ref(rkfdOracle *o)
+{
+  int r = evaluate( o, o->dis, o->vel, o->acc, 1 );
+  update_prev_trq( o );
+  return r;
+}
+
+int rkfdOracleEval(rkfdOracle *o, int doUpRef)
+{
+  if( doUpRef ) return eval_ref( o );
+  return evaluate( o, o->dis, o->vel, o->acc, 0 );
+}
+
+void rkfdOracleUpdateInit(rkfdOracle *o){ eval_ref( o ); }
+
+/* rkFDODECatDefault (reference src/rkfd_sim.c:306-320) with RoKi's rkChainCatJointDisAll:
+ * xnew = x (+) k v; float joints compose the rotation R(k w) R(aa)  [UNVERIFIED-DEP] */
+static void cat_dis(const rkfdOracle *o, const double *x, double k, const double *v, double *xn)
+{
+  const rkfdModel *m = o->m;
+  int i, j;
+  for( i=0; i<o->nl; i++ ){
+    int off = m->dofoff[i];
+    switch( m->jtype[i] ){
+    case RKFD_JOINT_FLOAT: {
+      double aa[3], Rk[9], R0[9], Rn[9];
+      for( j=0; j<3; j++ ) xn[off+j] = x[off+j] + k*v[off+j];
+      v3_mul( v+off+3, k, aa );
+      m3_from_aa( aa, Rk ); m3_from_aa( x+off+3, R0 );
+      m3_mul( Rk, R0, Rn );
+      m3_to_aa( Rn, xn+off+3 );
+    } break;
+    case RKFD_JOINT_FIXED: break;
+    default: xn[off] = x[off] + k*v[off];
+    }
+  }
+}
+
+/* rkFDUpdate (reference src/rkfd_sim.c:560-566): zODE2Update with the Runge-Kutta-Gill scheme
+ * [ZM zODE2 "Regular" + RKG, restated; UNVERIFIED-DEP], then the committing evaluation. */
+int rkfdOracleUpdate(rkfdOracle *o)
+{
+  const double h = o->m->dt;
+  const double s2 = sqrt( 2.0 );
+  const double c21 = ( s2 - 1.0 )/2.0, c22 = ( 2.0 - s2 )/2.0;
+  const double c31 = -s2/2.0, c32 = 1.0 + s2/2.0;
+  const double w2 = 2.0 - s2, w3 = 2.0 + s2;
+  int n = o->n, i, r = 0;
+  double t = o->t;
+
+  /* stage 1 */
+  memcpy( o->k_v[0], o->vel, sizeof(double)*n );
+  r |= evaluate( o, o->dis, o->vel, o->k_a[0], 0 );
+  /* stage 2: x + h/2 k1 */
+  cat_dis( o, o->dis, 0.5*h, o->k_v[0], o->xd );
+  for( i=0; i<n; i++ ) o->xv[i] = o->vel[i] + 0.5*h*o->k_a[0][i];
+  memcpy( o->k_v[1], o->xv, sizeof(double)*n );
+  r |= evaluate( o, o->xd, o->xv, o->k_a[1], 0 );
+  /* stage 3: x + h( c21 k1 + c22 k2 ) */
+  for( i=0; i<n; i++ ){ o->tv[i] = c21*o->k_v[0][i] + c22*o->k_v[1][i]; o->ta[i] = c21*o->k_a[0][i] + c22*o->k_a[1][i]; }
+  cat_dis( o, o->dis, h, o->tv, o->xd );
+  for( i=0; i<n; i++ ) o->xv[i] = o->vel[i] + h*o->ta[i];
+  memcpy( o->k_v[2], o->xv, sizeof(double)*n );
+  r |= evaluate( o, o->xd, o->xv, o->k_a[2], 0 );
+  /* stage 4: x + h( c31 k2 + c32 k3 ) */
+  for( i=0; i<n; i++ ){ o->tv[i] = c31*o->k_v[1][i] + c32*o->k_v[2][i]; o->ta[i] = c31*o->k_a[1][i] + c32*o->k_a[2][i]; }
+  cat_dis( o, o->dis, h, o->tv, o->xd );
+  for( i=0; i<n; i++ ) o->xv[i] = o->vel[i] + h*o->ta[i];
+  memcpy( o->k_v[3], o->xv, sizeof(double)*n );
+  r |= evaluate( o, o->xd, o->xv, o->k_a[3], 0 );
+  /* x += h/6 ( k1 + (2-sqrt2) k2 + (2+sqrt2) k3 + k4 ) */
+  for( i=0; i<n; i++ ){
+    o->tv[i] = o->k_v[0][i] + w2*o->k_v[1][i] + w3*o->k_v[2][i] + o->k_v[3][i];
+    o->ta[i] = o->k_a[0][i] + w2*o->k_a[1][i] + w3*o->k_a[2][i] + o->k_a[3][i];
+  }
+  cat_dis( o, o->dis, h/6.0, o->tv, o->xd );
+  memcpy( o->dis, o->xd, sizeof(double)*n );
+  for( i=0; i<n; i++ ) o->vel[i] += h/6.0*o->ta[i];
+  o->t = t + h;
+  r |= eval_ref( o );
+  return r;
+}

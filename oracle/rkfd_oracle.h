@@ -1,0 +1,62 @@
+/* rkfd_oracle.h - CPU restatement (fp64, single thread) of the rkFDUpdate hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (roki-fd_amd/, include/)
+ * may call or link this; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, as the checker / timed CPU stand-in.
+ *
+ * PARITY UNPINNED: the reference (mi-lib/roki-fd 1.7.9) ships no tests, golden
+ * vectors or expected outputs (reference test/test.sh:5-13 globs *test.c, none exist),
+ * and its arithmetic lives in un-vendored dependencies
+ * (zeda=1.12.1; zm=1.14.5; zeo=1.20.8; roki=2.13.13 - reference libinfo:3) that are
+ * absent here, so the reference cannot be built or run.  This restatement follows
+ * the reference's own control flow (file:line cited per function in the .c) and the
+ * published algorithms of the dependencies (Featherstone ABA, Runge-Kutta-Gill,
+ * projected Gauss-Seidel); it is pinned only by the analytic known-answer tests in
+ * tests/ and by self-generated golden vectors (labelled as such).
+ */
+#ifndef RKFD_ORACLE_H
+#define RKFD_ORACLE_H
+
+#include "rkfd_model.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rkfdOracle rkfdOracle;
+
+rkfdOracle *rkfdOracleCreate(const rkfdModel *m);
+void rkfdOracleDestroy(rkfdOracle *o);
+
+void rkfdOracleSetState(rkfdOracle *o, const double *dis, const double *vel);
+void rkfdOracleGetState(const rkfdOracle *o, double *dis, double *vel, double *acc);
+void rkfdOracleSetMotorInput(rkfdOracle *o, const double *input /* [nlink] */);
+double rkfdOracleTime(const rkfdOracle *o);
+
+/* persistent contact-vertex state, one entry per model candidate vertex */
+void rkfdOracleGetContact(const rkfdOracle *o, int *active, int *type, double *ref /*[ncand*3]*/, double *f /*[ncand*3]*/);
+void rkfdOracleSetContact(rkfdOracle *o, const int *active, const int *type, const double *ref);
+/* joint friction pivots, one entry per link (meaningful for 1-DoF joints) */
+void rkfdOracleGetPivot(const rkfdOracle *o, int *type, double *prev_trq);
+void rkfdOracleSetPivot(rkfdOracle *o, const int *type, const double *prev_trq);
+
+/* rkFDUpdateInit (reference src/rkfd_sim.c:552-558): one committing evaluation at t */
+void rkfdOracleUpdateInit(rkfdOracle *o);
+/* rkFDUpdate (reference src/rkfd_sim.c:560-566): RKG stages + committing evaluation */
+int  rkfdOracleUpdate(rkfdOracle *o);
+/* one dynamics evaluation at the current state: _rkFDUpdate / _rkFDUpdateRef
+ * (reference src/rkfd_sim.c:533-549); result in acc */
+int  rkfdOracleEval(rkfdOracle *o, int doUpRef);
+
+/* introspection for the known-answer tests */
+void rkfdOracleGetLinkFrames(const rkfdOracle *o, double *R /*[nlink*9]*/, double *p /*[nlink*3]*/);
+void rkfdOracleGetLinkVelAcc(const rkfdOracle *o, double *vel /*[nlink*6]*/, double *acc /*[nlink*6]*/);
+/* last MLCP system: returns number of rigid contact vertices nc; a is 3nc x 3nc row-major
+ * (after relaxation was added), b after bias/compensation, f after division by dt */
+int  rkfdOracleGetMLCP(const rkfdOracle *o, double *a, double *b, double *f, int cap);
+/* count of floating-point operations is not instrumented; see DESIGN.md */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

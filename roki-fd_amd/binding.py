@@ -1,0 +1,246 @@
+"""ctypes binding of librkfd_amd.so (include/rkfd_hip.h, include/roki_fd_amd.h)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librkfd_amd.so")
+
+JOINT_FIXED, JOINT_REVOL, JOINT_PRISM, JOINT_FLOAT = 0, 1, 2, 3
+SOLVER_VERT, SOLVER_MLCP, SOLVER_VOLUME = 0, 1, 2
+CONTACT_RIGID, CONTACT_ELASTIC = 0, 1
+SF, KF = 0, 1
+
+_pi = C.POINTER(C.c_int)
+_pd = C.POINTER(C.c_double)
+
+
+class RkfdError(RuntimeError):
+    pass
+
+
+class RkfdModel(C.Structure):
+    """Mirror of rkfdModel (include/rkfd_model.h); field order must match."""
+    _fields_ = [
+        ("nlink", C.c_int), ("ndof", C.c_int), ("nchain", C.c_int),
+        ("parent", _pi), ("jtype", _pi), ("dofoff", _pi), ("chain", _pi),
+        ("org", _pd), ("mass", _pd), ("com", _pd), ("inertia", _pd),
+        ("stiff", _pd), ("visc", _pd), ("coulomb", _pd), ("sfric", _pd),
+        ("mtype", _pi),
+        ("mot_k", _pd), ("mot_admit", _pd), ("mot_vmax", _pd), ("mot_vmin", _pd), ("mot_gear", _pd), ("mot_inertia", _pd),
+        ("nshape", C.c_int),
+        ("shape_link", _pi), ("shape_voff", _pi), ("shape_foff", _pi),
+        ("verts", _pd), ("planes", _pd),
+        ("npair", C.c_int),
+        ("pair_shape", _pi), ("pair_ci", _pi),
+        ("nci", C.c_int),
+        ("ci_type", _pi),
+        ("ci_sf", _pd), ("ci_kf", _pd), ("ci_k", _pd), ("ci_l", _pd), ("ci_e", _pd), ("ci_v", _pd),
+        ("ncand", C.c_int),
+        ("cand_pair", _pi), ("cand_side", _pi), ("cand_vert", _pi),
+        ("dt", C.c_double), ("friction_weight", C.c_double),
+        ("max_iter", C.c_int), ("solver", C.c_int),
+    ]
+
+    def arr(self, name, n, dtype=None):
+        p = getattr(self, name)
+        if n == 0:
+            return np.zeros(0, dtype=dtype or (np.int32 if isinstance(p, _pi) else np.float64))
+        return np.ctypeslib.as_array(p, shape=(n,)).copy()
+
+
+_lib = None
+
+
+def lib():
+    """Loads librkfd_amd.so; raises when it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RkfdError(f"{LIB_PATH} is missing: run `make` (or __graft_entry__.build()) first")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.rkfdWorldCreate.restype = vp
+    L.rkfdWorldFree.argtypes = [vp]
+    L.rkfdWorldRegFile.argtypes = [vp, C.c_char_p]
+    L.rkfdWorldSetContactInfo.argtypes = [vp, C.c_char_p]
+    L.rkfdWorldPairChainUnreg.argtypes = [vp, C.c_int]
+    L.rkfdWorldSetPrp.argtypes = [vp, C.c_double, C.c_double, C.c_int, C.c_int]
+    L.rkfdWorldModel.argtypes = [vp]
+    L.rkfdWorldModel.restype = C.POINTER(RkfdModel)
+    L.rkfdWorldChainDofOffset.argtypes = [vp, C.c_int]
+    L.rkfdWorldChainLinkOffset.argtypes = [vp, C.c_int]
+    L.rkfdWorldChainInitDis.argtypes = [vp, C.c_int, _pd]
+    L.rkfdHipLastError.restype = C.c_char_p
+    L.rkfdBatchCreate.argtypes = [C.POINTER(RkfdModel), C.c_int, C.c_int, C.c_int]
+    L.rkfdBatchCreate.restype = vp
+    L.rkfdBatchDestroy.argtypes = [vp]
+    for f in ("rkfdBatchSize", "rkfdBatchDof", "rkfdBatchLdsBytes"):
+        getattr(L, f).argtypes = [vp]
+    L.rkfdBatchSetState.argtypes = [vp, vp, vp]
+    L.rkfdBatchGetState.argtypes = [vp, vp, vp, vp]
+    L.rkfdBatchSetMotorInput.argtypes = [vp, vp]
+    L.rkfdBatchGetContact.argtypes = [vp, vp, vp, vp, vp]
+    L.rkfdBatchSetContact.argtypes = [vp, vp, vp, vp]
+    L.rkfdBatchGetPivot.argtypes = [vp, vp, vp]
+    L.rkfdBatchSetPivot.argtypes = [vp, vp, vp]
+    L.rkfdBatchUpdateInit.argtypes = [vp, vp]
+    L.rkfdBatchUpdate.argtypes = [vp, C.c_int, vp]
+    L.rkfdBatchEval.argtypes = [vp, C.c_int, vp]
+    L.rkfdBatchStatus.argtypes = [vp, vp]
+    for f in ("rkfdBatchDevDis", "rkfdBatchDevVel", "rkfdBatchDevAcc"):
+        getattr(L, f).argtypes = [vp]
+        getattr(L, f).restype = vp
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class World:
+    """The rkFD world builder: chains registered from ZTK files + contact-info table.
+    Mirrors rkFDCreate / rkFDChainRegFile / rkFDContactInfoScanFile / rkFDSetSolver /
+    rkFDPrpSet* (reference src/rkfd_sim.c:32-54,224-273; include/roki_fd/rkfd_sim.h:89-93)."""
+
+    def __init__(self, solver=SOLVER_VERT, dt=0.001, friction_weight=100.0, max_iter=10):
+        self._L = lib()
+        self._w = self._L.rkfdWorldCreate()
+        if not self._w:
+            raise RkfdError("rkfdWorldCreate failed")
+        self.nchain = 0
+        self.set_prp(dt, friction_weight, max_iter, solver)
+
+    def close(self):
+        if self._w:
+            self._L.rkfdWorldFree(self._w)
+            self._w = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_prp(self, dt, friction_weight, max_iter, solver):
+        self._L.rkfdWorldSetPrp(self._w, dt, friction_weight, max_iter, solver)
+
+    def reg_file(self, path):
+        cid = self._L.rkfdWorldRegFile(self._w, os.fspath(path).encode())
+        if cid < 0:
+            raise RkfdError(f"cannot register chain from {path}")
+        self.nchain = cid + 1
+        return cid
+
+    def contact_info(self, path):
+        if self._L.rkfdWorldSetContactInfo(self._w, os.fspath(path).encode()) != 0:
+            raise RkfdError(f"cannot read contact info from {path}")
+
+    def pair_chain_unreg(self, chain):
+        self._L.rkfdWorldPairChainUnreg(self._w, chain)
+
+    @property
+    def model(self):
+        p = self._L.rkfdWorldModel(self._w)
+        if not p:
+            raise RkfdError("rkfdWorldModel failed")
+        return p
+
+    def dof_offset(self, chain):
+        return self._L.rkfdWorldChainDofOffset(self._w, chain)
+
+    def link_offset(self, chain):
+        return self._L.rkfdWorldChainLinkOffset(self._w, chain)
+
+    def init_dis(self, chain):
+        buf = np.zeros(64, dtype=np.float64)
+        n = self._L.rkfdWorldChainInitDis(self._w, chain, buf.ctypes.data_as(_pd))
+        return buf[:n].copy()
+
+
+class Batch:
+    """B instances of one world on one GPU (include/rkfd_hip.h).  All arrays are
+    instance-major numpy arrays [B, ...]."""
+
+    def __init__(self, world, batch, device=0, max_rigid=8):
+        self._L = lib()
+        self.world = world
+        m = world.model.contents
+        self.B, self.ndof, self.nlink, self.ncand = batch, m.ndof, m.nlink, m.ncand
+        self._b = self._L.rkfdBatchCreate(world.model, batch, device, max_rigid)
+        if not self._b:
+            raise RkfdError(self._L.rkfdHipLastError().decode())
+
+    def close(self):
+        if getattr(self, "_b", None):
+            self._L.rkfdBatchDestroy(self._b)
+            self._b = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, r):
+        if r < 0:
+            raise RkfdError(self._L.rkfdHipLastError().decode())
+
+    def set_state(self, dis, vel):
+        dis = np.ascontiguousarray(dis, dtype=np.float64).reshape(self.B, self.ndof)
+        vel = np.ascontiguousarray(vel, dtype=np.float64).reshape(self.B, self.ndof)
+        self._chk(self._L.rkfdBatchSetState(self._b, _ptr(dis), _ptr(vel)))
+
+    def get_state(self):
+        dis = np.empty((self.B, self.ndof)); vel = np.empty_like(dis); acc = np.empty_like(dis)
+        self._chk(self._L.rkfdBatchGetState(self._b, _ptr(dis), _ptr(vel), _ptr(acc)))
+        return dis, vel, acc
+
+    def set_motor_input(self, inp):
+        inp = np.ascontiguousarray(inp, dtype=np.float64).reshape(self.B, self.nlink)
+        self._chk(self._L.rkfdBatchSetMotorInput(self._b, _ptr(inp)))
+
+    def get_contact(self):
+        act = np.empty((self.B, self.ncand), dtype=np.int32); typ = np.empty_like(act)
+        ref = np.empty((self.B, self.ncand, 3)); f = np.empty_like(ref)
+        self._chk(self._L.rkfdBatchGetContact(self._b, _ptr(act), _ptr(typ), _ptr(ref), _ptr(f)))
+        return act, typ, ref, f
+
+    def set_contact(self, act, typ, ref):
+        act = np.ascontiguousarray(act, dtype=np.int32); typ = np.ascontiguousarray(typ, dtype=np.int32)
+        ref = np.ascontiguousarray(ref, dtype=np.float64)
+        self._chk(self._L.rkfdBatchSetContact(self._b, _ptr(act), _ptr(typ), _ptr(ref)))
+
+    def get_pivot(self):
+        typ = np.empty((self.B, self.nlink), dtype=np.int32); prev = np.empty((self.B, self.nlink))
+        self._chk(self._L.rkfdBatchGetPivot(self._b, _ptr(typ), _ptr(prev)))
+        return typ, prev
+
+    def set_pivot(self, typ, prev):
+        typ = np.ascontiguousarray(typ, dtype=np.int32); prev = np.ascontiguousarray(prev, dtype=np.float64)
+        self._chk(self._L.rkfdBatchSetPivot(self._b, _ptr(typ), _ptr(prev)))
+
+    def update_init(self, stream=None):
+        self._chk(self._L.rkfdBatchUpdateInit(self._b, stream))
+
+    def update(self, nsteps=1, stream=None):
+        self._chk(self._L.rkfdBatchUpdate(self._b, nsteps, stream))
+
+    def eval(self, do_up_ref=False, stream=None):
+        self._chk(self._L.rkfdBatchEval(self._b, 1 if do_up_ref else 0, stream))
+
+    def status(self, stream=None):
+        r = self._L.rkfdBatchStatus(self._b, stream)
+        if r < 0:
+            raise RkfdError(self._L.rkfdHipLastError().decode())
+        return r
+
+    @property
+    def lds_bytes(self):
+        return self._L.rkfdBatchLdsBytes(self._b)
+
+    def dev_ptrs(self):
+        return (self._L.rkfdBatchDevDis(self._b), self._L.rkfdBatchDevVel(self._b), self._L.rkfdBatchDevAcc(self._b))

@@ -1,0 +1,358 @@
+/* rkfd_sim.c - host C API (include/roki_fd_amd.h): the rkFD object of the reference
+ * (reference src/rkfd_sim.c) re-built as a thin shim over the flattened world + the GPU batch.
+ * No dynamics is computed here; rkFDUpdate launches the device step with a batch of one.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "roki_fd_amd.h"
+#include "rkfd_world.h"
+
+typedef struct {
+  rkfdWorld world;
+  rkfdBatch *batch;
+  double *motor_in;   /* [nlink] of the world, host copy */
+  int dirty;          /* host state newer than device state */
+  int status;
+  int ncell;
+} rkFDImpl;
+
+typedef struct { int kind; int max_rigid; } rkFDSolverPrpAMD;
+
+#define IMPL(fd) ( (rkFDImpl *)(fd)->impl )
+
+/* ---- zVec --------------------------------------------------------------------------- */
+zVec zVecAlloc(int size)
+{
+  zVec v = (zVec)malloc( sizeof(zVecStruct) );
+  if( !v ) return NULL;
+  v->size = size;
+  v->buf = (double *)calloc( size > 0 ? size : 1, sizeof(double) );
+  if( !v->buf ){ free( v ); return NULL; }
+  return v;
+}
+void zVecFree(zVec v){ if( v ){ free( v->buf ); free( v ); } }
+void zVecFPrint(FILE *fp, zVec v)
+{
+  int i;
+  if( !v ){ fprintf( fp, "(null vector)\n" ); return; }
+  fprintf( fp, "%d (", v->size );
+  for( i=0; i<v->size; i++ ) fprintf( fp, " %.10g", v->buf[i] );
+  fprintf( fp, " )\n" );
+}
+
+/* ---- chain / joint views ------------------------------------------------------------ */
+int rkChainJointSize(rkChain *c){ return c->ndof; }
+int rkChainLinkNum(rkChain *c){ return c->nlink; }
+void rkChainGetJointDisAll(rkChain *c, zVec dis)
+{
+  memcpy( dis->buf, c->fd->dis->buf + c->dof_off, sizeof(double)*c->ndof );
+}
+void rkChainGetJointVelAll(rkChain *c, zVec vel)
+{
+  memcpy( vel->buf, c->fd->vel->buf + c->dof_off, sizeof(double)*c->ndof );
+}
+static int joint_dof_off(rkJoint *j, int *dof)
+{
+  rkFDImpl *im = IMPL( j->chain->fd );
+  rkfdChainDesc *cd = im->world.chain[j->chain->id];
+  int i, off = j->chain->dof_off;
+  for( i=0; i<j->link; i++ ) off += rkfd_joint_dof( cd->link[i].jtype );
+  *dof = rkfd_joint_dof( cd->link[j->link].jtype );
+  return off;
+}
+void rkJointGetDis(rkJoint *j, double *dis)
+{
+  int dof, off = joint_dof_off( j, &dof );
+  memcpy( dis, j->chain->fd->dis->buf + off, sizeof(double)*dof );
+}
+void rkJointGetVel(rkJoint *j, double *vel)
+{
+  int dof, off = joint_dof_off( j, &dof );
+  memcpy( vel, j->chain->fd->vel->buf + off, sizeof(double)*dof );
+}
+void rkJointMotorSetInput(rkJoint *j, double *input)
+{
+  rkFDImpl *im = IMPL( j->chain->fd );
+  if( im->motor_in ) im->motor_in[j->chain->link_off + j->link] = *input;
+}
+
+/* ---- solver plugin table -------------------------------------------------------------- */
+void rkFDSolverInit(rkFDSolver *solver)
+{
+  solver->prp = NULL; solver->com = NULL;
+  solver->t = 0; solver->fdprp = NULL; solver->cd = NULL; solver->fd = NULL;
+}
+void rkFDSolverReset(rkFDSolver *solver)
+{
+  if( solver->prp ) free( solver->prp );
+  solver->prp = NULL; solver->com = NULL;
+}
+void rkFDSolverDestroy(rkFDSolver *solver)
+{
+  rkFDSolverReset( solver );
+  rkFDSolverInit( solver );
+}
+
+static void defci_vert(rkFDSolver *s, rkContactInfo *ci)
+{ /* reference src/rkfd_vert.c:340-348 */
+  (void)s; memset( ci, 0, sizeof(*ci) );
+  ci->type = RKFD_CONTACT_RIGID; ci->k = 1000.0; ci->l = 1.0; ci->sf = 0.5; ci->kf = 0.3;
+}
+static void defci_mlcp(rkFDSolver *s, rkContactInfo *ci)
+{ /* reference src/rkfd_mlcp.c:301-310 */
+  (void)s; memset( ci, 0, sizeof(*ci) );
+  ci->type = RKFD_CONTACT_RIGID; ci->sf = 0.5; ci->kf = 0.3; ci->k = 1000.0; ci->l = 1.0;
+}
+static bool solver_init(rkFDSolver *s)
+{
+  rkFD *fd = s->fd;
+  rkFDImpl *im = IMPL( fd );
+  rkFDSolverPrpAMD *p = (rkFDSolverPrpAMD *)s->prp;
+  if( im->batch ){ rkfdBatchDestroy( im->batch ); im->batch = NULL; }
+  if( !rkFDBuildModel( fd ) ) return false;
+  im->batch = rkfdBatchCreate( &im->world.model, 1, 0, p->max_rigid );
+  if( !im->batch ){
+    fprintf( stderr, "rkfd: %s\n", rkfdHipLastError() );
+    return false;
+  }
+  return true;
+}
+static void solver_colchk(rkFDSolver *s, bool doUpRef){ (void)s; (void)doUpRef; /* fused into _update */ }
+static bool solver_update(rkFDSolver *s, bool doUpRef)
+{
+  rkFDImpl *im = IMPL( s->fd );
+  if( !im->batch ) return false;
+  return rkfdBatchEval( im->batch, doUpRef ? 1 : 0, NULL ) == 0;
+}
+static void solver_update_ref(rkFDSolver *s){ (void)s; /* prev driving torque is committed on the device */ }
+static void solver_destroy(rkFDSolver *s)
+{
+  rkFDImpl *im = IMPL( s->fd );
+  if( im->batch ){ rkfdBatchDestroy( im->batch ); im->batch = NULL; }
+}
+static rkFDSolverCom rkfd_solver_Vert = { defci_vert, solver_init, solver_colchk, solver_update, solver_update_ref, solver_destroy };
+static rkFDSolverCom rkfd_solver_MLCP = { defci_mlcp, solver_init, solver_colchk, solver_update, solver_update_ref, solver_destroy };
+
+static rkFDSolver *solver_create(rkFDSolver *s, int kind, rkFDSolverCom *com)
+{
+  rkFDSolverPrpAMD *p = (rkFDSolverPrpAMD *)malloc( sizeof(rkFDSolverPrpAMD) );
+  if( !p ) return NULL;
+  p->kind = kind; p->max_rigid = 16;
+  s->prp = p; s->com = com;
+  return s;
+}
+rkFDSolver *rkFDSolverCreate_Vert(rkFDSolver *s){ return solver_create( s, RKFD_SOLVER_VERT, &rkfd_solver_Vert ); }
+rkFDSolver *rkFDSolverCreate_MLCP(rkFDSolver *s){ return solver_create( s, RKFD_SOLVER_MLCP, &rkfd_solver_MLCP ); }
+
+/* ---- rkFD --------------------------------------------------------------------------- */
+rkFD *rkFDCreate(rkFD *fd)
+{
+  rkFDImpl *im = (rkFDImpl *)calloc( 1, sizeof(rkFDImpl) );
+  if( !im ) return NULL;
+  memset( fd, 0, sizeof(rkFD) );
+  fd->impl = im;
+  rkfdWorldInit( &im->world );
+  fd->t = 0.0;
+  /* rkFDPrpInit (reference src/rkfd_property.c:10-18) */
+  fd->prp.dt = 0.001; fd->prp.pyramid = 8; fd->prp.friction_weight = 100; fd->prp.max_iter = 10; fd->prp.vel_eps = 1.0e-8;
+  fd->cd.world = &im->world;
+  rkFDSolverInit( &fd->solver );
+  fd->solver.fdprp = &fd->prp; fd->solver.cd = &fd->cd; fd->solver.fd = fd;
+  rkFDSetSolver( fd, Vert );   /* default collision solver (reference src/rkfd_sim.c:52) */
+  return fd;
+}
+
+void rkFDDestroy(rkFD *fd)
+{
+  rkFDImpl *im = IMPL( fd );
+  rkFDCell *c, *n;
+  if( !im ) return;
+  if( im->batch ) rkfdBatchDestroy( im->batch );
+  rkFDSolverDestroy( &fd->solver );
+  for( c=fd->list; c; c=n ){ n = c->next; free( c->chain.joint ); free( c ); }
+  zVecFree( fd->dis ); zVecFree( fd->vel ); zVecFree( fd->acc );
+  rkfdWorldDestroy( &im->world );
+  free( im->motor_in );
+  free( im );
+  memset( fd, 0, sizeof(rkFD) );
+}
+
+rkFDCell *rkFDChainRegFile(rkFD *fd, char filename[])
+{
+  rkFDImpl *im = IMPL( fd );
+  rkfdChainDesc *cd;
+  rkFDCell *lc, **tail;
+  zVec nd, nv, na;
+  int id, i;
+
+  if( !( cd = rkfdChainReadZTK( filename ) ) ) return NULL;
+  if( !( lc = (rkFDCell *)calloc( 1, sizeof(rkFDCell) ) ) ){ rkfdChainDescFree( cd ); return NULL; }
+  lc->chain.link_off = rkfdWorldChainLinkOffset( &im->world, im->world.nchain );
+  lc->chain.dof_off  = rkfdWorldChainDofOffset( &im->world, im->world.nchain );
+  if( ( id = rkfdWorldAddChain( &im->world, cd ) ) < 0 ){ rkfdChainDescFree( cd ); free( lc ); return NULL; }
+  lc->chain.fd = fd; lc->chain.id = id; lc->chain.nlink = cd->nlink; lc->chain.ndof = cd->ndof;
+  lc->chain.joint = (rkJoint *)calloc( cd->nlink, sizeof(rkJoint) );
+  for( i=0; i<cd->nlink; i++ ){ lc->chain.joint[i].chain = &lc->chain; lc->chain.joint[i].link = i; }
+  for( tail=&fd->list; *tail; tail=&(*tail)->next );
+  *tail = lc;
+  /* grow the packed joint state (reference src/rkfd_sim.c:79-110) */
+  nd = zVecAlloc( fd->size + cd->ndof ); nv = zVecAlloc( fd->size + cd->ndof ); na = zVecAlloc( fd->size + cd->ndof );
+  if( !nd || !nv || !na ){ zVecFree( nd ); zVecFree( nv ); zVecFree( na ); rkFDDestroy( fd ); return NULL; }
+  if( fd->size ){
+    memcpy( nd->buf, fd->dis->buf, sizeof(double)*fd->size );
+    memcpy( nv->buf, fd->vel->buf, sizeof(double)*fd->size );
+  }
+  zVecFree( fd->dis ); zVecFree( fd->vel ); zVecFree( fd->acc );
+  fd->dis = nd; fd->vel = nv; fd->acc = na;
+  fd->size += cd->ndof;
+  im->motor_in = (double *)realloc( im->motor_in, sizeof(double)*( lc->chain.link_off + cd->nlink ) );
+  for( i=0; i<cd->nlink; i++ ) im->motor_in[lc->chain.link_off+i] = 0.0;
+  im->dirty = 1; im->ncell++;
+  return lc;
+}
+
+void rkFDChainSetDis(rkFDCell *lc, zVec dis)
+{
+  rkFD *fd = lc->chain.fd;
+  memcpy( fd->dis->buf + lc->chain.dof_off, dis->buf, sizeof(double)*lc->chain.ndof );
+  IMPL( fd )->dirty = 1;
+}
+void rkFDChainSetVel(rkFDCell *lc, zVec vel)
+{
+  rkFD *fd = lc->chain.fd;
+  memcpy( fd->vel->buf + lc->chain.dof_off, vel->buf, sizeof(double)*lc->chain.ndof );
+  IMPL( fd )->dirty = 1;
+}
+
+bool rkFDContactInfoScanFile(rkFD *fd, char filename[])
+{
+  return rkfdWorldSetContactInfo( &IMPL( fd )->world, filename ) == 0;
+}
+
+void rkCDPairChainUnreg(rkFDCD *cd, rkChain *chain)
+{
+  rkfdWorldPairChainUnreg( (rkfdWorld *)cd->world, chain->id );
+}
+
+const rkfdModel *rkFDBuildModel(rkFD *fd)
+{
+  rkFDImpl *im = IMPL( fd );
+  rkFDSolverPrpAMD *p = (rkFDSolverPrpAMD *)fd->solver.prp;
+  rkfdWorld *w = &im->world;
+  w->cidef.type = fd->cidef.type; w->cidef.sf = fd->cidef.sf; w->cidef.kf = fd->cidef.kf;
+  w->cidef.k = fd->cidef.k; w->cidef.l = fd->cidef.l; w->cidef.e = fd->cidef.e; w->cidef.v = fd->cidef.v;
+  w->model.dt = fd->prp.dt;
+  w->model.friction_weight = fd->prp.friction_weight;
+  w->model.max_iter = fd->prp.max_iter;
+  w->model.solver = p ? p->kind : RKFD_SOLVER_VERT;
+  if( rkfdWorldBuild( w ) < 0 ) return NULL;
+  return &w->model;
+}
+
+rkfdBatch *rkFDBatchCreate(rkFD *fd, int batch, int device, int max_rigid)
+{
+  const rkfdModel *m = rkFDBuildModel( fd );
+  if( !m ) return NULL;
+  return rkfdBatchCreate( m, batch, device, max_rigid );
+}
+
+static int sync_to_device(rkFD *fd)
+{
+  rkFDImpl *im = IMPL( fd );
+  if( !im->batch ) return -1;
+  if( im->dirty ){
+    if( rkfdBatchSetState( im->batch, fd->dis->buf, fd->vel->buf ) < 0 ) return -1;
+    im->dirty = 0;
+  }
+  return rkfdBatchSetMotorInput( im->batch, im->motor_in );
+}
+
+static void report(rkFD *fd)
+{
+  rkFDImpl *im = IMPL( fd );
+  im->status = im->batch ? rkfdBatchStatus( im->batch, NULL ) : -1;
+  if( im->status != 0 ) fprintf( stderr, "rkfd: %s\n", rkfdHipLastError() );
+}
+
+void rkFDUpdateInit(rkFD *fd)
+{
+  rkFDImpl *im = IMPL( fd );
+  im->dirty = 1;
+  if( !rkFDSolverUpdateInit( &fd->solver ) ){ im->status = -1; return; }
+  if( sync_to_device( fd ) < 0 || rkfdBatchUpdateInit( im->batch, NULL ) < 0 ){
+    fprintf( stderr, "rkfd: %s\n", rkfdHipLastError() );
+    im->status = -1;
+    return;
+  }
+  report( fd );
+  rkfdBatchGetState( im->batch, NULL, NULL, fd->acc->buf );
+}
+
+rkFD *rkFDUpdate(rkFD *fd)
+{
+  rkFDImpl *im = IMPL( fd );
+  if( !im->batch ){
+    fprintf( stderr, "rkfd: rkFDUpdate called without a device batch (rkFDUpdateInit failed or missing)\n" );
+    im->status = -1;
+    return fd;
+  }
+  if( sync_to_device( fd ) < 0 || rkfdBatchUpdate( im->batch, 1, NULL ) < 0 ){
+    fprintf( stderr, "rkfd: %s\n", rkfdHipLastError() );
+    im->status = -1;
+    return fd;
+  }
+  report( fd );
+  rkfdBatchGetState( im->batch, fd->dis->buf, fd->vel->buf, fd->acc->buf );
+  fd->t += rkFDDT( fd );
+  return fd;
+}
+
+void rkFDUpdateDestroy(rkFD *fd)
+{
+  if( fd->solver.com ) rkFDSolverUpdateDestroy( &fd->solver );
+}
+
+rkFD *rkFDSolve(rkFD *fd)
+{
+  rkFDUpdateInit( fd );
+  rkFDUpdate( fd );
+  rkFDUpdateDestroy( fd );
+  return fd;
+}
+
+int rkFDStatus(rkFD *fd){ return IMPL( fd )->status; }
+
+/* ---- flat entry points for FFI users that drive the world builder directly ----------- */
+rkfdWorld *rkfdWorldCreate(void)
+{
+  rkfdWorld *w = (rkfdWorld *)malloc( sizeof(rkfdWorld) );
+  if( w ) rkfdWorldInit( w );
+  return w;
+}
+void rkfdWorldFree(rkfdWorld *w){ if( w ){ rkfdWorldDestroy( w ); free( w ); } }
+int rkfdWorldRegFile(rkfdWorld *w, const char *filename)
+{
+  rkfdChainDesc *c = rkfdChainReadZTK( filename );
+  int id;
+  if( !c ) return -1;
+  if( ( id = rkfdWorldAddChain( w, c ) ) < 0 ) rkfdChainDescFree( c );
+  return id;
+}
+void rkfdWorldSetPrp(rkfdWorld *w, double dt, double friction_weight, int max_iter, int solver)
+{
+  w->model.dt = dt; w->model.friction_weight = friction_weight; w->model.max_iter = max_iter; w->model.solver = solver;
+  /* default contact info follows the solver, as rkFDSetSolver does */
+  w->cidef.type = RKFD_CONTACT_RIGID; w->cidef.k = 1000.0; w->cidef.l = 1.0; w->cidef.sf = 0.5; w->cidef.kf = 0.3;
+  w->built = 0;
+}
+const rkfdModel *rkfdWorldModel(rkfdWorld *w)
+{
+  if( !w->built && rkfdWorldBuild( w ) < 0 ) return NULL;
+  return &w->model;
+}
+int rkfdWorldChainInitDis(const rkfdWorld *w, int chain, double *dis)
+{
+  if( chain < 0 || chain >= w->nchain ) return -1;
+  memcpy( dis, w->chain[chain]->init_dis, sizeof(double)*w->chain[chain]->ndof );
+  return w->chain[chain]->ndof;
+}

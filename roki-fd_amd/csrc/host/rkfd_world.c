@@ -1,0 +1,258 @@
+/* rkfd_world.c - flatten registered chains into an rkfdModel.
+ * Role in the reference: rkFD cell list + packed joint state offsets
+ * (reference src/rkfd_sim.c:72-110,188-209), rkCD cell/pair registry (RoKi rk_cd,
+ * un-vendored) and contact-info association by "stuff" (reference src/rkfd_sim.c:200-207).
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "rkfd_world.h"
+
+void rkfdWorldInit(rkfdWorld *w)
+{
+  memset( w, 0, sizeof(rkfdWorld) );
+  /* default contact info of the default solver (Vert), reference src/rkfd_vert.c:340-348 */
+  w->cidef.type = RKFD_CONTACT_RIGID;
+  w->cidef.k = 1000.0; w->cidef.l = 1.0; w->cidef.sf = 0.5; w->cidef.kf = 0.3;
+  /* rkFDPrpInit defaults, reference src/rkfd_property.c:10-18, include/roki_fd/rkfd_defs.h:15-23 */
+  w->model.dt = 0.001;
+  w->model.friction_weight = 100.0;
+  w->model.max_iter = 10;
+  w->model.solver = RKFD_SOLVER_VERT;
+}
+
+void rkfdWorldDestroy(rkfdWorld *w)
+{
+  int i;
+  for( i=0; i<w->nchain; i++ ) rkfdChainDescFree( w->chain[i] );
+  free( w->chain ); free( w->nopair ); free( w->ci ); free( w->blob ); free( w->pair_off );
+  memset( w, 0, sizeof(rkfdWorld) );
+}
+
+int rkfdWorldAddChain(rkfdWorld *w, rkfdChainDesc *c)
+{
+  int n = w->nchain, i, j;
+  unsigned char *np;
+
+  w->chain = (rkfdChainDesc **)realloc( w->chain, sizeof(rkfdChainDesc*)*(n+1) );
+  np = (unsigned char *)calloc( (size_t)(n+1)*(n+1), 1 );
+  if( !w->chain || !np ) return -1;
+  for( i=0; i<n; i++ )
+    for( j=0; j<n; j++ ) np[i*(n+1)+j] = w->nopair[i*n+j];
+  free( w->nopair );
+  w->nopair = np;
+  w->chain[n] = c;
+  w->nchain = n+1;
+  w->built = 0;
+  return n;
+}
+
+void rkfdWorldPairChainUnreg(rkfdWorld *w, int chain)
+{
+  int j, n = w->nchain;
+  if( chain < 0 || chain >= n ) return;
+  for( j=0; j<n; j++ ){
+    w->nopair[chain*n+j] = 1;
+    w->nopair[j*n+chain] = 1;
+  }
+  w->built = 0;
+}
+
+int rkfdWorldSetContactInfo(rkfdWorld *w, const char *filename)
+{
+  rkfdContactInfo *ci;
+  int n = rkfdContactInfoReadZTK( filename, &ci );
+  if( n < 0 ) return -1;
+  free( w->ci );
+  w->ci = ci; w->nci = n;
+  w->built = 0;
+  return 0;
+}
+
+int rkfdWorldChainDofOffset(const rkfdWorld *w, int chain)
+{
+  int i, off = 0;
+  for( i=0; i<chain; i++ ) off += w->chain[i]->ndof;
+  return off;
+}
+
+int rkfdWorldChainLinkOffset(const rkfdWorld *w, int chain)
+{
+  int i, off = 0;
+  for( i=0; i<chain; i++ ) off += w->chain[i]->nlink;
+  return off;
+}
+
+static int assoc_ci(const rkfdWorld *w, const char *s0, const char *s1)
+{
+  int i;
+  for( i=0; i<w->nci; i++ ){
+    if( ( strcmp( w->ci[i].stuff[0], s0 ) == 0 && strcmp( w->ci[i].stuff[1], s1 ) == 0 ) ||
+        ( strcmp( w->ci[i].stuff[0], s1 ) == 0 && strcmp( w->ci[i].stuff[1], s0 ) == 0 ) ) return i;
+  }
+  return w->nci; /* default entry */
+}
+
+/* bump allocator over one blob */
+typedef struct { char *base; size_t off; } Arena;
+static void *arena_get(Arena *a, size_t bytes)
+{
+  void *p;
+  a->off = ( a->off + 15 ) & ~(size_t)15;
+  p = a->base ? a->base + a->off : NULL;
+  a->off += bytes;
+  return p;
+}
+
+int rkfdWorldBuild(rkfdWorld *w)
+{
+  int pass, c, i, k, s;
+  int nlink = 0, ndof = 0, nshape = 0, nvert = 0, nplane = 0, npair = 0, ncand = 0;
+  rkfdModel *m = &w->model;
+  Arena a = { NULL, 0 };
+  /* arrays (non-const views while filling) */
+  int *parent = NULL, *jtype = NULL, *dofoff = NULL, *chain = NULL, *mtype = NULL;
+  double *org = NULL, *mass = NULL, *com = NULL, *inertia = NULL;
+  double *stiff = NULL, *visc = NULL, *coulomb = NULL, *sfric = NULL;
+  double *mot_k = NULL, *mot_admit = NULL, *mot_vmax = NULL, *mot_vmin = NULL, *mot_gear = NULL, *mot_inertia = NULL;
+  int *shape_link = NULL, *shape_voff = NULL, *shape_foff = NULL, *shape_chain = NULL;
+  double *verts = NULL, *planes = NULL;
+  int *pair_shape = NULL, *pair_ci = NULL, *ci_type = NULL;
+  double *ci_sf = NULL, *ci_kf = NULL, *ci_k = NULL, *ci_l = NULL, *ci_e = NULL, *ci_v = NULL;
+  int *cand_pair = NULL, *cand_side = NULL, *cand_vert = NULL;
+  const char **shape_stuff = NULL;
+
+  /* counts */
+  for( c=0; c<w->nchain; c++ ){
+    rkfdChainDesc *cd = w->chain[c];
+    nlink += cd->nlink; ndof += cd->ndof;
+    for( i=0; i<cd->nlink; i++ )
+      for( s=0; s<cd->link[i].nshape; s++ ){
+        rkfdShape *sh = &cd->shape[cd->link[i].shape[s]];
+        if( sh->nvert == 0 || sh->nplane == 0 ) continue;
+        nshape++; nvert += sh->nvert; nplane += sh->nplane;
+      }
+  }
+
+  /* count pairs and candidates */
+  {
+    int *sc = (int *)malloc( sizeof(int)*( nshape ? nshape : 1 ) );
+    int *sv = (int *)malloc( sizeof(int)*( nshape ? nshape : 1 ) );
+    int n = 0, x, y;
+    for( c=0; c<w->nchain; c++ ){
+      rkfdChainDesc *cd = w->chain[c];
+      for( i=0; i<cd->nlink; i++ )
+        for( s=0; s<cd->link[i].nshape; s++ ){
+          rkfdShape *sh = &cd->shape[cd->link[i].shape[s]];
+          if( sh->nvert == 0 || sh->nplane == 0 ) continue;
+          sc[n] = c; sv[n] = sh->nvert; n++;
+        }
+    }
+    for( y=0; y<n; y++ )
+      for( x=0; x<y; x++ ){
+        if( sc[x] == sc[y] ) continue;
+        if( w->nopair[sc[x]*w->nchain+sc[y]] ) continue;
+        npair++; ncand += sv[x] + sv[y];
+      }
+    free( sc ); free( sv );
+  }
+
+  for( pass=0; pass<2; pass++ ){
+    int li = 0, si = 0, vi = 0, fi = 0, doff = 0, pi = 0, ci = 0;
+    if( pass == 1 ){
+      free( w->blob );
+      w->blob = calloc( 1, a.off + 64 );
+      if( !w->blob ) return -1;
+      a.base = (char *)w->blob; a.off = 0;
+    }
+#define GET(ptr,type,n) ptr = (type *)arena_get( &a, sizeof(type)*( (n) > 0 ? (n) : 1 ) )
+    GET( parent, int, nlink ); GET( jtype, int, nlink ); GET( dofoff, int, nlink ); GET( chain, int, nlink );
+    GET( mtype, int, nlink );
+    GET( org, double, nlink*12 ); GET( mass, double, nlink ); GET( com, double, nlink*3 ); GET( inertia, double, nlink*9 );
+    GET( stiff, double, nlink ); GET( visc, double, nlink ); GET( coulomb, double, nlink ); GET( sfric, double, nlink );
+    GET( mot_k, double, nlink ); GET( mot_admit, double, nlink ); GET( mot_vmax, double, nlink );
+    GET( mot_vmin, double, nlink ); GET( mot_gear, double, nlink ); GET( mot_inertia, double, nlink );
+    GET( shape_link, int, nshape ); GET( shape_voff, int, nshape+1 ); GET( shape_foff, int, nshape+1 );
+    GET( shape_chain, int, nshape );
+    GET( shape_stuff, const char *, nshape );
+    GET( verts, double, nvert*3 ); GET( planes, double, nplane*4 );
+    GET( pair_shape, int, npair*2 ); GET( pair_ci, int, npair );
+    GET( ci_type, int, w->nci+1 ); GET( ci_sf, double, w->nci+1 ); GET( ci_kf, double, w->nci+1 );
+    GET( ci_k, double, w->nci+1 ); GET( ci_l, double, w->nci+1 ); GET( ci_e, double, w->nci+1 ); GET( ci_v, double, w->nci+1 );
+    GET( cand_pair, int, ncand ); GET( cand_side, int, ncand ); GET( cand_vert, int, ncand );
+#undef GET
+    if( pass == 0 ) continue;
+    /* fill */
+    for( c=0; c<w->nchain; c++ ){
+      rkfdChainDesc *cd = w->chain[c];
+      int lbase = li;
+      for( i=0; i<cd->nlink; i++, li++ ){
+        rkfdLinkDesc *l = &cd->link[i];
+        parent[li] = l->parent < 0 ? -1 : lbase + l->parent;
+        jtype[li] = l->jtype; dofoff[li] = doff; chain[li] = c;
+        doff += rkfd_joint_dof( l->jtype );
+        memcpy( &org[12*li], l->org, sizeof(double)*12 );
+        mass[li] = l->mass;
+        memcpy( &com[3*li], l->com, sizeof(double)*3 );
+        memcpy( &inertia[9*li], l->inertia, sizeof(double)*9 );
+        if( rkfd_joint_dof( l->jtype ) == 1 ){
+          stiff[li] = l->stiff; visc[li] = l->visc; coulomb[li] = l->coulomb; sfric[li] = l->sfric;
+          if( l->motor >= 0 ){
+            rkfdMotor *mo = &cd->motor[l->motor];
+            mtype[li] = mo->type;
+            mot_k[li] = mo->k; mot_admit[li] = mo->admit; mot_vmax[li] = mo->vmax; mot_vmin[li] = mo->vmin;
+            mot_gear[li] = mo->gear; mot_inertia[li] = mo->rotor_inertia + mo->gear_inertia;
+          }
+        }
+        for( s=0; s<l->nshape; s++ ){
+          rkfdShape *sh = &cd->shape[l->shape[s]];
+          if( sh->nvert == 0 || sh->nplane == 0 ) continue;
+          shape_link[si] = li; shape_chain[si] = c; shape_stuff[si] = l->stuff;
+          shape_voff[si] = vi; shape_foff[si] = fi;
+          memcpy( &verts[3*vi], sh->vert, sizeof(double)*3*sh->nvert );
+          memcpy( &planes[4*fi], sh->plane, sizeof(double)*4*sh->nplane );
+          vi += sh->nvert; fi += sh->nplane; si++;
+        }
+      }
+    }
+    shape_voff[nshape] = vi; shape_foff[nshape] = fi;
+    /* contact infos: file entries then the solver default */
+    for( i=0; i<=w->nci; i++ ){
+      const rkfdContactInfo *q = i < w->nci ? &w->ci[i] : &w->cidef;
+      ci_type[i] = q->type; ci_sf[i] = q->sf; ci_kf[i] = q->kf;
+      ci_k[i] = q->k; ci_l[i] = q->l; ci_e[i] = q->e; ci_v[i] = q->v;
+    }
+    /* pairs: each later-registered cell against every earlier cell of another chain */
+    {
+      int x, y;
+      for( y=0; y<nshape; y++ )
+        for( x=0; x<y; x++ ){
+          if( shape_chain[x] == shape_chain[y] ) continue;
+          if( w->nopair[shape_chain[x]*w->nchain+shape_chain[y]] ) continue;
+          pair_shape[2*pi] = x; pair_shape[2*pi+1] = y;
+          pair_ci[pi] = assoc_ci( w, shape_stuff[x], shape_stuff[y] );
+          for( s=0; s<2; s++ ){
+            int sh = pair_shape[2*pi+s];
+            for( k=shape_voff[sh]; k<shape_voff[sh+1]; k++ ){
+              cand_pair[ci] = pi; cand_side[ci] = s; cand_vert[ci] = k; ci++;
+            }
+          }
+          pi++;
+        }
+    }
+  }
+
+  m->nlink = nlink; m->ndof = ndof; m->nchain = w->nchain;
+  m->parent = parent; m->jtype = jtype; m->dofoff = dofoff; m->chain = chain;
+  m->org = org; m->mass = mass; m->com = com; m->inertia = inertia;
+  m->stiff = stiff; m->visc = visc; m->coulomb = coulomb; m->sfric = sfric;
+  m->mtype = mtype; m->mot_k = mot_k; m->mot_admit = mot_admit; m->mot_vmax = mot_vmax;
+  m->mot_vmin = mot_vmin; m->mot_gear = mot_gear; m->mot_inertia = mot_inertia;
+  m->nshape = nshape; m->shape_link = shape_link; m->shape_voff = shape_voff; m->shape_foff = shape_foff;
+  m->verts = verts; m->planes = planes;
+  m->npair = npair; m->pair_shape = pair_shape; m->pair_ci = pair_ci;
+  m->nci = w->nci+1; m->ci_type = ci_type; m->ci_sf = ci_sf; m->ci_kf = ci_kf;
+  m->ci_k = ci_k; m->ci_l = ci_l; m->ci_e = ci_e; m->ci_v = ci_v;
+  m->ncand = ncand; m->cand_pair = cand_pair; m->cand_side = cand_side; m->cand_vert = cand_vert;
+  w->built = 1;
+  return 0;
+}

@@ -1,0 +1,210 @@
+/* rkfd_capi.hip - C ABI (include/rkfd_hip.h) over the gfx950 kernel in rkfd_device.h. */
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "rkfd_hip.h"
+#include "rkfd_device.h"
+#include "rkfd_devmodel_host.h"
+
+static thread_local char g_err[512] = "";
+#define SETERR(...) snprintf( g_err, sizeof(g_err), __VA_ARGS__ )
+#define HIPCHK(call, ret) do{ hipError_t e_ = (call); if( e_ != hipSuccess ){ \
+  SETERR( "%s failed: %s", #call, hipGetErrorString( e_ ) ); return ret; } }while(0)
+
+/* one workgroup = one wavefront = one world instance; state lives in LDS for the whole launch */
+extern "C" __global__ void __launch_bounds__(RKFD_WAVE)
+rkfd_step_kernel(rkfdDevModel m, rkfdDevState st, int mode, int nsteps, int *errflag)
+{
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int b = blockIdx.x;
+  if( b >= st.batch ) return;
+  rkfd_instance( m, st, b, lds, mode, nsteps, errflag );
+}
+
+struct rkfdBatch {
+  int device, batch, nlink, ndof, ncand;
+  rkfdDevModelHost host;
+  rkfdDevModel dm;        /* device-pointer version */
+  void *dblob;
+  rkfdDevState st;
+  int *d_err;
+  size_t lds_bytes;
+};
+
+extern "C" const char *rkfdHipLastError(void){ return g_err; }
+
+extern "C" int rkfdHipDeviceCount(void)
+{
+  int n = 0;
+  if( hipGetDeviceCount( &n ) != hipSuccess ) return 0;
+  return n;
+}
+
+template<class T> static int dalloc(T **p, size_t n)
+{
+  hipError_t e = hipMalloc( (void **)p, sizeof(T)*( n ? n : 1 ) );
+  if( e != hipSuccess ){ SETERR( "hipMalloc(%zu bytes) failed: %s", sizeof(T)*n, hipGetErrorString( e ) ); return -1; }
+  e = hipMemset( *p, 0, sizeof(T)*( n ? n : 1 ) );
+  if( e != hipSuccess ){ SETERR( "hipMemset failed: %s", hipGetErrorString( e ) ); return -1; }
+  return 0;
+}
+
+extern "C" rkfdBatch *rkfdBatchCreate(const rkfdModel *m, int batch, int device, int max_rigid)
+{
+  if( !m || batch < 1 ){ SETERR( "rkfdBatchCreate: bad arguments" ); return NULL; }
+  int ndev = 0;
+  if( hipGetDeviceCount( &ndev ) != hipSuccess || ndev == 0 ){
+    SETERR( "rkfdBatchCreate: no HIP device available (the MI355X path has no CPU fallback)" );
+    return NULL;
+  }
+  if( device < 0 || device >= ndev ){ SETERR( "rkfdBatchCreate: device %d out of range (%d visible)", device, ndev ); return NULL; }
+  HIPCHK( hipSetDevice( device ), NULL );
+
+  rkfdBatch *b = (rkfdBatch *)calloc( 1, sizeof(rkfdBatch) );
+  if( !b ){ SETERR( "out of memory" ); return NULL; }
+  char err[256];
+  if( rkfd_devmodel_build( m, max_rigid, &b->host, err, sizeof(err) ) < 0 ){
+    SETERR( "rkfdBatchCreate: %s", err );
+    free( b );
+    return NULL;
+  }
+  b->device = device; b->batch = batch; b->nlink = m->nlink; b->ndof = m->ndof; b->ncand = m->ncand;
+  b->lds_bytes = b->host.lds_bytes;
+  if( b->lds_bytes > 160*1024 ){
+    SETERR( "rkfdBatchCreate: one instance needs %zu bytes of LDS (> 160 KiB)", b->lds_bytes );
+    rkfd_devmodel_free( &b->host ); free( b );
+    return NULL;
+  }
+  if( hipMalloc( &b->dblob, b->host.bytes ) != hipSuccess ||
+      hipMemcpy( b->dblob, b->host.blob, b->host.bytes, hipMemcpyHostToDevice ) != hipSuccess ){
+    SETERR( "rkfdBatchCreate: cannot copy the model to the device" );
+    rkfd_devmodel_free( &b->host ); free( b );
+    return NULL;
+  }
+  b->dm = b->host.dm;
+  rkfd_devmodel_rebase( &b->dm, b->host.blob, b->dblob );
+
+  const size_t B = batch, ND = m->ndof, NL = m->nlink, NC = m->ncand;
+  int bad = 0;
+  bad |= dalloc( &b->st.dis, B*ND ); bad |= dalloc( &b->st.vel, B*ND ); bad |= dalloc( &b->st.acc, B*ND );
+  bad |= dalloc( &b->st.motor_in, B*NL ); bad |= dalloc( &b->st.piv_type, B*NL ); bad |= dalloc( &b->st.piv_prev, B*NL );
+  bad |= dalloc( &b->st.cv_active, B*NC ); bad |= dalloc( &b->st.cv_type, B*NC );
+  bad |= dalloc( &b->st.cv_ref, B*NC*3 ); bad |= dalloc( &b->st.cv_f, B*NC*3 );
+  bad |= dalloc( &b->d_err, 1 );
+  b->st.dbg = NULL; b->st.dbg_stride = 0; b->st.batch = batch;
+  if( bad ){ rkfdBatchDestroy( b ); return NULL; }
+  if( b->lds_bytes > 64*1024 ){
+    hipError_t e = hipFuncSetAttribute( (const void *)rkfd_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes );
+    if( e != hipSuccess ){ SETERR( "hipFuncSetAttribute(LDS=%zu) failed: %s", b->lds_bytes, hipGetErrorString( e ) ); rkfdBatchDestroy( b ); return NULL; }
+  }
+  return b;
+}
+
+extern "C" void rkfdBatchDestroy(rkfdBatch *b)
+{
+  if( !b ) return;
+  (void)hipFree( b->st.dis ); (void)hipFree( b->st.vel ); (void)hipFree( b->st.acc );
+  (void)hipFree( b->st.motor_in ); (void)hipFree( b->st.piv_type ); (void)hipFree( b->st.piv_prev );
+  (void)hipFree( b->st.cv_active ); (void)hipFree( b->st.cv_type ); (void)hipFree( b->st.cv_ref ); (void)hipFree( b->st.cv_f );
+  (void)hipFree( b->d_err ); (void)hipFree( b->dblob );
+  rkfd_devmodel_free( &b->host );
+  free( b );
+}
+
+extern "C" int rkfdBatchSize(const rkfdBatch *b){ return b ? b->batch : -1; }
+extern "C" int rkfdBatchDof(const rkfdBatch *b){ return b ? b->ndof : -1; }
+extern "C" int rkfdBatchLdsBytes(const rkfdBatch *b){ return b ? (int)b->lds_bytes : -1; }
+extern "C" double *rkfdBatchDevDis(rkfdBatch *b){ return b ? b->st.dis : NULL; }
+extern "C" double *rkfdBatchDevVel(rkfdBatch *b){ return b ? b->st.vel : NULL; }
+extern "C" double *rkfdBatchDevAcc(rkfdBatch *b){ return b ? b->st.acc : NULL; }
+
+#define H2D(dst, src, bytes) do{ if( src ) HIPCHK( hipMemcpy( dst, src, bytes, hipMemcpyHostToDevice ), -1 ); }while(0)
+#define D2H(dst, src, bytes) do{ if( dst ) HIPCHK( hipMemcpy( dst, src, bytes, hipMemcpyDeviceToHost ), -1 ); }while(0)
+
+extern "C" int rkfdBatchSetState(rkfdBatch *b, const double *dis, const double *vel)
+{
+  if( !b ){ SETERR( "null batch" ); return -1; }
+  HIPCHK( hipSetDevice( b->device ), -1 );
+  const size_t n = sizeof(double)*(size_t)b->batch*b->ndof;
+  H2D( b->st.dis, dis, n ); H2D( b->st.vel, vel, n );
+  return 0;
+}
+extern "C" int rkfdBatchGetState(rkfdBatch *b, double *dis, double *vel, double *acc)
+{
+  if( !b ){ SETERR( "null batch" ); return -1; }
+  HIPCHK( hipSetDevice( b->device ), -1 );
+  const size_t n = sizeof(double)*(size_t)b->batch*b->ndof;
+  D2H( dis, b->st.dis, n ); D2H( vel, b->st.vel, n ); D2H( acc, b->st.acc, n );
+  return 0;
+}
+extern "C" int rkfdBatchSetMotorInput(rkfdBatch *b, const double *input)
+{
+  if( !b ){ SETERR( "null batch" ); return -1; }
+  HIPCHK( hipSetDevice( b->device ), -1 );
+  H2D( b->st.motor_in, input, sizeof(double)*(size_t)b->batch*b->nlink );
+  return 0;
+}
+extern "C" int rkfdBatchGetContact(rkfdBatch *b, int *active, int *type, double *ref, double *f)
+{
+  if( !b ){ SETERR( "null batch" ); return -1; }
+  HIPCHK( hipSetDevice( b->device ), -1 );
+  const size_t n = (size_t)b->batch*b->ncand;
+  D2H( active, b->st.cv_active, sizeof(int)*n ); D2H( type, b->st.cv_type, sizeof(int)*n );
+  D2H( ref, b->st.cv_ref, sizeof(double)*3*n ); D2H( f, b->st.cv_f, sizeof(double)*3*n );
+  return 0;
+}
+extern "C" int rkfdBatchSetContact(rkfdBatch *b, const int *active, const int *type, const double *ref)
+{
+  if( !b ){ SETERR( "null batch" ); return -1; }
+  HIPCHK( hipSetDevice( b->device ), -1 );
+  const size_t n = (size_t)b->batch*b->ncand;
+  H2D( b->st.cv_active, active, sizeof(int)*n ); H2D( b->st.cv_type, type, sizeof(int)*n );
+  H2D( b->st.cv_ref, ref, sizeof(double)*3*n );
+  return 0;
+}
+extern "C" int rkfdBatchGetPivot(rkfdBatch *b, int *type, double *prev_trq)
+{
+  if( !b ){ SETERR( "null batch" ); return -1; }
+  HIPCHK( hipSetDevice( b->device ), -1 );
+  const size_t n = (size_t)b->batch*b->nlink;
+  D2H( type, b->st.piv_type, sizeof(int)*n ); D2H( prev_trq, b->st.piv_prev, sizeof(double)*n );
+  return 0;
+}
+extern "C" int rkfdBatchSetPivot(rkfdBatch *b, const int *type, const double *prev_trq)
+{
+  if( !b ){ SETERR( "null batch" ); return -1; }
+  HIPCHK( hipSetDevice( b->device ), -1 );
+  const size_t n = (size_t)b->batch*b->nlink;
+  H2D( b->st.piv_type, type, sizeof(int)*n ); H2D( b->st.piv_prev, prev_trq, sizeof(double)*n );
+  return 0;
+}
+
+static int launch(rkfdBatch *b, int mode, int nsteps, void *stream)
+{
+  if( !b ){ SETERR( "null batch" ); return -1; }
+  HIPCHK( hipSetDevice( b->device ), -1 );
+  hipLaunchKernelGGL( rkfd_step_kernel, dim3( b->batch ), dim3( RKFD_WAVE ), b->lds_bytes, (hipStream_t)stream,
+                      b->dm, b->st, mode, nsteps, b->d_err );
+  HIPCHK( hipGetLastError(), -1 );
+  return 0;
+}
+extern "C" int rkfdBatchUpdateInit(rkfdBatch *b, void *stream){ return launch( b, 1, 0, stream ); }
+extern "C" int rkfdBatchUpdate(rkfdBatch *b, int nsteps, void *stream)
+{
+  if( nsteps < 1 ){ SETERR( "rkfdBatchUpdate: nsteps must be >= 1" ); return -1; }
+  return launch( b, 0, nsteps, stream );
+}
+extern "C" int rkfdBatchEval(rkfdBatch *b, int doUpRef, void *stream){ return launch( b, doUpRef ? 1 : 2, 0, stream ); }
+
+extern "C" int rkfdBatchStatus(rkfdBatch *b, void *stream)
+{
+  if( !b ){ SETERR( "null batch" ); return -1; }
+  HIPCHK( hipSetDevice( b->device ), -1 );
+  HIPCHK( hipStreamSynchronize( (hipStream_t)stream ), -1 );
+  int e = 0;
+  HIPCHK( hipMemcpy( &e, b->d_err, sizeof(int), hipMemcpyDeviceToHost ), -1 );
+  if( e == 1 ) SETERR( "a rigid contact occurred but the selected solver has no device path (use MLCP)" );
+  if( e == 2 ) SETERR( "rigid-contact capacity (max_rigid) exceeded in at least one instance" );
+  return e;
+}

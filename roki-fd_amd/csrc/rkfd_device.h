@@ -1,0 +1,1198 @@
+/* rkfd_device.h - the batched rkFDUpdate step, one world instance per 64-lane wavefront.
+ *
+ * This is the MI355X-native restatement of the reference hot path
+ *   rkFDUpdate -> zODE2Update(RKG) -> _rkFDUpdate -> {FK, CD, contact solver, ABA}
+ *   (reference src/rkfd_sim.c:525-566; src/rkfd_util.c; src/rkfd_penalty.c:11-31;
+ *    src/rkfd_mlcp.c), designed for a wavefront rather than translated:
+ *   - all spatial quantities are expressed in ONE world frame (Pluecker coordinates at
+ *     the world origin, (angular, linear) ordering), so the three ABA sweeps need no
+ *     6x6 congruence transforms: parents simply sum their children's articulated
+ *     inertias;
+ *   - forward kinematics and link velocities are log-depth pointer-jumping scans over
+ *     lanes (lane = link) instead of serial recursions;
+ *   - sweep 2 / sweep 3 run level-synchronously, 8 lanes per link (lane = row of the
+ *     6x6), up to 8 links of a level at once, 6x6 data staged in LDS, 6-lane
+ *     reductions done with DPP;
+ *   - contact candidates, penalty forces, MLCP probe columns and the PGS residual
+ *     update are lane-parallel (lane = candidate / contact / probe column / row).
+ * The file compiles for gfx950 (hipcc) and, with -DRKFD_EMU, under a 64-thread lane
+ * emulator that exists only so that tests can exercise the kernel logic without a GPU
+ * (tests/emu; never part of the product library).
+ */
+#ifndef RKFD_DEVICE_H
+#define RKFD_DEVICE_H
+
+#include <math.h>
+#include "rkfd_model.h"
+#include "rkfd_devmodel.h"
+
+#ifdef RKFD_EMU
+#  define RKFD_DEV static inline
+   int    rkfd_emu_lane(void);
+   void   rkfd_emu_sync(void);
+   double rkfd_emu_g8sum(double x);
+   double rkfd_emu_bcast(double x, int src);
+   unsigned long long rkfd_emu_ballot(int pred);
+#  define LANE()        rkfd_emu_lane()
+#  define SYNC()        rkfd_emu_sync()
+#  define G8SUM(x)      rkfd_emu_g8sum(x)
+#  define BCAST(x,l)    rkfd_emu_bcast(x,l)
+#  define BALLOT(p)     rkfd_emu_ballot(p)
+#else
+#  define RKFD_DEV __device__ __forceinline__
+#  define LANE()        ((int)threadIdx.x)
+#  define SYNC()        __syncthreads()
+RKFD_DEV double rkfd_dpp_xor1(double x)
+{
+  int lo = __double2loint( x ), hi = __double2hiint( x );
+  lo = __builtin_amdgcn_update_dpp( lo, lo, 0xB1, 0xF, 0xF, false ); /* quad_perm [1,0,3,2] */
+  hi = __builtin_amdgcn_update_dpp( hi, hi, 0xB1, 0xF, 0xF, false );
+  return __hiloint2double( hi, lo );
+}
+RKFD_DEV double rkfd_dpp_xor2(double x)
+{
+  int lo = __double2loint( x ), hi = __double2hiint( x );
+  lo = __builtin_amdgcn_update_dpp( lo, lo, 0x4E, 0xF, 0xF, false ); /* quad_perm [2,3,0,1] */
+  hi = __builtin_amdgcn_update_dpp( hi, hi, 0x4E, 0xF, 0xF, false );
+  return __hiloint2double( hi, lo );
+}
+RKFD_DEV double rkfd_dpp_hmirror(double x)
+{
+  int lo = __double2loint( x ), hi = __double2hiint( x );
+  lo = __builtin_amdgcn_update_dpp( lo, lo, 0x141, 0xF, 0xF, false ); /* row_half_mirror */
+  hi = __builtin_amdgcn_update_dpp( hi, hi, 0x141, 0xF, 0xF, false );
+  return __hiloint2double( hi, lo );
+}
+/* sum over the aligned group of 8 lanes, result in every lane of the group */
+RKFD_DEV double rkfd_g8sum(double x)
+{
+  x += rkfd_dpp_xor1( x );
+  x += rkfd_dpp_xor2( x );
+  x += rkfd_dpp_hmirror( x );
+  return x;
+}
+/* broadcast lane src (wave-uniform) to every lane */
+RKFD_DEV double rkfd_bcast(double x, int src)
+{
+  int lo = __builtin_amdgcn_readlane( __double2loint( x ), src );
+  int hi = __builtin_amdgcn_readlane( __double2hiint( x ), src );
+  return __hiloint2double( hi, lo );
+}
+#  define G8SUM(x)      rkfd_g8sum(x)
+#  define BCAST(x,l)    rkfd_bcast(x,l)
+#  define BALLOT(p)     __ballot(p)
+#endif
+
+#define RKFD_DEV_TOL RKFD_TOL
+
+/* ------------------------------------------------------------------------ */
+/* 3-vector helpers on plain arrays */
+RKFD_DEV void d_cross(const double *a, const double *b, double *c)
+{
+  double x = a[1]*b[2]-a[2]*b[1], y = a[2]*b[0]-a[0]*b[2], z = a[0]*b[1]-a[1]*b[0];
+  c[0]=x; c[1]=y; c[2]=z;
+}
+RKFD_DEV double d_dot(const double *a, const double *b){ return a[0]*b[0]+a[1]*b[1]+a[2]*b[2]; }
+RKFD_DEV void d_mulv(const double *m, const double *v, double *r)
+{
+  double x = m[0]*v[0]+m[1]*v[1]+m[2]*v[2], y = m[3]*v[0]+m[4]*v[1]+m[5]*v[2], z = m[6]*v[0]+m[7]*v[1]+m[8]*v[2];
+  r[0]=x; r[1]=y; r[2]=z;
+}
+RKFD_DEV void d_tmulv(const double *m, const double *v, double *r)
+{
+  double x = m[0]*v[0]+m[3]*v[1]+m[6]*v[2], y = m[1]*v[0]+m[4]*v[1]+m[7]*v[2], z = m[2]*v[0]+m[5]*v[1]+m[8]*v[2];
+  r[0]=x; r[1]=y; r[2]=z;
+}
+RKFD_DEV void d_mul33(const double *a, const double *b, double *c)
+{
+  double t[9];
+#pragma unroll
+  for( int i=0; i<3; i++ )
+#pragma unroll
+    for( int j=0; j<3; j++ )
+      t[3*i+j] = a[3*i]*b[j] + a[3*i+1]*b[3+j] + a[3*i+2]*b[6+j];
+#pragma unroll
+  for( int i=0; i<9; i++ ) c[i] = t[i];
+}
+RKFD_DEV void d_from_aa(const double *aa, double *m)
+{
+  double th = sqrt( d_dot( aa, aa ) );
+  if( th < RKFD_DEV_TOL ){
+    m[0]=1; m[1]=0; m[2]=0; m[3]=0; m[4]=1; m[5]=0; m[6]=0; m[7]=0; m[8]=1;
+    return;
+  }
+  double s = sin(th), c = cos(th), k = 1-c;
+  double x = aa[0]/th, y = aa[1]/th, z = aa[2]/th;
+  m[0] = c+k*x*x;   m[1] = k*x*y-s*z; m[2] = k*x*z+s*y;
+  m[3] = k*x*y+s*z; m[4] = c+k*y*y;   m[5] = k*y*z-s*x;
+  m[6] = k*x*z-s*y; m[7] = k*y*z+s*x; m[8] = c+k*z*z;
+}
+RKFD_DEV void d_to_aa(const double *m, double *aa)
+{
+  double l[3] = { m[7]-m[5], m[2]-m[6], m[3]-m[1] };
+  double a = sqrt( d_dot( l, l ) );
+  double th = atan2( a, m[0]+m[4]+m[8]-1.0 );
+  if( a < RKFD_DEV_TOL ){ aa[0]=aa[1]=aa[2]=0; return; }
+  double k = th/a;
+  aa[0] = l[0]*k; aa[1] = l[1]*k; aa[2] = l[2]*k;
+}
+RKFD_DEV void d_ortho_space(const double *n, double *t1, double *t2)
+{
+  int k = 0;
+  if( fabs(n[1]) < fabs(n[k]) ) k = 1;
+  if( fabs(n[2]) < fabs(n[k]) ) k = 2;
+  double e[3] = { k==0 ? 1.0 : 0.0, k==1 ? 1.0 : 0.0, k==2 ? 1.0 : 0.0 };
+  double d = d_dot( e, n );
+  t1[0] = e[0]-d*n[0]; t1[1] = e[1]-d*n[1]; t1[2] = e[2]-d*n[2];
+  double l = sqrt( d_dot( t1, t1 ) );
+  t1[0] /= l; t1[1] /= l; t1[2] /= l;
+  d_cross( n, t1, t2 );
+}
+/* spatial motion cross product v x m and force cross product v x* f, (ang, lin) ordering */
+RKFD_DEV void d_crm(const double *v, const double *m, double *r)
+{
+  double a[3], b[3], c[3];
+  d_cross( v, m, a ); d_cross( v, m+3, b ); d_cross( v+3, m, c );
+  r[0]=a[0]; r[1]=a[1]; r[2]=a[2]; r[3]=b[0]+c[0]; r[4]=b[1]+c[1]; r[5]=b[2]+c[2];
+}
+RKFD_DEV void d_crf(const double *v, const double *f, double *r)
+{
+  double a[3], b[3], c[3];
+  d_cross( v, f, a ); d_cross( v+3, f+3, b ); d_cross( v, f+3, c );
+  r[0]=a[0]+b[0]; r[1]=a[1]+b[1]; r[2]=a[2]+b[2]; r[3]=c[0]; r[4]=c[1]; r[5]=c[2];
+}
+
+/* ------------------------------------------------------------------------ */
+/* motor model (see oracle/rkfd_oracle.c for the RoKi call sites it restates) */
+RKFD_DEV double d_clamp(double x, double lo, double hi){ return x < lo ? lo : ( x > hi ? hi : x ); }
+
+/* ------------------------------------------------------------------------ */
+/* LDS carve-up for one instance */
+typedef struct {
+  double *q, *qd, *acc, *tmp;     /* [ndof] each                                         */
+  double *X;                      /* [NL*12] world frame R(9) p(3)                        */
+  double *S;                      /* [NL*6]  joint axis (ang, lin)                        */
+  double *V;                      /* [NL*6]  spatial velocity                             */
+  double *C;                      /* [NL*6]  velocity-product acceleration                */
+  double *IA;                     /* [NL*36] spatial / articulated inertia                */
+  double *PB;                     /* [NL*6]  own bias force                               */
+  double *FE;                     /* [NL*6]  external wrench                              */
+  double *PA;                     /* [NL*6]  bias force handed to the parent              */
+  double *U;                      /* [NL*6]                                               */
+  double *AC;                     /* [NL*6]  spatial acceleration                         */
+  double *MS;                     /* [NL*4]  Dinv, u, tau, jm                             */
+  double *CX, *AX, *RW, *PRO, *REF, *CF; /* per candidate: 3, 9, 3, 3, 3, 3               */
+  double *MA, *MB, *MF, *PU;      /* MLCP: [M*(M+1)], [M], [M], [2*nlevel*M]              */
+  int *act, *typ, *lrg, *lel, *tgt, *cnt, *dofkind, *pivt;
+  double *pivp, *min;             /* [NL] pivot prev torque, motor input                  */
+} rkfdLds;
+
+RKFD_DEV size_t rkfd_lds_doubles(int NL, int ND, int NC, int M, int nlevel)
+{
+  return (size_t)4*ND + (size_t)NL*( 12+6+6+6+36+6+6+6+6+6+4 ) + (size_t)NC*( 3+9+3+3+3+3 )
+       + (size_t)M*(M+1) + 2*(size_t)M + 2*(size_t)nlevel*M + 2*(size_t)NL;
+}
+RKFD_DEV size_t rkfd_lds_ints(int NL, int ND, int NC)
+{
+  return (size_t)5*NC + 8 + (size_t)ND + (size_t)NL;
+}
+
+RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int M, int nlevel)
+{
+  double *d = (double *)base;
+  L->q = d; d += ND; L->qd = d; d += ND; L->acc = d; d += ND; L->tmp = d; d += ND;
+  L->X = d; d += NL*12; L->S = d; d += NL*6; L->V = d; d += NL*6; L->C = d; d += NL*6;
+  L->IA = d; d += NL*36; L->PB = d; d += NL*6; L->FE = d; d += NL*6; L->PA = d; d += NL*6;
+  L->U = d; d += NL*6; L->AC = d; d += NL*6; L->MS = d; d += NL*4;
+  L->CX = d; d += NC*3; L->AX = d; d += NC*9; L->RW = d; d += NC*3; L->PRO = d; d += NC*3;
+  L->REF = d; d += NC*3; L->CF = d; d += NC*3;
+  L->MA = d; d += M*(M+1); L->MB = d; d += M; L->MF = d; d += M; L->PU = d; d += 2*nlevel*M;
+  L->pivp = d; d += NL; L->min = d; d += NL;
+  int *ip = (int *)d;
+  L->act = ip; ip += NC; L->typ = ip; ip += NC; L->lrg = ip; ip += NC; L->lel = ip; ip += NC;
+  L->tgt = ip; ip += NC; L->cnt = ip; ip += 8; L->dofkind = ip; ip += ND; L->pivt = ip; ip += NL;
+}
+
+/* counters in L->cnt */
+#define CNT_NRG 0
+#define CNT_NEL 1
+#define CNT_NTGT 2
+#define CNT_OVF 3
+
+/* ------------------------------------------------------------------------ */
+/* phase: forward kinematics, link velocities, per-link spatial inertia and bias terms.
+ * Mirrors _rkFDConnectJointState (reference src/rkfd_sim.c:290-302) + the per-link set-up
+ * of RoKi's ABA.  lane = link. */
+RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, const rkfdLds &L)
+{
+  const int lane = LANE();
+  const int NL = m.nlink;
+  const bool on = lane < NL;
+  const int i = on ? lane : 0;
+  const int jt = on ? m.jtype[i] : RKFD_JOINT_FIXED;
+  const int off = m.dofoff[i];
+  double R[9], p[3], Rj[9], vJ[6], qd1 = 0, qdf[6] = {0,0,0,0,0,0};
+
+  /* local (adjacent) transform = org frame * joint transform */
+  {
+    const double *Ro = &m.org[12*i];
+    double o[12];
+#pragma unroll
+    for( int k=0; k<12; k++ ) o[k] = Ro[k];
+    Rj[0]=1; Rj[1]=0; Rj[2]=0; Rj[3]=0; Rj[4]=1; Rj[5]=0; Rj[6]=0; Rj[7]=0; Rj[8]=1;
+#pragma unroll
+    for( int k=0; k<9; k++ ) R[k] = o[k];
+    p[0]=o[9]; p[1]=o[10]; p[2]=o[11];
+    if( jt == RKFD_JOINT_REVOL ){
+      double q = L.q[off], s = sin(q), c = cos(q);
+      double Rz[9] = { c,-s,0, s,c,0, 0,0,1 };
+      d_mul33( o, Rz, R );
+      qd1 = L.qd[off];
+    } else if( jt == RKFD_JOINT_PRISM ){
+      double q = L.q[off];
+      p[0] += q*o[2]; p[1] += q*o[5]; p[2] += q*o[8];
+      qd1 = L.qd[off];
+    } else if( jt == RKFD_JOINT_FLOAT ){
+      double qq[6], t[3];
+#pragma unroll
+      for( int k=0; k<6; k++ ){ qq[k] = L.q[off+k]; qdf[k] = L.qd[off+k]; }
+      d_from_aa( qq+3, Rj );
+      d_mul33( o, Rj, R );
+      d_mulv( o, qq, t );
+      p[0] += t[0]; p[1] += t[1]; p[2] += t[2];
+    }
+  }
+  if( on ){
+#pragma unroll
+    for( int k=0; k<9; k++ ) L.X[12*i+k] = R[k];
+    L.X[12*i+9] = p[0]; L.X[12*i+10] = p[1]; L.X[12*i+11] = p[2];
+  }
+  SYNC();
+  /* pointer jumping: compose with the ancestor 2^r levels up */
+  for( int r=0; r<m.nround; r++ ){
+    const int a = on ? m.anc[r*NL+i] : -1;
+    if( a >= 0 ){
+      double Ra[9], pa[3], t[3];
+#pragma unroll
+      for( int k=0; k<9; k++ ) Ra[k] = L.X[12*a+k];
+      pa[0] = L.X[12*a+9]; pa[1] = L.X[12*a+10]; pa[2] = L.X[12*a+11];
+      d_mulv( Ra, p, t );
+      p[0] = pa[0]+t[0]; p[1] = pa[1]+t[1]; p[2] = pa[2]+t[2];
+      d_mul33( Ra, R, R );
+    }
+    SYNC();
+    if( a >= 0 ){
+#pragma unroll
+      for( int k=0; k<9; k++ ) L.X[12*i+k] = R[k];
+      L.X[12*i+9] = p[0]; L.X[12*i+10] = p[1]; L.X[12*i+11] = p[2];
+    }
+    SYNC();
+  }
+  /* joint motion axis and joint velocity in world coordinates */
+  {
+    double z[3] = { R[2], R[5], R[8] }, S[6] = {0,0,0,0,0,0};
+#pragma unroll
+    for( int k=0; k<6; k++ ) vJ[k] = 0;
+    if( jt == RKFD_JOINT_REVOL ){
+      S[0]=z[0]; S[1]=z[1]; S[2]=z[2]; d_cross( p, z, S+3 );
+#pragma unroll
+      for( int k=0; k<6; k++ ) vJ[k] = S[k]*qd1;
+    } else if( jt == RKFD_JOINT_PRISM ){
+      S[3]=z[0]; S[4]=z[1]; S[5]=z[2];
+#pragma unroll
+      for( int k=0; k<6; k++ ) vJ[k] = S[k]*qd1;
+    } else if( jt == RKFD_JOINT_FLOAT ){
+      /* world orientation of the joint-origin frame: Row = R Rj' */
+      double Row[9], RjT[9] = { Rj[0],Rj[3],Rj[6], Rj[1],Rj[4],Rj[7], Rj[2],Rj[5],Rj[8] };
+      double vw[3], ww[3], t[3];
+      d_mul33( R, RjT, Row );
+      d_mulv( Row, qdf, vw ); d_mulv( Row, qdf+3, ww );
+      d_cross( p, ww, t );
+      vJ[0]=ww[0]; vJ[1]=ww[1]; vJ[2]=ww[2];
+      vJ[3]=vw[0]+t[0]; vJ[4]=vw[1]+t[1]; vJ[5]=vw[2]+t[2];
+      /* for float joints S holds the world velocity of the joint-origin-frame rate (lin part),
+       * needed later for the velocity-product term */
+      S[0]=vw[0]; S[1]=vw[1]; S[2]=vw[2]; S[3]=ww[0]; S[4]=ww[1]; S[5]=ww[2];
+    }
+    if( on ){
+#pragma unroll
+      for( int k=0; k<6; k++ ){ L.S[6*i+k] = S[k]; L.V[6*i+k] = vJ[k]; }
+    }
+  }
+  SYNC();
+  /* velocities: prefix sum of joint velocities along the path to the root */
+  {
+    double v[6];
+#pragma unroll
+    for( int k=0; k<6; k++ ) v[k] = vJ[k];
+    for( int r=0; r<m.nround; r++ ){
+      const int a = on ? m.anc[r*NL+i] : -1;
+      if( a >= 0 ){
+#pragma unroll
+        for( int k=0; k<6; k++ ) v[k] += L.V[6*a+k];
+      }
+      SYNC();
+      if( a >= 0 ){
+#pragma unroll
+        for( int k=0; k<6; k++ ) L.V[6*i+k] = v[k];
+      }
+      SYNC();
+    }
+    /* velocity-product acceleration c = v x vJ (+ float-joint term) */
+    double c[6];
+    d_crm( v, vJ, c );
+    if( jt == RKFD_JOINT_FLOAT ){
+      double vw[3] = { L.S[6*i], L.S[6*i+1], L.S[6*i+2] }, ww[3] = { vJ[0], vJ[1], vJ[2] }, t[3];
+      d_cross( vw, ww, t );
+      c[3] += t[0]; c[4] += t[1]; c[5] += t[2];
+    }
+    /* spatial inertia about the world origin and bias force */
+    const double ms = m.mass[i];
+    double cw[3], Iw[9], t9[9], Ic[9], RT[9] = { R[0],R[3],R[6], R[1],R[4],R[7], R[2],R[5],R[8] };
+    {
+      const double *cm = &m.com[3*i], *I0 = &m.inertia[9*i];
+      double cl[3] = { cm[0], cm[1], cm[2] };
+#pragma unroll
+      for( int k=0; k<9; k++ ) Ic[k] = I0[k];
+      d_mulv( R, cl, cw );
+      cw[0] += p[0]; cw[1] += p[1]; cw[2] += p[2];
+      d_mul33( R, Ic, t9 ); d_mul33( t9, RT, Iw );
+    }
+    /* I = [ Iw + m( |r|^2 1 - r r' )   m [r]x ;  m [r]x'   m 1 ] */
+    double I6[36];
+    {
+      const double r2 = d_dot( cw, cw );
+#pragma unroll
+      for( int a=0; a<3; a++ )
+#pragma unroll
+        for( int b=0; b<3; b++ ){
+          I6[6*a+b] = Iw[3*a+b] + ms*( ( a==b ? r2 : 0.0 ) - cw[a]*cw[b] );
+          I6[6*(3+a)+3+b] = ( a==b ? ms : 0.0 );
+        }
+      const double rx[9] = { 0,-cw[2],cw[1], cw[2],0,-cw[0], -cw[1],cw[0],0 };
+#pragma unroll
+      for( int a=0; a<3; a++ )
+#pragma unroll
+        for( int b=0; b<3; b++ ){
+          I6[6*a+3+b] = ms*rx[3*a+b];
+          I6[6*(3+a)+b] = ms*rx[3*b+a];
+        }
+    }
+    double h[6], pb[6];
+#pragma unroll
+    for( int a=0; a<6; a++ ){
+      double s = 0;
+#pragma unroll
+      for( int b=0; b<6; b++ ) s += I6[6*a+b]*v[b];
+      h[a] = s;
+    }
+    d_crf( v, h, pb );
+    /* gravity as an explicit force at the centre of mass: f = (r x mg, mg) */
+    {
+      double g[3] = { 0, 0, -RKFD_G*ms }, ng[3];
+      d_cross( cw, g, ng );
+      pb[0] -= ng[0]; pb[1] -= ng[1]; pb[2] -= ng[2]; pb[5] -= g[2];
+    }
+    if( on ){
+#pragma unroll
+      for( int k=0; k<36; k++ ) L.IA[36*i+k] = I6[k];
+#pragma unroll
+      for( int k=0; k<6; k++ ){ L.C[6*i+k] = c[k]; L.PB[6*i+k] = pb[k]; L.FE[6*i+k] = 0; }
+    }
+    /* joint friction and joint torque:
+     * rkFDJointFriction / rkFDJointFrictionRevolDC (reference src/rkfd_util.c:318-387) */
+    if( on ){
+      double tau = 0, jm = 0;
+      if( jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM ){
+        const int mt = m.mtype[i];
+        double tin = 0, treg = 0, tf = 0;
+        const double in = L.min[i];
+        if( mt == RKFD_MOTOR_DC ){
+          const double gk = m.mot_gear[i]*m.mot_k[i];
+          jm = m.mot_inertia[i]*m.mot_gear[i]*m.mot_gear[i];
+          tin = m.mot_admit[i]*gk*d_clamp( in, m.mot_vmin[i], m.mot_vmax[i] );
+          treg = m.mot_admit[i]*gk*gk*qd1;
+          tf = jm*( -qd1/m.dt ) - tin + treg + L.pivp[i];
+          double fmax;
+          if( L.pivt[i] == RKFD_SF ) fmax = m.sfric[i];
+          else {
+            const double q = L.q[off];
+            const double sg = qd1 > 0 ? 1.0 : ( qd1 < 0 ? -1.0 : 0.0 );
+            fmax = -m.stiff[i]*q - m.visc[i]*qd1 - m.coulomb[i]*sg;
+          }
+          fmax = fabs( fmax );
+          int newt;
+          if( fabs( tf ) > fmax ){ tf = tf > 0 ? fmax : -fmax; newt = RKFD_KF; }
+          else newt = RKFD_SF;
+          /* the pivot type is committed by the caller when doUpRef (stored in MS slot 1 as a flag) */
+          L.MS[4*i+1] = (double)newt;
+        } else if( mt == RKFD_MOTOR_TRQ ){
+          tin = d_clamp( in, m.mot_vmin[i], m.mot_vmax[i] );
+        }
+        tau = tin - treg + tf;
+        /* driving torque without the inertia term + friction, for rkFDUpdateJointPrevDrivingTrq */
+        L.MS[4*i+0] = tin - treg + tf;
+      }
+      L.MS[4*i+2] = tau;
+      L.MS[4*i+3] = jm;
+    }
+  }
+  SYNC();
+}
+
+/* ------------------------------------------------------------------------ */
+/* in-place Cholesky of the 6x6 at A (row-major, lower part used), one lane */
+RKFD_DEV void d_chol6_inplace(double *A)
+{
+  for( int j=0; j<6; j++ ){
+    double s = A[6*j+j];
+    for( int k=0; k<j; k++ ) s -= A[6*j+k]*A[6*j+k];
+    s = sqrt( s );
+    A[6*j+j] = s;
+    for( int i=j+1; i<6; i++ ){
+      double t = A[6*i+j];
+      for( int k=0; k<j; k++ ) t -= A[6*i+k]*A[6*j+k];
+      A[6*i+j] = t / s;
+    }
+  }
+}
+RKFD_DEV void d_chol6_solve(const double *Lm, const double *b, double *x)
+{
+  double y[6];
+#pragma unroll
+  for( int i=0; i<6; i++ ){
+    double s = b[i];
+#pragma unroll
+    for( int k=0; k<6; k++ ) if( k < i ) s -= Lm[6*i+k]*y[k];
+    y[i] = s / Lm[6*i+i];
+  }
+#pragma unroll
+  for( int i=5; i>=0; i-- ){
+    double s = y[i];
+#pragma unroll
+    for( int k=0; k<6; k++ ) if( k > i ) s -= Lm[6*k+i]*x[k];
+    x[i] = s / Lm[6*i+i];
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* ABA sweep 2 (leaf to root), level-synchronous; 8 lanes per link, lane r = row r.
+ * full = true : articulated inertia + bias (rkChainUpdateABI, backward part)
+ * full = false: bias only, reusing Ia, U, Dinv (rkChainUpdateCachedABI, backward part).
+ * Collectives (G8SUM, SYNC) are issued from wave-uniform control flow only. */
+RKFD_DEV void rkfd_phase_sweep2(const rkfdDevModel &m, const rkfdLds &L, bool full)
+{
+  const int lane = LANE();
+  const int g = lane >> 3, r = lane & 7;
+  for( int lv=m.nlevel-1; lv>=0; lv-- ){
+    const int lo = m.level_off[lv], hi = m.level_off[lv+1];
+    for( int base=lo; base<hi; base+=8 ){
+      const bool onl = base+g < hi;
+      const bool on = onl && r < 6;
+      const int i = onl ? m.level_link[base+g] : 0;
+      const int jt = onl ? m.jtype[i] : RKFD_JOINT_FIXED;
+      const bool is1 = jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM;
+      const bool isf = jt == RKFD_JOINT_FLOAT;
+      const int rr = r < 6 ? r : 0;
+      double row[6], c[6], S[6], U_r = 0, Dinv = 0;
+      /* gather own + children */
+      double pr = L.PB[6*i+rr] - L.FE[6*i+rr];
+#pragma unroll
+      for( int k=0; k<6; k++ ){ row[k] = L.IA[36*i+6*rr+k]; S[k] = L.S[6*i+k]; c[k] = L.C[6*i+k]; }
+      {
+        const int c0 = m.child_off[i], c1 = onl ? m.child_off[i+1] : c0;
+        for( int cc=c0; cc<c1; cc++ ){
+          const int ch = m.child_idx[cc];
+          pr += L.PA[6*ch+rr];
+          if( full && m.jtype[ch] != RKFD_JOINT_FLOAT ){
+#pragma unroll
+            for( int k=0; k<6; k++ ) row[k] += L.IA[36*ch+6*rr+k];
+          }
+        }
+      }
+      const double S_r = S[rr];
+      if( full ){
+#pragma unroll
+        for( int k=0; k<6; k++ ) U_r += row[k]*S[k];
+        const double D = G8SUM( ( on && is1 ) ? S_r*U_r : 0.0 ) + L.MS[4*i+3];
+        Dinv = 1.0/D;
+      } else {
+        U_r = L.U[6*i+rr];
+        Dinv = L.MS[4*i+0];
+      }
+      const double u = L.MS[4*i+2] - G8SUM( ( on && is1 ) ? S_r*pr : 0.0 );
+      /* exchange U through LDS: every row needs every U[c] */
+      SYNC();
+      if( full && on && is1 ) L.U[6*i+rr] = U_r;
+      SYNC();
+      double pa = pr;
+      if( is1 ){
+        if( full ){
+          const double t = U_r*Dinv;
+#pragma unroll
+          for( int k=0; k<6; k++ ) row[k] -= t*L.U[6*i+k];
+        }
+        double s = 0;
+#pragma unroll
+        for( int k=0; k<6; k++ ) s += row[k]*c[k];
+        pa = pr + s + U_r*( u*Dinv );
+      } else if( isf ){
+        pa = 0;
+      }
+      /* write back: Ia row (float joints keep IA for the factorisation), pa, scalars */
+      if( on ){
+        if( full ){
+#pragma unroll
+          for( int k=0; k<6; k++ ) L.IA[36*i+6*rr+k] = row[k];
+        }
+        L.PA[6*i+rr] = pa;
+        if( isf ) L.U[6*i+rr] = pr;   /* float: the U slot keeps the bias pA */
+        if( rr == 0 && is1 ){
+          if( full ) L.MS[4*i+0] = Dinv;
+          L.MS[4*i+1] = u;
+        }
+      }
+      SYNC();
+      if( full && isf && onl && r == 0 ) d_chol6_inplace( &L.IA[36*i] );
+    }
+    SYNC();
+  }
+}
+
+/* ABA sweep 3 (root to leaf): accelerations and joint accelerations */
+RKFD_DEV void rkfd_phase_sweep3(const rkfdDevModel &m, const rkfdLds &L)
+{
+  const int lane = LANE();
+  const int g = lane >> 3, r = lane & 7;
+  for( int lv=0; lv<m.nlevel; lv++ ){
+    const int lo = m.level_off[lv], hi = m.level_off[lv+1];
+    for( int base=lo; base<hi; base+=8 ){
+      const bool onl = base+g < hi;
+      const bool on = onl && r < 6;
+      const int i = onl ? m.level_link[base+g] : 0;
+      const int jt = onl ? m.jtype[i] : RKFD_JOINT_FIXED;
+      const bool is1 = jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM;
+      const int par = m.parent[i];
+      const int rr = r < 6 ? r : 0;
+      const int off = m.dofoff[i];
+      const double ap = ( par >= 0 ) ? L.AC[6*par+rr] : 0.0;
+      const double y = ap + L.C[6*i+rr];
+      const double uy = G8SUM( ( on && is1 ) ? L.U[6*i+rr]*y : 0.0 );
+      double a = y;
+      if( is1 ){
+        const double qdd = ( L.MS[4*i+1] - uy )*L.MS[4*i+0];
+        a = y + L.S[6*i+rr]*qdd;
+        if( on && rr == 0 ) L.acc[off] = qdd;
+      } else if( jt == RKFD_JOINT_FLOAT && onl && r == 0 ){
+        /* a = IA^-1 ( -pA ); joint acceleration from a - a_parent - c */
+        double rhs[6], x[6], d[6], R[9], Rj[9], Row[9], p[3], qq[3];
+#pragma unroll
+        for( int k=0; k<6; k++ ) rhs[k] = -L.U[6*i+k];
+        d_chol6_solve( &L.IA[36*i], rhs, x );
+#pragma unroll
+        for( int k=0; k<6; k++ ){
+          L.AC[6*i+k] = x[k];
+          d[k] = x[k] - ( par >= 0 ? L.AC[6*par+k] : 0.0 ) - L.C[6*i+k];
+        }
+#pragma unroll
+        for( int k=0; k<9; k++ ) R[k] = L.X[12*i+k];
+        p[0] = L.X[12*i+9]; p[1] = L.X[12*i+10]; p[2] = L.X[12*i+11];
+        qq[0] = L.q[off+3]; qq[1] = L.q[off+4]; qq[2] = L.q[off+5];
+        d_from_aa( qq, Rj );
+        {
+          double RjT[9] = { Rj[0],Rj[3],Rj[6], Rj[1],Rj[4],Rj[7], Rj[2],Rj[5],Rj[8] };
+          d_mul33( R, RjT, Row );
+        }
+        /* wdot_j = Row' alpha ; vdot_j = Row' ( a_O - p x alpha ) */
+        double t[3], lin[3], o1[3], o2[3];
+        d_cross( p, d, t );
+        lin[0] = d[3]-t[0]; lin[1] = d[4]-t[1]; lin[2] = d[5]-t[2];
+        d_tmulv( Row, lin, o1 ); d_tmulv( Row, d, o2 );
+        L.acc[off] = o1[0]; L.acc[off+1] = o1[1]; L.acc[off+2] = o1[2];
+        L.acc[off+3] = o2[0]; L.acc[off+4] = o2[1]; L.acc[off+5] = o2[2];
+      }
+      if( on && jt != RKFD_JOINT_FLOAT ) L.AC[6*i+rr] = a;
+    }
+    SYNC();
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* point kinematics in world coordinates from spatial quantities at the origin */
+RKFD_DEV void d_point_vel(const double *V, const double *x, double *v)
+{
+  double t[3];
+  d_cross( V, x, t );
+  v[0] = V[3]+t[0]; v[1] = V[4]+t[1]; v[2] = V[5]+t[2];
+}
+RKFD_DEV void d_point_acc(const double *A, const double *V, const double *x, double *a)
+{
+  double v[3], t[3], s[3];
+  d_point_vel( V, x, v );
+  d_cross( A, x, t ); d_cross( V, v, s );
+  a[0] = A[3]+t[0]+s[0]; a[1] = A[4]+t[1]+s[1]; a[2] = A[5]+t[2]+s[2];
+}
+
+/* collision detection for convex shapes, lane = candidate vertex.
+ * rkCDColChkVert [RoKi, restated as in oracle/rkfd_oracle.c collision()] + rkFDCDUpdate
+ * (reference src/rkfd_cd.c:33-49).  Builds the rigid / elastic contact lists in candidate order. */
+RKFD_DEV void rkfd_phase_collision(const rkfdDevModel &m, const rkfdLds &L)
+{
+  const int lane = LANE();
+  const bool on = lane < m.ncand;
+  const int j = on ? lane : 0;
+  int is_act = 0, is_rg = 0, is_el = 0;
+  if( on ){
+    const int la = m.cand_linkA[j], lb = m.cand_linkB[j];
+    double RA[9], pA[3], RB[9], pB[3], vl[3], x[3], y[3], rr[3];
+#pragma unroll
+    for( int k=0; k<9; k++ ){ RA[k] = L.X[12*la+k]; RB[k] = L.X[12*lb+k]; }
+#pragma unroll
+    for( int k=0; k<3; k++ ){ pA[k] = L.X[12*la+9+k]; pB[k] = L.X[12*lb+9+k]; vl[k] = m.cand_vert[3*j+k]; }
+    d_mulv( RA, vl, x );
+    x[0] += pA[0]; x[1] += pA[1]; x[2] += pA[2];
+    rr[0] = x[0]-pB[0]; rr[1] = x[1]-pB[1]; rr[2] = x[2]-pB[2];
+    d_tmulv( RB, rr, y );
+    double smax = -HUGE_VAL; int fbest = -1;
+    const int f0 = m.cand_foff[j], nf = m.cand_nf[j];
+    for( int f=f0; f<f0+nf; f++ ){
+      const double s = m.planes[4*f]*y[0] + m.planes[4*f+1]*y[1] + m.planes[4*f+2]*y[2] - m.planes[4*f+3];
+      if( s > smax ){ smax = s; fbest = f; }
+    }
+    L.CX[3*j] = x[0]; L.CX[3*j+1] = x[1]; L.CX[3*j+2] = x[2];
+    L.CF[3*j] = 0; L.CF[3*j+1] = 0; L.CF[3*j+2] = 0;
+    if( fbest >= 0 && smax < RKFD_DEV_TOL ){
+      double n[3] = { m.planes[4*fbest], m.planes[4*fbest+1], m.planes[4*fbest+2] };
+      double pro[3] = { y[0]-smax*n[0], y[1]-smax*n[1], y[2]-smax*n[2] };
+      double nw[3], t1[3], t2[3], ref[3], rw[3];
+      L.PRO[3*j] = pro[0]; L.PRO[3*j+1] = pro[1]; L.PRO[3*j+2] = pro[2];
+      d_mulv( RB, n, nw );
+      if( !L.act[j] ){
+        L.act[j] = 1; L.typ[j] = RKFD_SF;
+        L.REF[3*j] = pro[0]; L.REF[3*j+1] = pro[1]; L.REF[3*j+2] = pro[2];
+      }
+      ref[0] = L.REF[3*j]; ref[1] = L.REF[3*j+1]; ref[2] = L.REF[3*j+2];
+      d_mulv( RB, ref, rw );
+      L.RW[3*j] = rw[0]+pB[0]; L.RW[3*j+1] = rw[1]+pB[1]; L.RW[3*j+2] = rw[2]+pB[2];
+      d_ortho_space( nw, t1, t2 );
+#pragma unroll
+      for( int k=0; k<3; k++ ){ L.AX[9*j+k] = nw[k]; L.AX[9*j+3+k] = t1[k]; L.AX[9*j+6+k] = t2[k]; }
+      is_act = 1;
+      const int ct = m.ci_type[m.cand_ci[j]];
+      is_rg = ct == RKFD_CONTACT_RIGID; is_el = ct == RKFD_CONTACT_ELASTIC;
+    } else {
+      L.act[j] = 0;
+    }
+  }
+  (void)is_act;
+  /* ordered compaction */
+  const unsigned long long mrg = BALLOT( is_rg ), mel = BALLOT( is_el );
+  const unsigned long long below = lane == 0 ? 0ull : ( ~0ull >> ( 64-lane ) );
+  if( is_rg && __builtin_popcountll( mrg & below ) < m.maxrg ) L.lrg[ __builtin_popcountll( mrg & below ) ] = j;
+  if( is_el ) L.lel[ __builtin_popcountll( mel & below ) ] = j;
+  if( lane == 0 ){
+    int nrg = __builtin_popcountll( mrg );
+    if( nrg > m.maxrg ){ nrg = m.maxrg; L.cnt[CNT_OVF] = 1; }   /* contact capacity exceeded */
+    L.cnt[CNT_NRG] = nrg;
+    L.cnt[CNT_NEL] = __builtin_popcountll( mel );
+  }
+  SYNC();
+}
+
+/* accumulate the contact forces CF of the listed contacts into the links' external
+ * wrenches (rkFDContactForcePushWrench, reference src/rkfd_util.c:268-282): in world
+ * coordinates the wrench on the owner link is (x x f, f), on the other link its negative.
+ * lanes 0..5 own one component each and walk the list in order (deterministic). */
+RKFD_DEV void rkfd_push_wrenches(const rkfdDevModel &m, const rkfdLds &L, const int *list, int n)
+{
+  const int lane = LANE();
+  if( lane < 6 ){
+    for( int e=0; e<n; e++ ){
+      const int j = list[e];
+      const double f[3] = { L.CF[3*j], L.CF[3*j+1], L.CF[3*j+2] };
+      const double x[3] = { L.CX[3*j], L.CX[3*j+1], L.CX[3*j+2] };
+      double w;
+      if( lane < 3 ){
+        double t[3]; d_cross( x, f, t );
+        w = lane == 0 ? t[0] : ( lane == 1 ? t[1] : t[2] );
+      } else {
+        w = lane == 3 ? f[0] : ( lane == 4 ? f[1] : f[2] );
+      }
+      L.FE[6*m.cand_linkA[j]+lane] += w;
+      L.FE[6*m.cand_linkB[j]+lane] -= w;
+    }
+  }
+  SYNC();
+}
+
+/* rkFDContactForceModifyFriction (reference src/rkfd_util.c:239-266), one lane = one contact */
+RKFD_DEV void d_modify_friction(const rkfdDevModel &m, const rkfdLds &L, int j, const double *vr, double *f, bool doUpRef)
+{
+  const int ci = m.cand_ci[j];
+  const double *ax = &L.AX[9*j];
+  const double fn = d_dot( f, ax );
+  const double f1 = d_dot( f, ax+3 ), f2 = d_dot( f, ax+6 );
+  const double fs = sqrt( f1*f1 + f2*f2 );
+  const double mu = L.typ[j] == RKFD_SF ? m.ci_sf[ci] : m.ci_kf[ci];
+  if( !( fabs( fs ) < RKFD_DEV_TOL ) && fs > mu*fn ){
+    const double vn = d_dot( vr, ax );
+    double v[3] = { vr[0]-vn*ax[0], vr[1]-vn*ax[1], vr[2]-vn*ax[2] };
+    const double vs = sqrt( d_dot( v, v ) );
+    f[0] = fn*ax[0]; f[1] = fn*ax[1]; f[2] = fn*ax[2];
+    if( !( fabs( vs ) < RKFD_DEV_TOL ) ){
+      const double k = -( 1.0 - exp( -1.0*m.fric_w*vs ) )*m.ci_kf[ci]*fn/vs;
+      f[0] += k*v[0]; f[1] += k*v[1]; f[2] += k*v[2];
+    }
+    if( doUpRef ){
+      L.typ[j] = RKFD_KF;
+      L.REF[3*j] = L.PRO[3*j]; L.REF[3*j+1] = L.PRO[3*j+1]; L.REF[3*j+2] = L.PRO[3*j+2];
+    }
+  } else {
+    if( doUpRef ) L.typ[j] = RKFD_SF;
+  }
+}
+
+/* rkFDSolverPenalty (reference src/rkfd_penalty.c:11-31), lane = elastic contact */
+RKFD_DEV void rkfd_phase_penalty(const rkfdDevModel &m, const rkfdLds &L, bool doUpRef)
+{
+  const int lane = LANE();
+  const int nel = L.cnt[CNT_NEL];
+  if( lane < nel ){
+    const int j = L.lel[lane], ci = m.cand_ci[j];
+    const double x[3] = { L.CX[3*j], L.CX[3*j+1], L.CX[3*j+2] };
+    double va[3], vb[3], vr[3], f[3];
+    d_point_vel( &L.V[6*m.cand_linkA[j]], x, va );
+    d_point_vel( &L.V[6*m.cand_linkB[j]], x, vb );
+    const double E = m.ci_e[ci], kv = -1.0*( m.ci_v[ci] + E*m.dt );
+#pragma unroll
+    for( int k=0; k<3; k++ ){
+      vr[k] = va[k]-vb[k];
+      f[k] = -E*( x[k]-L.RW[3*j+k] ) + kv*vr[k];
+    }
+    if( d_dot( f, &L.AX[9*j] ) < 0.0 ){
+      f[0] = f[1] = f[2] = 0;
+    } else {
+      d_modify_friction( m, L, j, vr, f, doUpRef );
+    }
+    L.CF[3*j] = f[0]; L.CF[3*j+1] = f[1]; L.CF[3*j+2] = f[2];
+  }
+  SYNC();
+  rkfd_push_wrenches( m, L, L.lel, nel );
+}
+
+/* ------------------------------------------------------------------------ */
+/* MLCP rigid branch (reference src/rkfd_mlcp.c:287-297).  Preconditions: sweep 2 (full) and
+ * sweep 3 have been run with the wrenches applied so far (rkFDUpdateAccBias), so AC holds
+ * the free accelerations and IA/U/MS hold Ia, U, Dinv.  Adds the contact wrenches to FE. */
+RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L)
+{
+  const int lane = LANE();
+  const int nc = L.cnt[CNT_NRG];
+  const int M = 3*nc;
+  const int ld = M+1;
+  const int NLV = m.nlevel;
+  const double dt = m.dt;
+
+  /* distinct non-static links that carry a rigid contact (targets of the response walk) */
+  if( lane == 0 ){
+    int nt = 0;
+    for( int c=0; c<nc; c++ ){
+      const int j = L.lrg[c];
+      for( int s=0; s<2; s++ ){
+        const int l = s == 0 ? m.cand_linkA[j] : m.cand_linkB[j];
+        if( m.is_static[l] ) continue;
+        int k; for( k=0; k<nt; k++ ) if( L.tgt[k] == l ) break;
+        if( k == nt ) L.tgt[nt++] = l;
+      }
+    }
+    L.cnt[CNT_NTGT] = nt;
+  }
+  /* b: free relative acceleration, then *dt + relative velocity + compensation
+   * (_rkFDSolverBiasAcc / BiasVel / RelaxationCompensation, reference src/rkfd_mlcp.c:58-74,146-188) */
+  if( lane < nc ){
+    const int j = L.lrg[lane], ci = m.cand_ci[j];
+    const int la = m.cand_linkA[j], lb = m.cand_linkB[j];
+    const double x[3] = { L.CX[3*j], L.CX[3*j+1], L.CX[3*j+2] };
+    double aa[3], ab[3], va[3], vb[3], ra[3], rv[3], d[3];
+    d_point_acc( &L.AC[6*la], &L.V[6*la], x, aa );
+    d_point_acc( &L.AC[6*lb], &L.V[6*lb], x, ab );
+    d_point_vel( &L.V[6*la], x, va );
+    d_point_vel( &L.V[6*lb], x, vb );
+#pragma unroll
+    for( int k=0; k<3; k++ ){ ra[k] = aa[k]-ab[k]; rv[k] = va[k]-vb[k]; d[k] = x[k]-L.RW[3*j+k]; }
+    const double mu = L.typ[j] == RKFD_SF ? m.ci_sf[ci] : m.ci_kf[ci];
+    const double K = m.ci_k[ci];
+#pragma unroll
+    for( int i=0; i<3; i++ ){
+      const double *ax = &L.AX[9*j+3*i];
+      double b = d_dot( ax, ra )*dt + d_dot( rv, ax );
+      b += ( i == 0 ? K : K*mu )*d_dot( d, ax );
+      L.MB[3*lane+i] = b;
+    }
+  }
+  SYNC();
+  /* probes: lane = column k = 3c+i; unit force along axis i at contact c, applied to the
+   * owner link (+) and the other link (-).  Linear response only (delta form of
+   * rkFDChainUpdateCachedABIPair + _rkFDSolverRelativeAcc, reference src/rkfd_mlcp.c:76-122). */
+  {
+    const bool on = lane < M;
+    const int c = on ? lane/3 : 0, ia = on ? lane%3 : 0;
+    const int j = nc > 0 ? L.lrg[c] : 0;
+    const int lk[2] = { m.cand_linkA[j], m.cand_linkB[j] };
+    double W[6], droot[2][6];
+    int rootl[2] = { -1, -1 };
+    {
+      const double x[3] = { L.CX[3*j], L.CX[3*j+1], L.CX[3*j+2] };
+      const double *ax = &L.AX[9*j+3*ia];
+      d_cross( x, ax, W );
+      W[3] = ax[0]; W[4] = ax[1]; W[5] = ax[2];
+    }
+    if( on ){
+      for( int s=0; s<2; s++ ){
+        int i = lk[s];
+#pragma unroll
+        for( int k=0; k<6; k++ ) droot[s][k] = 0;
+        if( m.is_static[i] ) continue;
+        /* bias force delta: p = -f_ext */
+        double dp[6];
+        const double sg = s == 0 ? -1.0 : 1.0;
+#pragma unroll
+        for( int k=0; k<6; k++ ) dp[k] = sg*W[k];
+        for(;;){
+          const int jt = m.jtype[i], par = m.parent[i];
+          if( jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM ){
+            double du = 0;
+#pragma unroll
+            for( int k=0; k<6; k++ ) du -= L.S[6*i+k]*dp[k];
+            L.PU[( s*NLV + m.depth[i] )*M + lane] = du;
+            const double t = du*L.MS[4*i+0];
+#pragma unroll
+            for( int k=0; k<6; k++ ) dp[k] += L.U[6*i+k]*t;
+          } else if( jt == RKFD_JOINT_FLOAT ){
+            /* delta a = IA^-1 ( -dp ) */
+            double rhs[6];
+#pragma unroll
+            for( int k=0; k<6; k++ ) rhs[k] = -dp[k];
+            d_chol6_solve( &L.IA[36*i], rhs, droot[s] );
+            rootl[s] = i;
+            break;
+          }
+          if( par < 0 ){ rootl[s] = i; break; }  /* fixed / 1-DoF root: world does not move */
+          i = par;
+        }
+      }
+    }
+    SYNC();
+    /* response at every target link, then the column entries */
+    const int nt = L.cnt[CNT_NTGT];
+    if( on ){
+      for( int r=0; r<M; r++ ) L.MA[r*ld+lane] = 0.0;
+      for( int t=0; t<nt; t++ ){
+        const int T = L.tgt[t];
+        const int dT = m.depth[T];
+        const int rt = m.pathlink[T*NLV];
+        double da[6] = {0,0,0,0,0,0};
+        int side = -1;
+        if( rootl[0] >= 0 && m.pathlink[lk[0]*NLV] == rt ) side = 0;
+        else if( rootl[1] >= 0 && m.pathlink[lk[1]*NLV] == rt ) side = 1;
+        if( side < 0 ) continue;
+        const int src = lk[side], dsrc = m.depth[src];
+        for( int d=0; d<=dT; d++ ){
+          const int i = m.pathlink[T*NLV+d];
+          const int jt = m.jtype[i];
+          if( jt == RKFD_JOINT_FLOAT ){
+#pragma unroll
+            for( int k=0; k<6; k++ ) da[k] = droot[side][k];
+          } else if( jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM ){
+            const bool onpath = d <= dsrc && m.pathlink[src*NLV+d] == i;
+            double du = onpath ? L.PU[( side*NLV + d )*M + lane] : 0.0;
+            double ua = 0;
+#pragma unroll
+            for( int k=0; k<6; k++ ) ua += L.U[6*i+k]*da[k];
+            const double qdd = ( du - ua )*L.MS[4*i+0];
+#pragma unroll
+            for( int k=0; k<6; k++ ) da[k] += L.S[6*i+k]*qdd;
+          }
+        }
+        /* entries for the contacts that touch T */
+        for( int r=0; r<nc; r++ ){
+          const int jr = L.lrg[r];
+          double sgn = 0;
+          if( m.cand_linkA[jr] == T ) sgn = 1.0;
+          else if( m.cand_linkB[jr] == T ) sgn = -1.0;
+          if( sgn == 0 ) continue;
+          const double x[3] = { L.CX[3*jr], L.CX[3*jr+1], L.CX[3*jr+2] };
+          double t3[3], acc[3];
+          d_cross( da, x, t3 );
+          acc[0] = da[3]+t3[0]; acc[1] = da[4]+t3[1]; acc[2] = da[5]+t3[2];
+#pragma unroll
+          for( int i2=0; i2<3; i2++ )
+            L.MA[(3*r+i2)*ld+lane] += sgn*d_dot( &L.AX[9*jr+3*i2], acc );
+        }
+      }
+      /* relaxation on the diagonal */
+      L.MA[lane*ld+lane] += m.ci_l[m.cand_ci[j]];
+    }
+    SYNC();
+  }
+  /* projected Gauss-Seidel, fixed max_iter sweeps, no warm start (_rkFDSolverMLCP, reference
+   * src/rkfd_mlcp.c:190-249).  lane = row; the residual res = b + A f is kept up to date. */
+  {
+    const bool on = lane < M;
+    const int row = on ? lane : 0;
+    double res = on ? L.MB[row] : 0.0, f = 0.0;
+    const double diag = on ? L.MA[row*ld+row] : 1.0;
+    for( int it=0; it<m.max_iter; it++ ){
+      for( int c=0; c<nc; c++ ){
+        const int k = 3*c;
+        const double rk = BCAST( res, k ), fk = BCAST( f, k ), akk = BCAST( diag, k );
+        double ff = -( rk - akk*fk )/akk;
+        if( ff < RKFD_DEV_TOL ) ff = 0.0;
+        const double dl = ff - fk;
+        if( lane == k ) f = ff;
+        if( on ) res += L.MA[row*ld+k]*dl;
+      }
+      for( int c=0; c<nc; c++ ){
+        const int k1 = 3*c+1, k2 = 3*c+2;
+        const int j = L.lrg[c], ci = m.cand_ci[j];
+        const double r1 = BCAST( res, k1 ), f1 = BCAST( f, k1 ), a11 = BCAST( diag, k1 );
+        const double r2 = BCAST( res, k2 ), f2 = BCAST( f, k2 ), a22 = BCAST( diag, k2 );
+        const double fn = BCAST( f, 3*c );
+        const double ff0 = fabs( a11 ) < RKFD_DEV_TOL ? 0.0 : -( r1 - a11*f1 )/a11;
+        const double ff1 = fabs( a22 ) < RKFD_DEV_TOL ? 0.0 : -( r2 - a22*f2 )/a22;
+        const double fnorm = ff0*ff0 + ff1*ff1;
+        const double mu = L.typ[j] == RKFD_SF ? m.ci_sf[ci] : m.ci_kf[ci];
+        double fs = mu*fn; fs = fs*fs;
+        double n1, n2;
+        if( fnorm < RKFD_DEV_TOL || fs < RKFD_DEV_TOL ){ n1 = 0; n2 = 0; }
+        else if( fnorm > fs ){ const double s = fs/fnorm; n1 = ff0*s; n2 = ff1*s; }
+        else { n1 = ff0; n2 = ff1; }
+        const double d1 = n1-f1, d2 = n2-f2;
+        if( lane == k1 ) f = n1;
+        if( lane == k2 ) f = n2;
+        if( on ) res += L.MA[row*ld+k1]*d1 + L.MA[row*ld+k2]*d2;
+      }
+    }
+    if( on ) L.MF[row] = f/dt;
+  }
+  SYNC();
+  /* _rkFDSolverSetForce (reference src/rkfd_mlcp.c:252-284) incl. quirks Q1 / Q2 */
+  if( lane < nc ){
+    const int j = L.lrg[lane], ci = m.cand_ci[j];
+    double fw[3] = {0,0,0};
+#pragma unroll
+    for( int i=0; i<3; i++ ){
+      const double fi = L.MF[3*lane+i];
+      fw[0] += fi*L.AX[9*j+3*i]; fw[1] += fi*L.AX[9*j+3*i+1]; fw[2] += fi*L.AX[9*j+3*i+2];
+    }
+    L.CF[3*j] = fw[0]; L.CF[3*j+1] = fw[1]; L.CF[3*j+2] = fw[2];
+    const double fn = fw[0], fs = sqrt( fw[1]*fw[1] + fw[2]*fw[2] );
+    const double mu = L.typ[j] == RKFD_SF ? m.ci_sf[ci] : m.ci_kf[ci];
+    if( fs > mu*fn - RKFD_DEV_TOL ){
+      L.typ[j] = RKFD_KF;
+      L.REF[3*j] = L.PRO[3*j]; L.REF[3*j+1] = L.PRO[3*j+1]; L.REF[3*j+2] = L.PRO[3*j+2];
+    } else {
+      L.typ[j] = RKFD_SF;
+    }
+  }
+  SYNC();
+  rkfd_push_wrenches( m, L, L.lrg, nc );
+}
+
+/* ------------------------------------------------------------------------ */
+/* one dynamics evaluation: _rkFDUpdate / _rkFDUpdateRef (reference src/rkfd_sim.c:533-549).
+ * Input L.q, L.qd; output L.acc (and contact / pivot state).  Returns nonzero when the model
+ * needs a rigid solver that is not available on the device (wave-uniform). */
+RKFD_DEV int rkfd_evaluate(const rkfdDevModel &m, const rkfdLds &L, bool doUpRef)
+{
+  const int lane = LANE();
+  int err = 0;
+  if( lane < m.ndof ) L.acc[lane] = 0.0;
+  rkfd_phase_kinematics( m, L );
+  /* commit joint friction pivots (the reference does so inside rkFDJointFrictionRevolDC) */
+  if( doUpRef && lane < m.nlink ){
+    const int jt = m.jtype[lane];
+    if( ( jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM ) && m.mtype[lane] == RKFD_MOTOR_DC )
+      L.pivt[lane] = (int)L.MS[4*lane+1];
+  }
+  /* MS slot 0 carries (driving torque + friction) until sweep 2 overwrites it: keep a copy */
+  double drv = 0;
+  if( lane < m.nlink ) drv = L.MS[4*lane+0];
+  SYNC();
+  if( m.ncand > 0 ){
+    rkfd_phase_collision( m, L );
+    if( L.cnt[CNT_NEL] > 0 ) rkfd_phase_penalty( m, L, doUpRef );
+  } else if( lane == 0 ){
+    L.cnt[CNT_NRG] = 0; L.cnt[CNT_NEL] = 0;
+  }
+  SYNC();
+  rkfd_phase_sweep2( m, L, true );
+  rkfd_phase_sweep3( m, L );
+  if( L.cnt[CNT_NRG] > 0 ){
+    if( m.solver == RKFD_SOLVER_MLCP ){
+      rkfd_phase_mlcp( m, L );
+      rkfd_phase_sweep2( m, L, false );
+      rkfd_phase_sweep3( m, L );
+    } else {
+      err = 1;
+    }
+  }
+  /* rkFDUpdateJointPrevDrivingTrq (reference src/rkfd_util.c:289-311), committing evaluation only */
+  if( doUpRef && lane < m.nlink ){
+    const int jt = m.jtype[lane];
+    if( jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM )
+      L.pivp[lane] = drv - L.MS[4*lane+3]*L.acc[m.dofoff[lane]];
+  }
+  SYNC();
+  return err;
+}
+
+/* rkFDODECatDefault (reference src/rkfd_sim.c:306-320): q = q0 (+) k v.  lane = dof.
+ * q0 and v are per-lane registers; the rotational part of float joints is composed by the
+ * lane of the first angular dof (dofkind 1) through LDS. */
+RKFD_DEV void rkfd_cat_dis(const rkfdDevModel &m, const rkfdLds &L, double q0, double k, double v)
+{
+  const int lane = LANE();
+  const bool on = lane < m.ndof;
+  const int kind = on ? L.dofkind[lane] : 0;
+  if( on ){
+    L.q[lane] = q0 + k*v;
+    L.tmp[lane] = v;
+    L.acc[lane] = q0;      /* acc is free at this point: used as scratch for q0 */
+  }
+  SYNC();
+  if( on && kind == 1 ){
+    double aa[3] = { k*L.tmp[lane], k*L.tmp[lane+1], k*L.tmp[lane+2] };
+    double a0[3] = { L.acc[lane], L.acc[lane+1], L.acc[lane+2] };
+    double Rk[9], R0[9], Rn[9], an[3];
+    d_from_aa( aa, Rk ); d_from_aa( a0, R0 );
+    d_mul33( Rk, R0, Rn );
+    d_to_aa( Rn, an );
+    L.q[lane] = an[0]; L.q[lane+1] = an[1]; L.q[lane+2] = an[2];
+  }
+  SYNC();
+}
+
+/* the whole step for one instance: load state, nsteps x rkFDUpdate (or a single evaluation),
+ * store state.  mode 0: rkFDUpdate x nsteps; mode 1: rkFDUpdateInit (committing evaluation);
+ * mode 2: evaluation without commit. */
+RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkfdDevState &st, int b, void *ldsbase,
+                            int mode, int nsteps, int *errflag)
+{
+  const int lane = LANE();
+  const int ND = m.ndof, NL = m.nlink, NC = m.ncand;
+  rkfdLds L;
+  rkfd_lds_carve( &L, ldsbase, NL, ND, NC, 3*m.maxrg, m.nlevel );
+  if( lane == 0 ) L.cnt[CNT_OVF] = 0;
+
+  /* load persistent state */
+  double q = 0, qd = 0;
+  if( lane < ND ){ q = st.dis[(size_t)b*ND+lane]; qd = st.vel[(size_t)b*ND+lane]; L.dofkind[lane] = 0; }
+  if( lane < NL ){
+    L.min[lane]  = st.motor_in[(size_t)b*NL+lane];
+    L.pivt[lane] = st.piv_type[(size_t)b*NL+lane];
+    L.pivp[lane] = st.piv_prev[(size_t)b*NL+lane];
+  }
+  if( lane < NC ){
+    L.act[lane] = st.cv_active[(size_t)b*NC+lane];
+    L.typ[lane] = st.cv_type[(size_t)b*NC+lane];
+#pragma unroll
+    for( int k=0; k<3; k++ ) L.REF[3*lane+k] = st.cv_ref[((size_t)b*NC+lane)*3+k];
+  }
+  SYNC();
+  if( lane < NL && m.jtype[lane] == RKFD_JOINT_FLOAT ){
+    L.dofkind[m.dofoff[lane]+3] = 1;
+    L.dofkind[m.dofoff[lane]+4] = 2;
+    L.dofkind[m.dofoff[lane]+5] = 2;
+  }
+  SYNC();
+  int err = 0;
+  if( mode != 0 ){
+    if( lane < ND ){ L.q[lane] = q; L.qd[lane] = qd; }
+    SYNC();
+    err |= rkfd_evaluate( m, L, mode == 1 );
+  } else {
+    const double h = m.dt;
+    const double s2 = sqrt( 2.0 );
+    const double c21 = ( s2-1.0 )/2.0, c22 = ( 2.0-s2 )/2.0, c31 = -s2/2.0, c32 = 1.0+s2/2.0;
+    const double w2 = 2.0-s2, w3 = 2.0+s2;
+    const bool on = lane < ND;
+    for( int step=0; step<nsteps; step++ ){
+      double kv1, kv2, kv3, kv4, ka1, ka2, ka3, ka4, xv;
+      /* stage 1 */
+      if( on ){ L.q[lane] = q; L.qd[lane] = qd; }
+      SYNC();
+      kv1 = qd;
+      err |= rkfd_evaluate( m, L, false );
+      ka1 = on ? L.acc[lane] : 0.0;
+      SYNC();
+      /* stage 2 */
+      xv = qd + 0.5*h*ka1;
+      rkfd_cat_dis( m, L, q, 0.5*h, kv1 );
+      if( on ) L.qd[lane] = xv;
+      SYNC();
+      kv2 = xv;
+      err |= rkfd_evaluate( m, L, false );
+      ka2 = on ? L.acc[lane] : 0.0;
+      SYNC();
+      /* stage 3 */
+      xv = qd + h*( c21*ka1 + c22*ka2 );
+      rkfd_cat_dis( m, L, q, h, c21*kv1 + c22*kv2 );
+      if( on ) L.qd[lane] = xv;
+      SYNC();
+      kv3 = xv;
+      err |= rkfd_evaluate( m, L, false );
+      ka3 = on ? L.acc[lane] : 0.0;
+      SYNC();
+      /* stage 4 */
+      xv = qd + h*( c31*ka2 + c32*ka3 );
+      rkfd_cat_dis( m, L, q, h, c31*kv2 + c32*kv3 );
+      if( on ) L.qd[lane] = xv;
+      SYNC();
+      kv4 = xv;
+      err |= rkfd_evaluate( m, L, false );
+      ka4 = on ? L.acc[lane] : 0.0;
+      SYNC();
+      /* combine */
+      rkfd_cat_dis( m, L, q, h/6.0, kv1 + w2*kv2 + w3*kv3 + kv4 );
+      q = on ? L.q[lane] : 0.0;
+      qd += h/6.0*( ka1 + w2*ka2 + w3*ka3 + ka4 );
+      if( on ) L.qd[lane] = qd;
+      SYNC();
+      /* committing evaluation at the new state (_rkFDUpdateRef) */
+      err |= rkfd_evaluate( m, L, true );
+    }
+  }
+  /* store */
+  if( lane < ND ){
+    st.dis[(size_t)b*ND+lane] = q; st.vel[(size_t)b*ND+lane] = qd;
+    st.acc[(size_t)b*ND+lane] = L.acc[lane];
+  }
+  if( lane < NL ){
+    st.piv_type[(size_t)b*NL+lane] = L.pivt[lane];
+    st.piv_prev[(size_t)b*NL+lane] = L.pivp[lane];
+  }
+  if( lane < NC ){
+    st.cv_active[(size_t)b*NC+lane] = L.act[lane];
+    st.cv_type[(size_t)b*NC+lane] = L.typ[lane];
+#pragma unroll
+    for( int k=0; k<3; k++ ){
+      st.cv_ref[((size_t)b*NC+lane)*3+k] = L.REF[3*lane+k];
+      st.cv_f[((size_t)b*NC+lane)*3+k] = L.CF[3*lane+k];
+    }
+  }
+  if( st.dbg ){
+    /* debug dump: world frames (12/link) then spatial accelerations (6/link) */
+    if( lane < NL ){
+      double *o = st.dbg + (size_t)b*st.dbg_stride;
+      for( int k=0; k<12; k++ ) o[12*lane+k] = L.X[12*lane+k];
+      for( int k=0; k<6; k++ ) o[12*NL+6*lane+k] = L.AC[6*lane+k];
+    }
+  }
+  if( lane == 0 && errflag ){
+    if( err ) *errflag = 1;              /* rigid contact with a solver that has no device path */
+    if( L.cnt[CNT_OVF] ) *errflag = 2;   /* more rigid contacts than the configured capacity   */
+  }
+}
+
+#endif /* RKFD_DEVICE_H */

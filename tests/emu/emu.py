@@ -1,0 +1,85 @@
+"""ctypes wrapper of the lane emulator (tests/emu/rkfd_emu.cpp): runs the DEVICE code of
+roki-fd_amd/csrc/rkfd_device.h on host threads.  Development / test harness only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+LIB_PATH = os.path.join(HERE, "librkfd_emu.so")
+_lib = None
+
+
+class DevState(C.Structure):
+    _fields_ = [("dis", C.c_void_p), ("vel", C.c_void_p), ("acc", C.c_void_p), ("motor_in", C.c_void_p),
+                ("piv_type", C.c_void_p), ("piv_prev", C.c_void_p), ("cv_active", C.c_void_p), ("cv_type", C.c_void_p),
+                ("cv_ref", C.c_void_p), ("cv_f", C.c_void_p), ("dbg", C.c_void_p), ("dbg_stride", C.c_int), ("batch", C.c_int)]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            subprocess.run(["make", "-C", ROOT, "emu"], check=True, stdout=subprocess.DEVNULL)
+        L = C.CDLL(LIB_PATH)
+        L.rkfd_emu_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(DevState), C.c_int, C.c_int]
+        _lib = L
+    return _lib
+
+
+class EmuBatch:
+    """Same surface as roki_fd_amd.Batch, backed by the emulator."""
+
+    def __init__(self, world, batch, max_rigid=8):
+        self.world = world
+        m = world.model.contents
+        self.B, self.ndof, self.nlink, self.ncand = batch, m.ndof, m.nlink, m.ncand
+        self.max_rigid = max_rigid
+        B = batch
+        self.dis = np.zeros((B, self.ndof)); self.vel = np.zeros((B, self.ndof)); self.acc = np.zeros((B, self.ndof))
+        self.motor_in = np.zeros((B, self.nlink))
+        self.piv_type = np.zeros((B, self.nlink), dtype=np.int32); self.piv_prev = np.zeros((B, self.nlink))
+        self.cv_active = np.zeros((B, max(self.ncand, 1)), dtype=np.int32); self.cv_type = np.zeros_like(self.cv_active)
+        self.cv_ref = np.zeros((B, max(self.ncand, 1), 3)); self.cv_f = np.zeros_like(self.cv_ref)
+        self.dbg = np.zeros((B, 18 * self.nlink))
+        self.err = 0
+
+    def _run(self, mode, nsteps):
+        st = DevState()
+        for k in ("dis", "vel", "acc", "motor_in", "piv_type", "piv_prev", "cv_active", "cv_type", "cv_ref", "cv_f", "dbg"):
+            setattr(st, k, getattr(self, k).ctypes.data)
+        st.dbg_stride = 18 * self.nlink
+        st.batch = self.B
+        self.err = lib().rkfd_emu_run(C.cast(self.world.model, C.c_void_p), self.max_rigid, C.byref(st), mode, nsteps)
+        if self.err < 0:
+            raise RuntimeError("emulator: device model build failed")
+
+    def set_state(self, dis, vel):
+        self.dis[...] = np.asarray(dis).reshape(self.B, self.ndof); self.vel[...] = np.asarray(vel).reshape(self.B, self.ndof)
+
+    def get_state(self):
+        return self.dis.copy(), self.vel.copy(), self.acc.copy()
+
+    def set_motor_input(self, inp):
+        self.motor_in[...] = np.asarray(inp).reshape(self.B, self.nlink)
+
+    def get_contact(self):
+        n = self.ncand
+        return self.cv_active[:, :n].copy(), self.cv_type[:, :n].copy(), self.cv_ref[:, :n].copy(), self.cv_f[:, :n].copy()
+
+    def get_pivot(self):
+        return self.piv_type.copy(), self.piv_prev.copy()
+
+    def update_init(self):
+        self._run(1, 0)
+
+    def update(self, nsteps=1):
+        self._run(0, nsteps)
+
+    def eval(self, do_up_ref=False):
+        self._run(1 if do_up_ref else 2, 0)
+
+    def status(self):
+        return self.err

@@ -1,0 +1,73 @@
+/* rkfd_emu.cpp - DEVELOPMENT / TEST HARNESS ONLY.
+ *
+ * Runs the device code of roki-fd_amd/csrc/rkfd_device.h on the CPU by emulating one
+ * 64-lane wavefront with 64 host threads and barriers, so that the kernel LOGIC can be
+ * checked against the oracle in the no-GPU test tier.  It is not a fallback: nothing in the
+ * product library links or loads it, and the C-ABI fails loudly without a GPU.
+ */
+#include <barrier>
+#include <thread>
+#include <vector>
+#include <cstring>
+#include <cstdlib>
+
+#define RKFD_EMU
+static thread_local int t_lane;
+static std::barrier<> *g_bar;
+static double g_xd[64];
+static unsigned long long g_xb[64];
+
+int rkfd_emu_lane(void){ return t_lane; }
+void rkfd_emu_sync(void){ g_bar->arrive_and_wait(); }
+double rkfd_emu_g8sum(double x)
+{
+  g_xd[t_lane] = x;
+  g_bar->arrive_and_wait();
+  /* same association as the DPP butterfly: (l^1), then (l^2), then mirrored half */
+  const int b = t_lane & ~7, l = t_lane & 7;
+  auto q = [&](int k){ int base = k & ~3; double s[4]; for( int i=0; i<4; i++ ) s[i] = g_xd[b+base+i];
+                       int j = k & 3; double p1 = s[j] + s[j^1]; double p2 = s[j^2] + s[(j^2)^1]; return p1 + p2; };
+  double r = q( l ) + q( 7-l );
+  g_bar->arrive_and_wait();
+  return r;
+}
+double rkfd_emu_bcast(double x, int src)
+{
+  g_xd[t_lane] = x;
+  g_bar->arrive_and_wait();
+  double r = g_xd[src];
+  g_bar->arrive_and_wait();
+  return r;
+}
+unsigned long long rkfd_emu_ballot(int pred)
+{
+  g_xb[t_lane] = pred ? 1ull : 0ull;
+  g_bar->arrive_and_wait();
+  unsigned long long m = 0;
+  for( int i=0; i<64; i++ ) m |= g_xb[i] << i;
+  g_bar->arrive_and_wait();
+  return m;
+}
+
+#include "rkfd_device.h"
+#include "rkfd_devmodel_host.h"
+
+extern "C" int rkfd_emu_run(const rkfdModel *m, int max_rigid, rkfdDevState *st, int mode, int nsteps)
+{
+  rkfdDevModelHost h;
+  char err[256];
+  if( rkfd_devmodel_build( m, max_rigid, &h, err, sizeof(err) ) < 0 ) return -1;
+  std::vector<char> lds( h.lds_bytes + 64 );
+  int errflag = 0;
+  for( int b=0; b<st->batch; b++ ){
+    std::barrier<> bar( 64 );
+    g_bar = &bar;
+    std::memset( lds.data(), 0, lds.size() );
+    std::vector<std::thread> th;
+    for( int l=0; l<64; l++ )
+      th.emplace_back( [&, l](){ t_lane = l; rkfd_instance( h.dm, *st, b, lds.data(), mode, nsteps, &errflag ); } );
+    for( auto &t : th ) t.join();
+  }
+  rkfd_devmodel_free( &h );
+  return errflag;
+}
