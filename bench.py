@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""bench.py - sim-steps/sec of the batched rkFDUpdate hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W [--workload config4|config3|config2] [--batch B]
+
+A "step" is one rkFDUpdate (4 RKG stage evaluations + the committing evaluation) of every
+instance of the batch; state stays resident in HBM between steps.  One process per GPU; for
+N>1 the driver launches this file under torch.distributed.run and every rank simulates its
+own shard of instances (no data-path collective; one RCCL all-gather of the final states).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALG_BYTES = {  # algorithmic HBM bytes per instance-step (SURVEY.md 8d / DESIGN.md)
+    "config2": lambda m: 8 * 6 * m.ndof,
+    "config3": lambda m: 8 * 6 * m.ndof + 8 * 80 + 24 * 24,
+    "config4": lambda m: 8 * 6 * m.ndof + 8 * 80 + 24 * 24,
+}
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(R, name, seconds=10.0):
+    """the oracle (CPU restatement, 'port') timed on one host core on a bounded sample"""
+    import numpy as np
+    from oracle.pyoracle import Oracle
+    sc = R.scenarios.CONFIGS[name](batch=4)
+    nsteps = 0
+    t0 = time.perf_counter()
+    inst = 0
+    while time.perf_counter() - t0 < seconds:
+        o = Oracle(sc["world"].model)
+        o.set_state(sc["dis"][inst % 4], sc["vel"][inst % 4])
+        o.update_init()
+        for _ in range(200):
+            o.update()
+        nsteps += 200
+        inst += 1
+    dt = time.perf_counter() - t0
+    return dict(value=nsteps / dt, unit="sim-steps/sec", cores=1, kind="port",
+                sample=f"{inst} instances x 200 steps of {name}, sequential on 1 core (oracle/rkfd_oracle.c, gcc -O3 -funroll-loops)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="config4")
+    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import rkfd_pkg
+    R = rkfd_pkg.load()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+
+    Bn = args.batch
+    sc = R.scenarios.CONFIGS[args.workload](batch=Bn * world)
+    sl = slice(rank * Bn, (rank + 1) * Bn)
+    b = R.Batch(sc["world"], Bn, device=local, max_rigid=sc["max_rigid"])
+    b.set_state(sc["dis"][sl], sc["vel"][sl])
+    stream = torch.cuda.current_stream().cuda_stream
+    b.update_init(stream)
+    for _ in range(args.warmup):
+        b.update(1, stream)
+    assert b.status(stream) == 0
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        b.update(1, stream)
+    ev1.record()
+    barrier()
+    t1 = time.perf_counter()
+    st = b.status(stream)
+    elapsed = t1 - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # gather of final states only (RCCL over xGMI)
+        dis, vel, _ = b.get_state()
+        mine = torch.from_numpy(np.concatenate([dis, vel], axis=1)).cuda()
+        out = torch.empty((world * Bn, mine.shape[1]), dtype=mine.dtype, device="cuda")
+        dist.all_gather_into_tensor(out, mine)
+        torch.cuda.synchronize()
+
+    if rank == 0:
+        m = sc["world"].model.contents
+        alg = ALG_BYTES.get(args.workload, ALG_BYTES["config4"])(m)
+        achieved = alg * Bn / (kernel_ms * 1e-3) / 1e9
+        res = {
+            "metric": "sim-steps/sec (node), 30-DoF humanoid + ground contact, batch=4096",
+            "value": Bn * world * args.steps / elapsed, "unit": "sim-steps/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": sc["name"], "instances_per_gpu": Bn, "ndof": m.ndof, "nlink": m.nlink,
+                       "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "rkfd_step_kernel", "kernel_ms": kernel_ms, "alg_bytes_per_instance_step": alg},
+            "device_status": st,
+        }
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(R, args.workload)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
