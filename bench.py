@@ -73,8 +73,10 @@ def main():
     torch.cuda.set_device(local)
 
     Bn = args.batch
-    sc = R.scenarios.CONFIGS[args.workload](batch=Bn * world)
-    sl = slice(rank * Bn, (rank + 1) * Bn)
+    total = Bn * world                       # weak scaling: per-GPU work is fixed
+    sc = R.scenarios.CONFIGS[args.workload](batch=total)
+    lo, hi = R.sharding.shard_range(rank, world, total)
+    sl = slice(lo, hi)
     b = R.Batch(sc["world"], Bn, device=local, max_rigid=sc["max_rigid"])
     b.set_state(sc["dis"][sl], sc["vel"][sl])
     stream = torch.cuda.current_stream().cuda_stream
@@ -108,9 +110,9 @@ def main():
         # gather of final states only (RCCL over xGMI)
         dis, vel, _ = b.get_state()
         mine = torch.from_numpy(np.concatenate([dis, vel], axis=1)).cuda()
-        out = torch.empty((world * Bn, mine.shape[1]), dtype=mine.dtype, device="cuda")
-        dist.all_gather_into_tensor(out, mine)
+        out = R.sharding.gather_final_states(dist, mine, total)
         torch.cuda.synchronize()
+        assert out.shape[0] == total
 
     if rank == 0:
         m = sc["world"].model.contents

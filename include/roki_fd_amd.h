@@ -3,7 +3,7 @@
  * Mirrors the public interface of roki-fd for this path - same function names, argument
  * meaning and error behaviour as reference include/roki_fd/rkfd_sim.h:54-98,
  * rkfd_property.h:15-34 and rkfd_solver.h:23-60 - so that a driver written against the
- * reference (reference example/chain/*.c) reads the same here.  Everything below the API is
+ * reference (the drivers under reference example/chain/) reads the same here.  Everything below the API is
  * new: models are flattened into an rkfdModel and every evaluation runs on the GPU
  * (include/rkfd_hip.h); nothing is computed on the host.
  *

@@ -11,3 +11,4 @@ from .binding import (  # noqa: F401
     SOLVER_VERT, SOLVER_MLCP, SOLVER_VOLUME, CONTACT_RIGID, CONTACT_ELASTIC, SF, KF,
 )
 from . import scenarios  # noqa: F401
+from . import sharding  # noqa: F401

@@ -184,6 +184,9 @@ typedef struct {
   double *CX, *AX, *RW, *PRO, *REF, *CF; /* per candidate: 3, 9, 3, 3, 3, 3               */
   double *MA, *MB, *MF, *PU;      /* MLCP: [M*(M+1)], [M], [M], [2*nlevel*M]              */
   int *act, *typ, *lrg, *lel, *tgt, *cnt, *dofkind, *pivt;
+  int *LI;                        /* [NL] packed link info (RKFD_LI_*)                    */
+  int *CIp, *CFO;                 /* [NC] packed candidate info, first plane              */
+  int *PL;                        /* [NL*nlevel] ancestor at depth d (MLCP only)          */
   double *pivp, *min;             /* [NL] pivot prev torque, motor input                  */
 } rkfdLds;
 
@@ -192,12 +195,9 @@ RKFD_DEV size_t rkfd_lds_doubles(int NL, int ND, int NC, int M, int nlevel)
   return (size_t)4*ND + (size_t)NL*( 12+6+6+6+36+6+6+6+6+6+4 ) + (size_t)NC*( 3+9+3+3+3+3 )
        + (size_t)M*(M+1) + 2*(size_t)M + 2*(size_t)nlevel*M + 2*(size_t)NL;
 }
-RKFD_DEV size_t rkfd_lds_ints(int NL, int ND, int NC)
-{
-  return (size_t)5*NC + 8 + (size_t)ND + (size_t)NL;
-}
 
 RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int M, int nlevel)
+/* must match the byte count computed in rkfd_devmodel.cpp */
 {
   double *d = (double *)base;
   L->q = d; d += ND; L->qd = d; d += ND; L->acc = d; d += ND; L->tmp = d; d += ND;
@@ -211,6 +211,8 @@ RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int
   int *ip = (int *)d;
   L->act = ip; ip += NC; L->typ = ip; ip += NC; L->lrg = ip; ip += NC; L->lel = ip; ip += NC;
   L->tgt = ip; ip += NC; L->cnt = ip; ip += 8; L->dofkind = ip; ip += ND; L->pivt = ip; ip += NL;
+  L->LI = ip; ip += NL; L->CIp = ip; ip += NC; L->CFO = ip; ip += NC;
+  L->PL = ip;
 }
 
 /* counters in L->cnt */
@@ -229,9 +231,13 @@ RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, const rkfdLds &L)
   const int NL = m.nlink;
   const bool on = lane < NL;
   const int i = on ? lane : 0;
-  const int jt = on ? m.jtype[i] : RKFD_JOINT_FIXED;
-  const int off = m.dofoff[i];
+  const int li = L.LI[i];
+  const int jt = on ? RKFD_LI_JT( li ) : RKFD_JOINT_FIXED;
+  const int off = RKFD_LI_OFF( li );
   double R[9], p[3], Rj[9], vJ[6], qd1 = 0, qdf[6] = {0,0,0,0,0,0};
+  int anc[RKFD_MAX_ROUND];
+#pragma unroll
+  for( int r=0; r<RKFD_MAX_ROUND; r++ ) anc[r] = ( on && r < m.nround ) ? m.anc[r*NL+i] : -1;
 
   /* local (adjacent) transform = org frame * joint transform */
   {
@@ -269,8 +275,10 @@ RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, const rkfdLds &L)
   }
   SYNC();
   /* pointer jumping: compose with the ancestor 2^r levels up */
-  for( int r=0; r<m.nround; r++ ){
-    const int a = on ? m.anc[r*NL+i] : -1;
+#pragma unroll
+  for( int r=0; r<RKFD_MAX_ROUND; r++ ){
+    if( r >= m.nround ) break;
+    const int a = anc[r];
     if( a >= 0 ){
       double Ra[9], pa[3], t[3];
 #pragma unroll
@@ -325,8 +333,10 @@ RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, const rkfdLds &L)
     double v[6];
 #pragma unroll
     for( int k=0; k<6; k++ ) v[k] = vJ[k];
-    for( int r=0; r<m.nround; r++ ){
-      const int a = on ? m.anc[r*NL+i] : -1;
+#pragma unroll
+    for( int r=0; r<RKFD_MAX_ROUND; r++ ){
+      if( r >= m.nround ) break;
+      const int a = anc[r];
       if( a >= 0 ){
 #pragma unroll
         for( int k=0; k<6; k++ ) v[k] += L.V[6*a+k];
@@ -404,7 +414,7 @@ RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, const rkfdLds &L)
     if( on ){
       double tau = 0, jm = 0;
       if( jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM ){
-        const int mt = m.mtype[i];
+        const int mt = RKFD_LI_MT( li );
         double tin = 0, treg = 0, tf = 0;
         const double in = L.min[i];
         if( mt == RKFD_MOTOR_DC ){
@@ -476,85 +486,94 @@ RKFD_DEV void d_chol6_solve(const double *Lm, const double *b, double *x)
 }
 
 /* ------------------------------------------------------------------------ */
+/* one schedule record: what one 8-lane group does in one sweep iteration */
+typedef struct { int i, li, nchild, c0, c1, c2, c3, coff; } rkfdRec;
+RKFD_DEV rkfdRec rkfd_rec_load(const rkfdDevModel &m, int t, int g)
+{
+  rkfdRec r;
+  if( t < 0 || t >= m.nsched ){ r.i = -1; r.li = 0; r.nchild = 0; r.c0 = r.c1 = r.c2 = r.c3 = -1; r.coff = 0; return r; }
+  const int *p = m.sched + ( (size_t)t*8 + g )*8;
+  r.i = p[0]; r.li = p[1]; r.nchild = p[2]; r.c0 = p[3]; r.c1 = p[4]; r.c2 = p[5]; r.c3 = p[6]; r.coff = p[7];
+  return r;
+}
+
 /* ABA sweep 2 (leaf to root), level-synchronous; 8 lanes per link, lane r = row r.
  * full = true : articulated inertia + bias (rkChainUpdateABI, backward part)
  * full = false: bias only, reusing Ia, U, Dinv (rkChainUpdateCachedABI, backward part).
- * Collectives (G8SUM, SYNC) are issued from wave-uniform control flow only. */
+ * The per-iteration work list comes from the model's schedule (prefetched one iteration
+ * ahead); collectives (G8SUM, SYNC) are issued from wave-uniform control flow only. */
 RKFD_DEV void rkfd_phase_sweep2(const rkfdDevModel &m, const rkfdLds &L, bool full)
 {
   const int lane = LANE();
   const int g = lane >> 3, r = lane & 7;
-  for( int lv=m.nlevel-1; lv>=0; lv-- ){
-    const int lo = m.level_off[lv], hi = m.level_off[lv+1];
-    for( int base=lo; base<hi; base+=8 ){
-      const bool onl = base+g < hi;
-      const bool on = onl && r < 6;
-      const int i = onl ? m.level_link[base+g] : 0;
-      const int jt = onl ? m.jtype[i] : RKFD_JOINT_FIXED;
-      const bool is1 = jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM;
-      const bool isf = jt == RKFD_JOINT_FLOAT;
-      const int rr = r < 6 ? r : 0;
-      double row[6], c[6], S[6], U_r = 0, Dinv = 0;
-      /* gather own + children */
-      double pr = L.PB[6*i+rr] - L.FE[6*i+rr];
+  const int rr = r < 6 ? r : 0;
+  rkfdRec nxt = rkfd_rec_load( m, m.nsched-1, g );
+  for( int t=m.nsched-1; t>=0; t-- ){
+    const rkfdRec rec = nxt;
+    nxt = rkfd_rec_load( m, t-1, g );
+    const bool onl = rec.i >= 0;
+    const bool on = onl && r < 6;
+    const int i = onl ? rec.i : 0;
+    const int jt = onl ? RKFD_LI_JT( rec.li ) : RKFD_JOINT_FIXED;
+    const bool is1 = jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM;
+    const bool isf = jt == RKFD_JOINT_FLOAT;
+    double row[6], c[6], S[6], U_r = 0, Dinv = 0;
+    /* gather own + children */
+    double pr = L.PB[6*i+rr] - L.FE[6*i+rr];
 #pragma unroll
-      for( int k=0; k<6; k++ ){ row[k] = L.IA[36*i+6*rr+k]; S[k] = L.S[6*i+k]; c[k] = L.C[6*i+k]; }
-      {
-        const int c0 = m.child_off[i], c1 = onl ? m.child_off[i+1] : c0;
-        for( int cc=c0; cc<c1; cc++ ){
-          const int ch = m.child_idx[cc];
-          pr += L.PA[6*ch+rr];
-          if( full && m.jtype[ch] != RKFD_JOINT_FLOAT ){
+    for( int k=0; k<6; k++ ){ row[k] = L.IA[36*i+6*rr+k]; S[k] = L.S[6*i+k]; c[k] = L.C[6*i+k]; }
+    for( int cc=0; cc<rec.nchild; cc++ ){
+      const int ch = cc == 0 ? rec.c0 : ( cc == 1 ? rec.c1 : ( cc == 2 ? rec.c2 : ( cc == 3 ? rec.c3 : m.child_idx[rec.coff+cc] ) ) );
+      pr += L.PA[6*ch+rr];
+      if( full && RKFD_LI_JT( L.LI[ch] ) != RKFD_JOINT_FLOAT ){
 #pragma unroll
-            for( int k=0; k<6; k++ ) row[k] += L.IA[36*ch+6*rr+k];
-          }
-        }
+        for( int k=0; k<6; k++ ) row[k] += L.IA[36*ch+6*rr+k];
       }
-      const double S_r = S[rr];
+    }
+    const double S_r = S[rr];
+    if( full ){
+#pragma unroll
+      for( int k=0; k<6; k++ ) U_r += row[k]*S[k];
+      const double D = G8SUM( ( on && is1 ) ? S_r*U_r : 0.0 ) + L.MS[4*i+3];
+      Dinv = 1.0/D;
+    } else {
+      U_r = L.U[6*i+rr];
+      Dinv = L.MS[4*i+0];
+    }
+    const double u = L.MS[4*i+2] - G8SUM( ( on && is1 ) ? S_r*pr : 0.0 );
+    /* exchange U through LDS: every row needs every U[c] */
+    SYNC();
+    if( full && on && is1 ) L.U[6*i+rr] = U_r;
+    SYNC();
+    double pa = pr;
+    if( is1 ){
+      if( full ){
+        const double tt = U_r*Dinv;
+#pragma unroll
+        for( int k=0; k<6; k++ ) row[k] -= tt*L.U[6*i+k];
+      }
+      double sacc = 0;
+#pragma unroll
+      for( int k=0; k<6; k++ ) sacc += row[k]*c[k];
+      pa = pr + sacc + U_r*( u*Dinv );
+    } else if( isf ){
+      pa = 0;
+    }
+    /* write back: Ia row (float joints keep IA for the factorisation), pa, scalars */
+    if( on ){
       if( full ){
 #pragma unroll
-        for( int k=0; k<6; k++ ) U_r += row[k]*S[k];
-        const double D = G8SUM( ( on && is1 ) ? S_r*U_r : 0.0 ) + L.MS[4*i+3];
-        Dinv = 1.0/D;
-      } else {
-        U_r = L.U[6*i+rr];
-        Dinv = L.MS[4*i+0];
+        for( int k=0; k<6; k++ ) L.IA[36*i+6*rr+k] = row[k];
       }
-      const double u = L.MS[4*i+2] - G8SUM( ( on && is1 ) ? S_r*pr : 0.0 );
-      /* exchange U through LDS: every row needs every U[c] */
-      SYNC();
-      if( full && on && is1 ) L.U[6*i+rr] = U_r;
-      SYNC();
-      double pa = pr;
-      if( is1 ){
-        if( full ){
-          const double t = U_r*Dinv;
-#pragma unroll
-          for( int k=0; k<6; k++ ) row[k] -= t*L.U[6*i+k];
-        }
-        double s = 0;
-#pragma unroll
-        for( int k=0; k<6; k++ ) s += row[k]*c[k];
-        pa = pr + s + U_r*( u*Dinv );
-      } else if( isf ){
-        pa = 0;
+      L.PA[6*i+rr] = pa;
+      if( isf ) L.U[6*i+rr] = pr;   /* float: the U slot keeps the bias pA */
+      if( rr == 0 && is1 ){
+        if( full ) L.MS[4*i+0] = Dinv;
+        L.MS[4*i+1] = u;
       }
-      /* write back: Ia row (float joints keep IA for the factorisation), pa, scalars */
-      if( on ){
-        if( full ){
-#pragma unroll
-          for( int k=0; k<6; k++ ) L.IA[36*i+6*rr+k] = row[k];
-        }
-        L.PA[6*i+rr] = pa;
-        if( isf ) L.U[6*i+rr] = pr;   /* float: the U slot keeps the bias pA */
-        if( rr == 0 && is1 ){
-          if( full ) L.MS[4*i+0] = Dinv;
-          L.MS[4*i+1] = u;
-        }
-      }
-      SYNC();
-      if( full && isf && onl && r == 0 ) d_chol6_inplace( &L.IA[36*i] );
     }
+    SYNC();
+    if( full && isf && onl && r == 0 ) d_chol6_inplace( &L.IA[36*i] );
     SYNC();
   }
 }
@@ -564,55 +583,55 @@ RKFD_DEV void rkfd_phase_sweep3(const rkfdDevModel &m, const rkfdLds &L)
 {
   const int lane = LANE();
   const int g = lane >> 3, r = lane & 7;
-  for( int lv=0; lv<m.nlevel; lv++ ){
-    const int lo = m.level_off[lv], hi = m.level_off[lv+1];
-    for( int base=lo; base<hi; base+=8 ){
-      const bool onl = base+g < hi;
-      const bool on = onl && r < 6;
-      const int i = onl ? m.level_link[base+g] : 0;
-      const int jt = onl ? m.jtype[i] : RKFD_JOINT_FIXED;
-      const bool is1 = jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM;
-      const int par = m.parent[i];
-      const int rr = r < 6 ? r : 0;
-      const int off = m.dofoff[i];
-      const double ap = ( par >= 0 ) ? L.AC[6*par+rr] : 0.0;
-      const double y = ap + L.C[6*i+rr];
-      const double uy = G8SUM( ( on && is1 ) ? L.U[6*i+rr]*y : 0.0 );
-      double a = y;
-      if( is1 ){
-        const double qdd = ( L.MS[4*i+1] - uy )*L.MS[4*i+0];
-        a = y + L.S[6*i+rr]*qdd;
-        if( on && rr == 0 ) L.acc[off] = qdd;
-      } else if( jt == RKFD_JOINT_FLOAT && onl && r == 0 ){
-        /* a = IA^-1 ( -pA ); joint acceleration from a - a_parent - c */
-        double rhs[6], x[6], d[6], R[9], Rj[9], Row[9], p[3], qq[3];
+  const int rr = r < 6 ? r : 0;
+  rkfdRec nxt = rkfd_rec_load( m, 0, g );
+  for( int t=0; t<m.nsched; t++ ){
+    const rkfdRec rec = nxt;
+    nxt = rkfd_rec_load( m, t+1, g );
+    const bool onl = rec.i >= 0;
+    const bool on = onl && r < 6;
+    const int i = onl ? rec.i : 0;
+    const int jt = onl ? RKFD_LI_JT( rec.li ) : RKFD_JOINT_FIXED;
+    const bool is1 = jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM;
+    const int par = onl ? RKFD_LI_PAR( rec.li ) : -1;
+    const int off = RKFD_LI_OFF( rec.li );
+    const double ap = ( par >= 0 ) ? L.AC[6*par+rr] : 0.0;
+    const double y = ap + L.C[6*i+rr];
+    const double uy = G8SUM( ( on && is1 ) ? L.U[6*i+rr]*y : 0.0 );
+    double a = y;
+    if( is1 ){
+      const double qdd = ( L.MS[4*i+1] - uy )*L.MS[4*i+0];
+      a = y + L.S[6*i+rr]*qdd;
+      if( on && rr == 0 ) L.acc[off] = qdd;
+    } else if( jt == RKFD_JOINT_FLOAT && onl && r == 0 ){
+      /* a = IA^-1 ( -pA ); joint acceleration from a - a_parent - c */
+      double rhs[6], x[6], d[6], R[9], Rj[9], Row[9], p[3], qq[3];
 #pragma unroll
-        for( int k=0; k<6; k++ ) rhs[k] = -L.U[6*i+k];
-        d_chol6_solve( &L.IA[36*i], rhs, x );
+      for( int k=0; k<6; k++ ) rhs[k] = -L.U[6*i+k];
+      d_chol6_solve( &L.IA[36*i], rhs, x );
 #pragma unroll
-        for( int k=0; k<6; k++ ){
-          L.AC[6*i+k] = x[k];
-          d[k] = x[k] - ( par >= 0 ? L.AC[6*par+k] : 0.0 ) - L.C[6*i+k];
-        }
-#pragma unroll
-        for( int k=0; k<9; k++ ) R[k] = L.X[12*i+k];
-        p[0] = L.X[12*i+9]; p[1] = L.X[12*i+10]; p[2] = L.X[12*i+11];
-        qq[0] = L.q[off+3]; qq[1] = L.q[off+4]; qq[2] = L.q[off+5];
-        d_from_aa( qq, Rj );
-        {
-          double RjT[9] = { Rj[0],Rj[3],Rj[6], Rj[1],Rj[4],Rj[7], Rj[2],Rj[5],Rj[8] };
-          d_mul33( R, RjT, Row );
-        }
-        /* wdot_j = Row' alpha ; vdot_j = Row' ( a_O - p x alpha ) */
-        double t[3], lin[3], o1[3], o2[3];
-        d_cross( p, d, t );
-        lin[0] = d[3]-t[0]; lin[1] = d[4]-t[1]; lin[2] = d[5]-t[2];
-        d_tmulv( Row, lin, o1 ); d_tmulv( Row, d, o2 );
-        L.acc[off] = o1[0]; L.acc[off+1] = o1[1]; L.acc[off+2] = o1[2];
-        L.acc[off+3] = o2[0]; L.acc[off+4] = o2[1]; L.acc[off+5] = o2[2];
+      for( int k=0; k<6; k++ ){
+        L.AC[6*i+k] = x[k];
+        d[k] = x[k] - ( par >= 0 ? L.AC[6*par+k] : 0.0 ) - L.C[6*i+k];
       }
-      if( on && jt != RKFD_JOINT_FLOAT ) L.AC[6*i+rr] = a;
+#pragma unroll
+      for( int k=0; k<9; k++ ) R[k] = L.X[12*i+k];
+      p[0] = L.X[12*i+9]; p[1] = L.X[12*i+10]; p[2] = L.X[12*i+11];
+      qq[0] = L.q[off+3]; qq[1] = L.q[off+4]; qq[2] = L.q[off+5];
+      d_from_aa( qq, Rj );
+      {
+        double RjT[9] = { Rj[0],Rj[3],Rj[6], Rj[1],Rj[4],Rj[7], Rj[2],Rj[5],Rj[8] };
+        d_mul33( R, RjT, Row );
+      }
+      /* wdot_j = Row' alpha ; vdot_j = Row' ( a_O - p x alpha ) */
+      double t3[3], lin[3], o1[3], o2[3];
+      d_cross( p, d, t3 );
+      lin[0] = d[3]-t3[0]; lin[1] = d[4]-t3[1]; lin[2] = d[5]-t3[2];
+      d_tmulv( Row, lin, o1 ); d_tmulv( Row, d, o2 );
+      L.acc[off] = o1[0]; L.acc[off+1] = o1[1]; L.acc[off+2] = o1[2];
+      L.acc[off+3] = o2[0]; L.acc[off+4] = o2[1]; L.acc[off+5] = o2[2];
     }
+    if( on && jt != RKFD_JOINT_FLOAT ) L.AC[6*i+rr] = a;
     SYNC();
   }
 }
@@ -643,7 +662,8 @@ RKFD_DEV void rkfd_phase_collision(const rkfdDevModel &m, const rkfdLds &L)
   const int j = on ? lane : 0;
   int is_act = 0, is_rg = 0, is_el = 0;
   if( on ){
-    const int la = m.cand_linkA[j], lb = m.cand_linkB[j];
+    const int cinf = L.CIp[j];
+    const int la = RKFD_CI_A( cinf ), lb = RKFD_CI_B( cinf );
     double RA[9], pA[3], RB[9], pB[3], vl[3], x[3], y[3], rr[3];
 #pragma unroll
     for( int k=0; k<9; k++ ){ RA[k] = L.X[12*la+k]; RB[k] = L.X[12*lb+k]; }
@@ -654,7 +674,7 @@ RKFD_DEV void rkfd_phase_collision(const rkfdDevModel &m, const rkfdLds &L)
     rr[0] = x[0]-pB[0]; rr[1] = x[1]-pB[1]; rr[2] = x[2]-pB[2];
     d_tmulv( RB, rr, y );
     double smax = -HUGE_VAL; int fbest = -1;
-    const int f0 = m.cand_foff[j], nf = m.cand_nf[j];
+    const int f0 = L.CFO[j], nf = RKFD_CI_NF( cinf );
     for( int f=f0; f<f0+nf; f++ ){
       const double s = m.planes[4*f]*y[0] + m.planes[4*f+1]*y[1] + m.planes[4*f+2]*y[2] - m.planes[4*f+3];
       if( s > smax ){ smax = s; fbest = f; }
@@ -678,7 +698,7 @@ RKFD_DEV void rkfd_phase_collision(const rkfdDevModel &m, const rkfdLds &L)
 #pragma unroll
       for( int k=0; k<3; k++ ){ L.AX[9*j+k] = nw[k]; L.AX[9*j+3+k] = t1[k]; L.AX[9*j+6+k] = t2[k]; }
       is_act = 1;
-      const int ct = m.ci_type[m.cand_ci[j]];
+      const int ct = m.ci_type[RKFD_CI_CI( cinf )];
       is_rg = ct == RKFD_CONTACT_RIGID; is_el = ct == RKFD_CONTACT_ELASTIC;
     } else {
       L.act[j] = 0;
@@ -718,8 +738,9 @@ RKFD_DEV void rkfd_push_wrenches(const rkfdDevModel &m, const rkfdLds &L, const 
       } else {
         w = lane == 3 ? f[0] : ( lane == 4 ? f[1] : f[2] );
       }
-      L.FE[6*m.cand_linkA[j]+lane] += w;
-      L.FE[6*m.cand_linkB[j]+lane] -= w;
+      const int cinf = L.CIp[j];
+      L.FE[6*RKFD_CI_A( cinf )+lane] += w;
+      L.FE[6*RKFD_CI_B( cinf )+lane] -= w;
     }
   }
   SYNC();
@@ -728,7 +749,7 @@ RKFD_DEV void rkfd_push_wrenches(const rkfdDevModel &m, const rkfdLds &L, const 
 /* rkFDContactForceModifyFriction (reference src/rkfd_util.c:239-266), one lane = one contact */
 RKFD_DEV void d_modify_friction(const rkfdDevModel &m, const rkfdLds &L, int j, const double *vr, double *f, bool doUpRef)
 {
-  const int ci = m.cand_ci[j];
+  const int ci = RKFD_CI_CI( L.CIp[j] );
   const double *ax = &L.AX[9*j];
   const double fn = d_dot( f, ax );
   const double f1 = d_dot( f, ax+3 ), f2 = d_dot( f, ax+6 );
@@ -758,11 +779,11 @@ RKFD_DEV void rkfd_phase_penalty(const rkfdDevModel &m, const rkfdLds &L, bool d
   const int lane = LANE();
   const int nel = L.cnt[CNT_NEL];
   if( lane < nel ){
-    const int j = L.lel[lane], ci = m.cand_ci[j];
+    const int j = L.lel[lane], cinf = L.CIp[j], ci = RKFD_CI_CI( cinf );
     const double x[3] = { L.CX[3*j], L.CX[3*j+1], L.CX[3*j+2] };
     double va[3], vb[3], vr[3], f[3];
-    d_point_vel( &L.V[6*m.cand_linkA[j]], x, va );
-    d_point_vel( &L.V[6*m.cand_linkB[j]], x, vb );
+    d_point_vel( &L.V[6*RKFD_CI_A( cinf )], x, va );
+    d_point_vel( &L.V[6*RKFD_CI_B( cinf )], x, vb );
     const double E = m.ci_e[ci], kv = -1.0*( m.ci_v[ci] + E*m.dt );
 #pragma unroll
     for( int k=0; k<3; k++ ){
@@ -799,8 +820,8 @@ RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L)
     for( int c=0; c<nc; c++ ){
       const int j = L.lrg[c];
       for( int s=0; s<2; s++ ){
-        const int l = s == 0 ? m.cand_linkA[j] : m.cand_linkB[j];
-        if( m.is_static[l] ) continue;
+        const int l = s == 0 ? RKFD_CI_A( L.CIp[j] ) : RKFD_CI_B( L.CIp[j] );
+        if( RKFD_LI_STATIC( L.LI[l] ) ) continue;
         int k; for( k=0; k<nt; k++ ) if( L.tgt[k] == l ) break;
         if( k == nt ) L.tgt[nt++] = l;
       }
@@ -810,8 +831,8 @@ RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L)
   /* b: free relative acceleration, then *dt + relative velocity + compensation
    * (_rkFDSolverBiasAcc / BiasVel / RelaxationCompensation, reference src/rkfd_mlcp.c:58-74,146-188) */
   if( lane < nc ){
-    const int j = L.lrg[lane], ci = m.cand_ci[j];
-    const int la = m.cand_linkA[j], lb = m.cand_linkB[j];
+    const int j = L.lrg[lane], cinf = L.CIp[j], ci = RKFD_CI_CI( cinf );
+    const int la = RKFD_CI_A( cinf ), lb = RKFD_CI_B( cinf );
     const double x[3] = { L.CX[3*j], L.CX[3*j+1], L.CX[3*j+2] };
     double aa[3], ab[3], va[3], vb[3], ra[3], rv[3], d[3];
     d_point_acc( &L.AC[6*la], &L.V[6*la], x, aa );
@@ -838,7 +859,8 @@ RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L)
     const bool on = lane < M;
     const int c = on ? lane/3 : 0, ia = on ? lane%3 : 0;
     const int j = nc > 0 ? L.lrg[c] : 0;
-    const int lk[2] = { m.cand_linkA[j], m.cand_linkB[j] };
+    const int cinfk = L.CIp[j];
+    const int lk[2] = { RKFD_CI_A( cinfk ), RKFD_CI_B( cinfk ) };
     double W[6], droot[2][6];
     int rootl[2] = { -1, -1 };
     {
@@ -852,19 +874,20 @@ RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L)
         int i = lk[s];
 #pragma unroll
         for( int k=0; k<6; k++ ) droot[s][k] = 0;
-        if( m.is_static[i] ) continue;
+        if( RKFD_LI_STATIC( L.LI[i] ) ) continue;
         /* bias force delta: p = -f_ext */
         double dp[6];
         const double sg = s == 0 ? -1.0 : 1.0;
 #pragma unroll
         for( int k=0; k<6; k++ ) dp[k] = sg*W[k];
         for(;;){
-          const int jt = m.jtype[i], par = m.parent[i];
+          const int lii = L.LI[i];
+          const int jt = RKFD_LI_JT( lii ), par = RKFD_LI_PAR( lii );
           if( jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM ){
             double du = 0;
 #pragma unroll
             for( int k=0; k<6; k++ ) du -= L.S[6*i+k]*dp[k];
-            L.PU[( s*NLV + m.depth[i] )*M + lane] = du;
+            L.PU[( s*NLV + RKFD_LI_DEPTH( lii ) )*M + lane] = du;
             const double t = du*L.MS[4*i+0];
 #pragma unroll
             for( int k=0; k<6; k++ ) dp[k] += L.U[6*i+k]*t;
@@ -889,22 +912,22 @@ RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L)
       for( int r=0; r<M; r++ ) L.MA[r*ld+lane] = 0.0;
       for( int t=0; t<nt; t++ ){
         const int T = L.tgt[t];
-        const int dT = m.depth[T];
-        const int rt = m.pathlink[T*NLV];
+        const int dT = RKFD_LI_DEPTH( L.LI[T] );
+        const int rt = L.PL[T*NLV];
         double da[6] = {0,0,0,0,0,0};
         int side = -1;
-        if( rootl[0] >= 0 && m.pathlink[lk[0]*NLV] == rt ) side = 0;
-        else if( rootl[1] >= 0 && m.pathlink[lk[1]*NLV] == rt ) side = 1;
+        if( rootl[0] >= 0 && L.PL[lk[0]*NLV] == rt ) side = 0;
+        else if( rootl[1] >= 0 && L.PL[lk[1]*NLV] == rt ) side = 1;
         if( side < 0 ) continue;
-        const int src = lk[side], dsrc = m.depth[src];
+        const int src = lk[side], dsrc = RKFD_LI_DEPTH( L.LI[src] );
         for( int d=0; d<=dT; d++ ){
-          const int i = m.pathlink[T*NLV+d];
-          const int jt = m.jtype[i];
+          const int i = L.PL[T*NLV+d];
+          const int jt = RKFD_LI_JT( L.LI[i] );
           if( jt == RKFD_JOINT_FLOAT ){
 #pragma unroll
             for( int k=0; k<6; k++ ) da[k] = droot[side][k];
           } else if( jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM ){
-            const bool onpath = d <= dsrc && m.pathlink[src*NLV+d] == i;
+            const bool onpath = d <= dsrc && L.PL[src*NLV+d] == i;
             double du = onpath ? L.PU[( side*NLV + d )*M + lane] : 0.0;
             double ua = 0;
 #pragma unroll
@@ -918,8 +941,8 @@ RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L)
         for( int r=0; r<nc; r++ ){
           const int jr = L.lrg[r];
           double sgn = 0;
-          if( m.cand_linkA[jr] == T ) sgn = 1.0;
-          else if( m.cand_linkB[jr] == T ) sgn = -1.0;
+          if( RKFD_CI_A( L.CIp[jr] ) == T ) sgn = 1.0;
+          else if( RKFD_CI_B( L.CIp[jr] ) == T ) sgn = -1.0;
           if( sgn == 0 ) continue;
           const double x[3] = { L.CX[3*jr], L.CX[3*jr+1], L.CX[3*jr+2] };
           double t3[3], acc[3];
@@ -931,7 +954,7 @@ RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L)
         }
       }
       /* relaxation on the diagonal */
-      L.MA[lane*ld+lane] += m.ci_l[m.cand_ci[j]];
+      L.MA[lane*ld+lane] += m.ci_l[RKFD_CI_CI( cinfk )];
     }
     SYNC();
   }
@@ -942,6 +965,12 @@ RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L)
     const int row = on ? lane : 0;
     double res = on ? L.MB[row] : 0.0, f = 0.0;
     const double diag = on ? L.MA[row*ld+row] : 1.0;
+    /* friction coefficient of this row's contact (type as of the start of the solve) */
+    double murow = 0.0;
+    if( on ){
+      const int jr_ = L.lrg[row/3], cir_ = RKFD_CI_CI( L.CIp[jr_] );
+      murow = L.typ[jr_] == RKFD_SF ? m.ci_sf[cir_] : m.ci_kf[cir_];
+    }
     for( int it=0; it<m.max_iter; it++ ){
       for( int c=0; c<nc; c++ ){
         const int k = 3*c;
@@ -954,14 +983,13 @@ RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L)
       }
       for( int c=0; c<nc; c++ ){
         const int k1 = 3*c+1, k2 = 3*c+2;
-        const int j = L.lrg[c], ci = m.cand_ci[j];
         const double r1 = BCAST( res, k1 ), f1 = BCAST( f, k1 ), a11 = BCAST( diag, k1 );
         const double r2 = BCAST( res, k2 ), f2 = BCAST( f, k2 ), a22 = BCAST( diag, k2 );
         const double fn = BCAST( f, 3*c );
         const double ff0 = fabs( a11 ) < RKFD_DEV_TOL ? 0.0 : -( r1 - a11*f1 )/a11;
         const double ff1 = fabs( a22 ) < RKFD_DEV_TOL ? 0.0 : -( r2 - a22*f2 )/a22;
         const double fnorm = ff0*ff0 + ff1*ff1;
-        const double mu = L.typ[j] == RKFD_SF ? m.ci_sf[ci] : m.ci_kf[ci];
+        const double mu = BCAST( murow, k1 );
         double fs = mu*fn; fs = fs*fs;
         double n1, n2;
         if( fnorm < RKFD_DEV_TOL || fs < RKFD_DEV_TOL ){ n1 = 0; n2 = 0; }
@@ -978,7 +1006,7 @@ RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L)
   SYNC();
   /* _rkFDSolverSetForce (reference src/rkfd_mlcp.c:252-284) incl. quirks Q1 / Q2 */
   if( lane < nc ){
-    const int j = L.lrg[lane], ci = m.cand_ci[j];
+    const int j = L.lrg[lane], ci = RKFD_CI_CI( L.CIp[j] );
     double fw[3] = {0,0,0};
 #pragma unroll
     for( int i=0; i<3; i++ ){
@@ -1011,8 +1039,8 @@ RKFD_DEV int rkfd_evaluate(const rkfdDevModel &m, const rkfdLds &L, bool doUpRef
   rkfd_phase_kinematics( m, L );
   /* commit joint friction pivots (the reference does so inside rkFDJointFrictionRevolDC) */
   if( doUpRef && lane < m.nlink ){
-    const int jt = m.jtype[lane];
-    if( ( jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM ) && m.mtype[lane] == RKFD_MOTOR_DC )
+    const int jt = RKFD_LI_JT( L.LI[lane] );
+    if( ( jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM ) && RKFD_LI_MT( L.LI[lane] ) == RKFD_MOTOR_DC )
       L.pivt[lane] = (int)L.MS[4*lane+1];
   }
   /* MS slot 0 carries (driving torque + friction) until sweep 2 overwrites it: keep a copy */
@@ -1026,22 +1054,27 @@ RKFD_DEV int rkfd_evaluate(const rkfdDevModel &m, const rkfdLds &L, bool doUpRef
     L.cnt[CNT_NRG] = 0; L.cnt[CNT_NEL] = 0;
   }
   SYNC();
-  rkfd_phase_sweep2( m, L, true );
-  rkfd_phase_sweep3( m, L );
-  if( L.cnt[CNT_NRG] > 0 ){
-    if( m.solver == RKFD_SOLVER_MLCP ){
-      rkfd_phase_mlcp( m, L );
-      rkfd_phase_sweep2( m, L, false );
-      rkfd_phase_sweep3( m, L );
-    } else {
-      err = 1;
+  /* pass 0: rkChainUpdateABI (full sweeps; with rigid contacts this is rkFDUpdateAccBias);
+   * pass 1 (only after the MLCP solve): rkChainUpdateCachedABI with the contact wrenches.
+   * Written as a loop so that the sweep code exists once in the instruction stream. */
+  int npass = 1;
+  for( int pass=0; pass<npass; pass++ ){
+    rkfd_phase_sweep2( m, L, pass == 0 );
+    rkfd_phase_sweep3( m, L );
+    if( pass == 0 && L.cnt[CNT_NRG] > 0 ){
+      if( m.solver == RKFD_SOLVER_MLCP ){
+        rkfd_phase_mlcp( m, L );
+        npass = 2;
+      } else {
+        err = 1;
+      }
     }
   }
   /* rkFDUpdateJointPrevDrivingTrq (reference src/rkfd_util.c:289-311), committing evaluation only */
   if( doUpRef && lane < m.nlink ){
-    const int jt = m.jtype[lane];
+    const int jt = RKFD_LI_JT( L.LI[lane] );
     if( jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM )
-      L.pivp[lane] = drv - L.MS[4*lane+3]*L.acc[m.dofoff[lane]];
+      L.pivp[lane] = drv - L.MS[4*lane+3]*L.acc[RKFD_LI_OFF( L.LI[lane] )];
   }
   SYNC();
   return err;
@@ -1089,78 +1122,74 @@ RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkfdDevState &st, int b
   double q = 0, qd = 0;
   if( lane < ND ){ q = st.dis[(size_t)b*ND+lane]; qd = st.vel[(size_t)b*ND+lane]; L.dofkind[lane] = 0; }
   if( lane < NL ){
+    L.LI[lane]   = m.linfo[lane];
     L.min[lane]  = st.motor_in[(size_t)b*NL+lane];
     L.pivt[lane] = st.piv_type[(size_t)b*NL+lane];
     L.pivp[lane] = st.piv_prev[(size_t)b*NL+lane];
   }
+  if( m.maxrg > 0 ){
+    for( int k=lane; k<NL*m.nlevel; k+=RKFD_WAVE ) L.PL[k] = m.pathlink[k];
+  }
   if( lane < NC ){
+    L.CIp[lane] = m.cinfo[lane];
+    L.CFO[lane] = m.cand_foff[lane];
     L.act[lane] = st.cv_active[(size_t)b*NC+lane];
     L.typ[lane] = st.cv_type[(size_t)b*NC+lane];
 #pragma unroll
     for( int k=0; k<3; k++ ) L.REF[3*lane+k] = st.cv_ref[((size_t)b*NC+lane)*3+k];
   }
   SYNC();
-  if( lane < NL && m.jtype[lane] == RKFD_JOINT_FLOAT ){
-    L.dofkind[m.dofoff[lane]+3] = 1;
-    L.dofkind[m.dofoff[lane]+4] = 2;
-    L.dofkind[m.dofoff[lane]+5] = 2;
+  if( lane < NL && RKFD_LI_JT( L.LI[lane] ) == RKFD_JOINT_FLOAT ){
+    const int o_ = RKFD_LI_OFF( L.LI[lane] );
+    L.dofkind[o_+3] = 1;
+    L.dofkind[o_+4] = 2;
+    L.dofkind[o_+5] = 2;
   }
   SYNC();
   int err = 0;
-  if( mode != 0 ){
-    if( lane < ND ){ L.q[lane] = q; L.qd[lane] = qd; }
-    SYNC();
-    err |= rkfd_evaluate( m, L, mode == 1 );
-  } else {
+  {
+    /* rkFDUpdate = zODE2Update (Runge-Kutta-Gill, 4 stage evaluations) + the committing
+     * evaluation at the new state (reference src/rkfd_sim.c:560-566).  All five evaluations
+     * run through ONE copy of rkfd_evaluate (stage loop) to keep the kernel inside the
+     * instruction cache.  mode 1 / 2: a single evaluation at the current state. */
     const double h = m.dt;
     const double s2 = sqrt( 2.0 );
     const double c21 = ( s2-1.0 )/2.0, c22 = ( 2.0-s2 )/2.0, c31 = -s2/2.0, c32 = 1.0+s2/2.0;
     const double w2 = 2.0-s2, w3 = 2.0+s2;
     const bool on = lane < ND;
-    for( int step=0; step<nsteps; step++ ){
-      double kv1, kv2, kv3, kv4, ka1, ka2, ka3, ka4, xv;
-      /* stage 1 */
-      if( on ){ L.q[lane] = q; L.qd[lane] = qd; }
-      SYNC();
-      kv1 = qd;
-      err |= rkfd_evaluate( m, L, false );
-      ka1 = on ? L.acc[lane] : 0.0;
-      SYNC();
-      /* stage 2 */
-      xv = qd + 0.5*h*ka1;
-      rkfd_cat_dis( m, L, q, 0.5*h, kv1 );
+    const int nst = mode == 0 ? 5 : 1;
+    const int ntot = mode == 0 ? nsteps*5 : 1;
+    double kv1 = 0, kv2 = 0, kv3 = 0, ka1 = 0, ka2 = 0, ka3 = 0, ka4 = 0, kv4 = 0;
+    int stage = 0;
+    for( int it=0; it<ntot; it++ ){
+      double k = 0, tv = 0, xv = qd;
+      if( mode == 0 ){
+        if( stage == 1 ){ k = 0.5*h; tv = kv1; xv = qd + 0.5*h*ka1; }
+        else if( stage == 2 ){ k = h; tv = c21*kv1 + c22*kv2; xv = qd + h*( c21*ka1 + c22*ka2 ); }
+        else if( stage == 3 ){ k = h; tv = c31*kv2 + c32*kv3; xv = qd + h*( c31*ka2 + c32*ka3 ); }
+        else if( stage == 4 ){
+          k = h/6.0; tv = kv1 + w2*kv2 + w3*kv3 + kv4;
+          xv = qd + h/6.0*( ka1 + w2*ka2 + w3*ka3 + ka4 );
+        }
+      }
+      if( stage == 0 ){
+        if( on ) L.q[lane] = q;
+        SYNC();
+      } else {
+        rkfd_cat_dis( m, L, q, k, tv );
+      }
       if( on ) L.qd[lane] = xv;
+      if( stage == 4 ){ q = on ? L.q[lane] : 0.0; qd = xv; }
       SYNC();
-      kv2 = xv;
-      err |= rkfd_evaluate( m, L, false );
-      ka2 = on ? L.acc[lane] : 0.0;
+      const bool doUp = mode == 0 ? stage == 4 : mode == 1;
+      err |= rkfd_evaluate( m, L, doUp );
+      const double a = on ? L.acc[lane] : 0.0;
+      if( stage == 0 ){ kv1 = xv; ka1 = a; }
+      else if( stage == 1 ){ kv2 = xv; ka2 = a; }
+      else if( stage == 2 ){ kv3 = xv; ka3 = a; }
+      else if( stage == 3 ){ kv4 = xv; ka4 = a; }
       SYNC();
-      /* stage 3 */
-      xv = qd + h*( c21*ka1 + c22*ka2 );
-      rkfd_cat_dis( m, L, q, h, c21*kv1 + c22*kv2 );
-      if( on ) L.qd[lane] = xv;
-      SYNC();
-      kv3 = xv;
-      err |= rkfd_evaluate( m, L, false );
-      ka3 = on ? L.acc[lane] : 0.0;
-      SYNC();
-      /* stage 4 */
-      xv = qd + h*( c31*ka2 + c32*ka3 );
-      rkfd_cat_dis( m, L, q, h, c31*kv2 + c32*kv3 );
-      if( on ) L.qd[lane] = xv;
-      SYNC();
-      kv4 = xv;
-      err |= rkfd_evaluate( m, L, false );
-      ka4 = on ? L.acc[lane] : 0.0;
-      SYNC();
-      /* combine */
-      rkfd_cat_dis( m, L, q, h/6.0, kv1 + w2*kv2 + w3*kv3 + kv4 );
-      q = on ? L.q[lane] : 0.0;
-      qd += h/6.0*( ka1 + w2*ka2 + w3*ka3 + ka4 );
-      if( on ) L.qd[lane] = qd;
-      SYNC();
-      /* committing evaluation at the new state (_rkFDUpdateRef) */
-      err |= rkfd_evaluate( m, L, true );
+      stage++; if( stage == nst ) stage = 0;
     }
   }
   /* store */

@@ -87,6 +87,33 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
     for( int k=0; k<3; k++ ) cv[3*j+k] = m->verts[3*m->cand_vert[j]+k];
   }
   const int nplane = m->nshape > 0 ? m->shape_foff[m->nshape] : 0;
+  if( m->nci > 255 ) FAIL( "too many contact infos" );
+  /* packed link / candidate info */
+  std::vector<int> linfo( NL ), cinfo( NC );
+  for( int i=0; i<NL; i++ )
+    linfo[i] = RKFD_LI_PACK( m->parent[i], m->jtype[i], depth[i], is_static[i], m->mtype[i], m->dofoff[i] );
+  for( int j=0; j<NC; j++ ){
+    if( cnf[j] > 255 ) FAIL( "a collision shape has more than 255 faces" );
+    cinfo[j] = cA[j] | ( cB[j] << 8 ) | ( cci[j] << 16 ) | ( cnf[j] << 24 );
+  }
+  /* sweep schedule: one iteration = up to 8 links of one level */
+  std::vector<int> sched;
+  int nsched = 0;
+  for( int d=0; d<nlevel; d++ )
+    for( int base=level_off[d]; base<level_off[d+1]; base+=8 ){
+      for( int g=0; g<8; g++ ){
+        int rec[8] = { -1, 0, 0, -1, -1, -1, -1, 0 };
+        if( base+g < level_off[d+1] ){
+          const int i = level_link[base+g];
+          rec[0] = i; rec[1] = linfo[i];
+          rec[2] = child_off[i+1] - child_off[i];
+          for( int k=0; k<4 && k<rec[2]; k++ ) rec[3+k] = child_idx[child_off[i]+k];
+          rec[7] = child_off[i];
+        }
+        sched.insert( sched.end(), rec, rec+8 );
+      }
+      nsched++;
+    }
 
   Blob b;
   rkfdDevModel dm;
@@ -94,6 +121,8 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   dm.nlink = NL; dm.ndof = ND; dm.ncand = NC; dm.nlevel = nlevel; dm.nround = nround; dm.nci = m->nci;
   dm.solver = m->solver; dm.max_iter = m->max_iter; dm.maxrg = max_rigid;
   dm.dt = m->dt; dm.fric_w = m->friction_weight;
+  dm.nsched = nsched;
+  if( nround > RKFD_MAX_ROUND ) FAIL( "tree too deep" );
   /* record offsets first (the vector may reallocate), then resolve */
   struct Ent { const void **slot; size_t off; };
   std::vector<Ent> ents;
@@ -112,6 +141,8 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   PUT( level_off, level_off.data(), sizeof(int)*( nlevel+1 ) ); PUT( level_link, level_link.data(), sizeof(int)*NL );
   PUT( child_off, child_off.data(), sizeof(int)*( NL+1 ) ); PUT( child_idx, child_idx.data(), sizeof(int)*NL );
   PUT( pathlink, pathlink.data(), sizeof(int)*pathlink.size() );
+  PUT( linfo, linfo.data(), sizeof(int)*NL ); PUT( cinfo, cinfo.data(), sizeof(int)*NC );
+  PUT( sched, sched.data(), sizeof(int)*sched.size() );
   PUT( cand_linkA, cA.data(), sizeof(int)*NC ); PUT( cand_linkB, cB.data(), sizeof(int)*NC );
   PUT( cand_foff, cfo.data(), sizeof(int)*NC ); PUT( cand_nf, cnf.data(), sizeof(int)*NC );
   PUT( cand_ci, cci.data(), sizeof(int)*NC ); PUT( cand_vert, cv.data(), sizeof(double)*3*NC );
@@ -131,7 +162,8 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   {
     const size_t M = 3*(size_t)max_rigid;
     const size_t dbl = (size_t)4*ND + (size_t)NL*100 + (size_t)NC*24 + M*(M+1) + 2*M + 2*(size_t)nlevel*M + 2*(size_t)NL;
-    const size_t ints = (size_t)5*NC + 8 + (size_t)ND + (size_t)NL;
+    const size_t ints = (size_t)5*NC + 8 + (size_t)ND + (size_t)NL      /* act typ lrg lel tgt, cnt, dofkind, pivt */
+                      + (size_t)NL + 2*(size_t)NC + ( max_rigid > 0 ? (size_t)NL*nlevel : 0 ); /* LI, CIp, CFO, PL */
     out->lds_bytes = dbl*sizeof(double) + ints*sizeof(int);
     out->lds_bytes = ( out->lds_bytes + 15 ) & ~(size_t)15;
   }
@@ -151,7 +183,7 @@ extern "C" void rkfd_devmodel_rebase(rkfdDevModel *dm, const void *from, const v
   RB(parent); RB(jtype); RB(dofoff); RB(mtype); RB(depth); RB(is_static);
   RB(org); RB(mass); RB(com); RB(inertia); RB(stiff); RB(visc); RB(coulomb); RB(sfric);
   RB(mot_k); RB(mot_admit); RB(mot_vmax); RB(mot_vmin); RB(mot_gear); RB(mot_inertia);
-  RB(anc); RB(level_off); RB(level_link); RB(child_off); RB(child_idx); RB(pathlink);
+  RB(anc); RB(level_off); RB(level_link); RB(child_off); RB(child_idx); RB(pathlink); RB(linfo); RB(sched); RB(cinfo);
   RB(cand_linkA); RB(cand_linkB); RB(cand_foff); RB(cand_nf); RB(cand_ci); RB(cand_vert); RB(planes);
   RB(ci_type); RB(ci_sf); RB(ci_kf); RB(ci_k); RB(ci_l); RB(ci_e); RB(ci_v);
 #undef RB

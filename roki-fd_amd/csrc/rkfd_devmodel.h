@@ -32,14 +32,35 @@ typedef struct {
   const int *child_off;  /* [nlink+1]                                                    */
   const int *child_idx;  /* [nlink-#roots]                                               */
   const int *pathlink;   /* [nlink][nlevel]: ancestor of link at depth d (d<=depth)      */
+  /* packed per-link ints (copied to LDS): see RKFD_LI_* */
+  const int *linfo;      /* [nlink]                                                      */
+  /* sweep schedule: nsched iterations x 8 lane groups x 8 ints
+   *   {link (-1 none), linfo[link], nchild, child0..child3, child_off[link]}            */
+  int nsched;
+  const int *sched;
   /* per candidate contact vertex */
   const int *cand_linkA, *cand_linkB, *cand_foff, *cand_nf, *cand_ci;
   const double *cand_vert; /* [ncand*3] vertex in link A's frame                         */
+  const int *cinfo;        /* [ncand] packed: linkA | linkB<<8 | ci<<16 | nf<<24              */
   const double *planes;    /* [nplane*4] in link B's frame                               */
   /* contact infos */
   const int *ci_type;
   const double *ci_sf, *ci_kf, *ci_k, *ci_l, *ci_e, *ci_v;
 } rkfdDevModel;
+
+#define RKFD_LI_PACK(par,jt,depth,stat,mt,off) \
+  ( ((par)+1) | ((jt)<<8) | ((depth)<<11) | ((stat)<<18) | ((mt)<<19) | ((off)<<21) )
+#define RKFD_LI_PAR(x)    ( ( (x) & 0xFF ) - 1 )
+#define RKFD_LI_JT(x)     ( ( (x) >> 8 ) & 7 )
+#define RKFD_LI_DEPTH(x)  ( ( (x) >> 11 ) & 0x7F )
+#define RKFD_LI_STATIC(x) ( ( (x) >> 18 ) & 1 )
+#define RKFD_LI_MT(x)     ( ( (x) >> 19 ) & 3 )
+#define RKFD_LI_OFF(x)    ( ( (x) >> 21 ) & 0xFF )
+#define RKFD_CI_A(x)      ( (x) & 0xFF )
+#define RKFD_CI_B(x)      ( ( (x) >> 8 ) & 0xFF )
+#define RKFD_CI_CI(x)     ( ( (x) >> 16 ) & 0xFF )
+#define RKFD_CI_NF(x)     ( ( (x) >> 24 ) & 0xFF )
+#define RKFD_MAX_ROUND 6
 
 /* per-batch state arrays, instance-major: x[b*stride + j] */
 typedef struct {

@@ -1,0 +1,209 @@
+"""Known-answer tests pinning the CPU oracle (the reference ships none: SURVEY.md 8c).
+Independent mechanics: tests/refmath.py (classical Newton-Euler inverse dynamics)."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+import refmath as rm
+
+G = 9.80665
+
+
+def _world(R, files, ci=None, solver=None, **kw):
+    w = R.World(solver=R.SOLVER_MLCP if solver is None else solver, **kw)
+    if ci:
+        w.contact_info(os.path.join(R.scenarios.MODELS, ci))
+    ids = [w.reg_file(f if os.path.isabs(f) else os.path.join(R.scenarios.MODELS, f)) for f in files]
+    return w, ids
+
+
+def test_free_fall_box(R, oracle_cls):
+    """(1) float box in free fall: qdd = (0,0,-g,0,0,0) whatever the attitude / spin-free velocity"""
+    w, _ = _world(R, ["box.ztk", "floor.ztk"], "contactinfo.ztk")
+    o = oracle_cls(w.model)
+    dis = np.array([0.3, -0.2, 1.0, 0.3, -0.2, 0.5]); vel = np.array([0.1, 0.2, 0.3, 0, 0, 0])
+    o.set_state(dis, vel); o.update_init()
+    acc = o.get_state()[2]
+    assert np.allclose(acc, [0, 0, -G, 0, 0, 0], atol=1e-12)
+
+
+def test_aba_vs_newton_euler_chain30(R, oracle_cls):
+    """(2) joint accelerations of the articulated-body sweeps satisfy the independent inverse dynamics"""
+    sc = R.scenarios.config2(batch=4)
+    md = rm.model_arrays(sc["world"].model.contents)
+    o = oracle_cls(sc["world"].model)
+    for b in range(4):
+        o.set_state(sc["dis"][b], sc["vel"][b]); assert o.eval(False) == 0
+        qdd = o.get_state()[2]
+        tau = rm.rnea(md, sc["dis"][b], sc["vel"][b], qdd)
+        assert np.abs(tau).max() < 1e-10 * max(1.0, np.abs(qdd).max())
+
+
+@pytest.fixture(scope="module")
+def humanoid_nomotor(R):
+    txt = open(os.path.join(R.scenarios.MODELS, "humanoid30.ztk")).read()
+    txt = "\n".join(l for l in txt.splitlines() if not l.strip().startswith("motor:"))
+    d = tempfile.mkdtemp()
+    p = os.path.join(d, "h30_nomotor.ztk")
+    open(p, "w").write(txt)
+    return p
+
+
+def test_aba_vs_newton_euler_float_humanoid(R, oracle_cls, humanoid_nomotor):
+    """(2) same on the 30-DoF floating-base tree (float joint bias terms, branches)"""
+    w, _ = _world(R, [humanoid_nomotor], solver=R.SOLVER_VERT)
+    md = rm.model_arrays(w.model.contents)
+    o = oracle_cls(w.model)
+    rng = np.random.default_rng(7)
+    for _ in range(4):
+        q = rng.uniform(-1, 1, 30); qd = rng.uniform(-2, 2, 30)
+        o.set_state(q, qd); assert o.eval(False) == 0
+        qdd = o.get_state()[2]
+        assert np.abs(rm.rnea(md, q, qd, qdd)).max() < 1e-10 * max(1.0, np.abs(qdd).max())
+
+
+def test_probed_matrix_is_J_Minv_JT(R, oracle_cls, humanoid_nomotor):
+    """(3) the column-by-column probed contact matrix equals J M^-1 J' + L, symmetric PSD"""
+    w, (h, f) = _world(R, [humanoid_nomotor, "floor.ztk"], "contact_rigid.ztk")
+    m = w.model.contents
+    md = rm.model_arrays(m)
+    o = oracle_cls(w.model)
+    q = np.zeros(30); q[2] = 0.3667 - 0.002   # soles 2 mm into the floor
+    o.set_state(q, np.zeros(30)); assert o.eval(False) == 0
+    nc, a, b, fv = o.mlcp()
+    assert nc >= 4
+    assert np.abs(a - a.T).max() < 1e-9 * np.abs(a).max()
+    act, typ, ref, fw = o.get_contact()
+    Rw, pw = o.link_frames()
+    # rebuild J' columns with the independent inverse dynamics
+    cand_pair = m.arr("cand_pair", m.ncand); cand_side = m.arr("cand_side", m.ncand); cand_vert = m.arr("cand_vert", m.ncand)
+    pair_shape = m.arr("pair_shape", 2 * m.npair).reshape(-1, 2); shape_link = m.arr("shape_link", m.nshape)
+    verts = m.arr("verts", 3 * (m.arr("shape_voff", m.nshape + 1)[-1])).reshape(-1, 3)
+    M = rm.mass_matrix(md, q)
+    cols = []
+    for j in np.nonzero(act)[0]:
+        la = shape_link[pair_shape[cand_pair[j], cand_side[j]]]
+        x = pw[la] + Rw[la] @ verts[cand_vert[j]]
+        n = np.array([0, 0, 1.0]); t1 = np.array([1.0, 0, 0]); t2 = np.array([0, 1.0, 0])
+        cols.append(rm.point_jacobian_T(md, q, la, x, [n, t1, t2]))
+    JT = np.concatenate(cols, axis=1)
+    a_ref = JT.T @ np.linalg.solve(M, JT) + 1e-4 * np.eye(3 * nc)
+    assert np.abs(a - a_ref).max() < 1e-8 * np.abs(a_ref).max()
+    assert np.linalg.eigvalsh((a + a.T) / 2).min() > 0
+
+
+def test_box_rests_on_rigid_floor(R, oracle_cls):
+    """(4) box on the rigid floor (K=1000, L=1e-4): it neither sinks nor bounces away, all four
+    bottom vertices stay in contact, the normal force of the committing evaluation stays of the
+    order of m g (0.5..2 m g) and there is no net tangential force.  (The velocity-level LCP with
+    relaxation, re-solved at every Runge-Kutta stage, settles into a micrometre-scale 4-step limit
+    cycle; the committing evaluation samples it, so equality with m g is not expected.)"""
+    w, _ = _world(R, ["box.ztk", "floor.ztk"], "contactinfo.ztk")
+    o = oracle_cls(w.model)
+    o.set_state(np.array([0, 0, 0.0499, 0, 0, 0.0]), np.zeros(6)); o.update_init()
+    fz = []
+    for k in range(1500):
+        assert o.update() == 0
+        if k >= 1000:
+            fz.append(o.get_contact()[3][:, 2].sum())
+    act, typ, ref, f = o.get_contact()
+    dis, vel, _ = o.get_state()
+    assert act.sum() == 4
+    assert 0.5 * 0.5 * G < min(fz) and max(fz) < 2.0 * 0.5 * G
+    assert np.abs(f[:, :2].sum(0)).max() < 1e-6
+    assert abs(dis[2] - 0.05) < 1e-5 and np.abs(vel).max() < 5e-3
+
+
+def test_pgs_fixed_iteration_iterate(R, oracle_cls):
+    """(5) the MLCP force is the 10-sweep projected Gauss-Seidel iterate (not the fixed point):
+    re-run the reference's loop (reference src/rkfd_mlcp.c:190-249) in Python on the oracle's a, b"""
+    sc = R.scenarios.config4(batch=1)
+    o = oracle_cls(sc["world"].model)
+    m = sc["world"].model.contents
+    o.set_state(sc["dis"][0], sc["vel"][0])
+    o.eval(False)                      # creates the contacts (all sticking)
+    act0, typ0, ref0, _ = o.get_contact()
+    o.eval(False)
+    nc, a, b, f = o.mlcp()
+    mu = [0.5 if t == 0 else 0.3 for t in typ0[act0 > 0]]
+    TOL = 1e-12
+    x = np.zeros(3 * nc)
+    for _ in range(m.max_iter):
+        for c in range(nc):
+            k = 3 * c
+            ff = -(b[k] + a[k] @ x - a[k, k] * x[k]) / a[k, k]
+            x[k] = 0.0 if ff < TOL else ff
+        for c in range(nc):
+            k = 3 * c
+            ff = [0.0 if abs(a[k + i, k + i]) < TOL else -(b[k + i] + a[k + i] @ x - a[k + i, k + i] * x[k + i]) / a[k + i, k + i] for i in (1, 2)]
+            fn = ff[0] ** 2 + ff[1] ** 2; fs = (mu[c] * x[k]) ** 2
+            if fn < TOL or fs < TOL:
+                x[k + 1] = x[k + 2] = 0.0
+            elif fn > fs:
+                x[k + 1], x[k + 2] = ff[0] * fs / fn, ff[1] * fs / fn
+            else:
+                x[k + 1], x[k + 2] = ff
+    assert np.allclose(x / m.dt, f, rtol=1e-12, atol=1e-12 * np.abs(f).max())
+
+
+def test_penalty_single_vertex(R, oracle_cls):
+    """(6) penalty force of one vertex, hand-computed: f = -E d - (V + E dt) v_rel (reference
+    src/rkfd_penalty.c:23-24) with E=100, V=1, dt=1e-3 ('soft body', contactinfo.ztk)"""
+    sc = R.scenarios.config1(batch=1)
+    o = oracle_cls(sc["world"].model)
+    dis = np.array([0, -1.0, 0.05 - 0.004, 0, 0, 0]); vel = np.array([0.0, 0, -0.2, 0, 0, 0])
+    o.set_state(dis, vel); o.eval(False)
+    act, typ, ref, f = o.get_contact()
+    idx = np.nonzero(act)[0]
+    assert len(idx) == 4
+    E, V, dt = 100.0, 1.0, 1e-3
+    expect = -E * (-0.004) - (V + E * dt) * (-0.2)
+    assert np.allclose(f[idx, 2], expect, rtol=1e-12)
+    assert np.allclose(f[idx, :2], 0, atol=1e-14)
+    # leaving contact fast enough flips the sign of the force: no adhesion (the vertex is skipped)
+    o2 = oracle_cls(sc["world"].model)
+    o2.set_state(dis, np.array([0.0, 0, 1.0, 0, 0, 0])); o2.eval(False)
+    assert np.abs(o2.get_contact()[3]).max() == 0.0
+
+
+def test_rkg_is_fourth_order(R, oracle_cls):
+    """(7) frictionless pendulum (first link of chain30 moving, others locked by symmetry is not
+    possible) -> use the 2-step error ratio on the full chain: halving dt divides the error by ~16"""
+    errs = []
+    sc = R.scenarios.config2(batch=1)
+    q0, v0 = sc["dis"][0] * 0.3, sc["vel"][0] * 0.3
+
+    def run(dt, n):
+        w = R.World(solver=R.SOLVER_VERT, dt=dt)
+        w.reg_file(os.path.join(R.scenarios.MODELS, "chain30.ztk"))
+        o = oracle_cls(w.model)
+        o.set_state(q0, v0); o.update_init()
+        for _ in range(n):
+            o.update()
+        return o.get_state()[0]
+    ref = run(1.25e-4, 160)
+    for dt, n in ((2e-3, 10), (1e-3, 20)):
+        errs.append(np.abs(run(dt, n) - ref).max())
+    assert 10.0 < errs[0] / errs[1] < 24.0
+
+
+def test_dc_motor_friction_truth_table(R, oracle_cls):
+    """(8) joint friction of a DC-motor joint (reference src/rkfd_util.c:330-364): at rest with zero
+    input the static friction holds the arm against gravity (|needed| < staticfriction) and the
+    pivot stays SF; a large input voltage breaks away and the committing evaluation flips it to KF"""
+    w, (h, f) = _world(R, ["humanoid30.ztk", "floor.ztk"], "contact_elastic.ztk", solver=R.SOLVER_VERT)
+    o = oracle_cls(w.model)
+    dis = np.zeros(30); dis[:6] = w.init_dis(h)[:6]; dis[2] = 1.0   # in the air
+    o.set_state(dis, np.zeros(30)); o.update_init()
+    typ, prev = o.get_pivot()
+    m = w.model.contents
+    jt = m.arr("jtype", m.nlink)
+    assert (typ[jt == 1] == 0).all()
+    acc = o.get_state()[2]
+    assert np.abs(acc[6:]).max() < 1e-9        # every joint sticks
+    inp = np.zeros(m.nlink); inp[1] = 24.0
+    o.set_motor_input(inp); o.eval(True)
+    typ2, _ = o.get_pivot()
+    assert typ2[1] == 1 and abs(o.get_state()[2][6]) > 1.0
