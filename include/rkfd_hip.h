@@ -68,6 +68,11 @@ int rkfdBatchEval(rkfdBatch *b, int doUpRef, void *stream);
  * 2 rigid-contact capacity exceeded; negative: HIP error */
 int rkfdBatchStatus(rkfdBatch *b, void *stream);
 
+/* diagnostic launch: nsteps x rkFDUpdate with in-kernel phase stamps.  out is [batch][8]
+ * shader-clock cycles: kinematics, collision+penalty, sweep 2, sweep 3, MLCP, tail, -, whole launch.
+ * Synchronous; not for timing runs (the stamps serialise the phases). */
+int rkfdBatchProfile(rkfdBatch *b, int nsteps, unsigned long long *out);
+
 /* device pointers to the live state ([batch][ndof] doubles), for zero-copy consumers
  * (e.g. an RCCL all-gather of final states) */
 double *rkfdBatchDevDis(rkfdBatch *b);

@@ -90,6 +90,7 @@ def lib():
     L.rkfdBatchUpdate.argtypes = [vp, C.c_int, vp]
     L.rkfdBatchEval.argtypes = [vp, C.c_int, vp]
     L.rkfdBatchStatus.argtypes = [vp, vp]
+    L.rkfdBatchProfile.argtypes = [vp, C.c_int, vp]
     for f in ("rkfdBatchDevDis", "rkfdBatchDevVel", "rkfdBatchDevAcc"):
         getattr(L, f).argtypes = [vp]
         getattr(L, f).restype = vp
@@ -237,6 +238,12 @@ class Batch:
         if r < 0:
             raise RkfdError(self._L.rkfdHipLastError().decode())
         return r
+
+    def profile(self, nsteps=1):
+        """diagnostic launch with in-kernel phase stamps: [B, 8] cycles"""
+        out = np.zeros((self.B, 16), dtype=np.uint64)
+        self._chk(self._L.rkfdBatchProfile(self._b, nsteps, _ptr(out)))
+        return out
 
     @property
     def lds_bytes(self):

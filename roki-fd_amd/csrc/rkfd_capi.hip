@@ -92,7 +92,7 @@ extern "C" rkfdBatch *rkfdBatchCreate(const rkfdModel *m, int batch, int device,
   bad |= dalloc( &b->st.cv_active, B*NC ); bad |= dalloc( &b->st.cv_type, B*NC );
   bad |= dalloc( &b->st.cv_ref, B*NC*3 ); bad |= dalloc( &b->st.cv_f, B*NC*3 );
   bad |= dalloc( &b->d_err, 1 );
-  b->st.dbg = NULL; b->st.dbg_stride = 0; b->st.batch = batch;
+  b->st.dbg = NULL; b->st.dbg_stride = 0; b->st.batch = batch; b->st.prof = NULL;
   if( bad ){ rkfdBatchDestroy( b ); return NULL; }
   if( b->lds_bytes > 64*1024 ){
     hipError_t e = hipFuncSetAttribute( (const void *)rkfd_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes );
@@ -196,6 +196,27 @@ extern "C" int rkfdBatchUpdate(rkfdBatch *b, int nsteps, void *stream)
   return launch( b, 0, nsteps, stream );
 }
 extern "C" int rkfdBatchEval(rkfdBatch *b, int doUpRef, void *stream){ return launch( b, doUpRef ? 1 : 2, 0, stream ); }
+
+/* diagnostic: nsteps x rkFDUpdate with in-kernel phase stamps; out[batch][8] shader-clock cycles of
+ * {kinematics, collision+penalty, sweep 2, sweep 3, MLCP, tail, unused, whole launch}.  Synchronous. */
+extern "C" int rkfdBatchProfile(rkfdBatch *b, int nsteps, unsigned long long *out)
+{
+  if( !b || !out ){ SETERR( "rkfdBatchProfile: bad arguments" ); return -1; }
+  HIPCHK( hipSetDevice( b->device ), -1 );
+  unsigned long long *d = NULL;
+  const size_t n = sizeof(unsigned long long)*(size_t)b->batch*RKFD_NPROF;
+  HIPCHK( hipMalloc( (void **)&d, n ), -1 );
+  HIPCHK( hipMemset( d, 0, n ), -1 );
+  b->st.prof = d;
+  int r = launch( b, 0, nsteps, NULL );
+  b->st.prof = NULL;
+  if( r == 0 ){
+    hipError_t e = hipMemcpy( out, d, n, hipMemcpyDeviceToHost );
+    if( e != hipSuccess ){ SETERR( "hipMemcpy failed: %s", hipGetErrorString( e ) ); r = -1; }
+  }
+  (void)hipFree( d );
+  return r;
+}
 
 extern "C" int rkfdBatchStatus(rkfdBatch *b, void *stream)
 {

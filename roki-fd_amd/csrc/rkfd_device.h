@@ -35,13 +35,21 @@
    unsigned long long rkfd_emu_ballot(int pred);
 #  define LANE()        rkfd_emu_lane()
 #  define SYNC()        rkfd_emu_sync()
+   double rkfd_emu_g8bcast(double x, int k);
 #  define G8SUM(x)      rkfd_emu_g8sum(x)
+#  define G8BCAST(x,k)  rkfd_emu_g8bcast(x,k)
+#  define RKFD_RCP(x)   ( 1.0/(x) )
+#  define LDS_FENCE()   rkfd_emu_sync()
 #  define BCAST(x,l)    rkfd_emu_bcast(x,l)
 #  define BALLOT(p)     rkfd_emu_ballot(p)
 #else
 #  define RKFD_DEV __device__ __forceinline__
 #  define LANE()        ((int)threadIdx.x)
-#  define SYNC()        __syncthreads()
+/* One workgroup is one wavefront: lanes exchange data through LDS in program order, so a
+ * "barrier" only has to (a) stop the compiler from moving LDS accesses across it and (b) wait
+ * for the wave's own outstanding LDS operations.  __syncthreads() would also drain vmcnt (the
+ * schedule-record prefetches), which is exactly the latency the prefetch is meant to hide. */
+#  define SYNC()        asm volatile( "s_waitcnt lgkmcnt(0)" ::: "memory" )
 RKFD_DEV double rkfd_dpp_xor1(double x)
 {
   int lo = __double2loint( x ), hi = __double2hiint( x );
@@ -78,12 +86,40 @@ RKFD_DEV double rkfd_bcast(double x, int src)
   int hi = __builtin_amdgcn_readlane( __double2hiint( x ), src );
   return __hiloint2double( hi, lo );
 }
+/* broadcast lane k (compile-time 0..7) of every aligned 8-lane group to the whole group:
+ * ds_swizzle in bit mode, lane' = ( lane & 0x18 ) | k within each half-wave; no LDS storage */
+template<int K> RKFD_DEV double rkfd_g8bcast(double x)
+{
+  int lo = __builtin_amdgcn_ds_swizzle( __double2loint( x ), ( K << 5 ) | 0x18 );
+  int hi = __builtin_amdgcn_ds_swizzle( __double2hiint( x ), ( K << 5 ) | 0x18 );
+  return __hiloint2double( hi, lo );
+}
+/* reciprocal: v_rcp_f64 + two Newton steps (relative error ~1e-16) instead of the IEEE division sequence */
+RKFD_DEV double rkfd_rcp(double x)
+{
+  double r = __builtin_amdgcn_rcp( x );
+  r = fma( r, fma( -x, r, 1.0 ), r );
+  r = fma( r, fma( -x, r, 1.0 ), r );
+  return r;
+}
 #  define G8SUM(x)      rkfd_g8sum(x)
+#  define G8BCAST(x,k)  rkfd_g8bcast<k>(x)
+#  define RKFD_RCP(x)   rkfd_rcp(x)
+/* compiler-only fence: LDS operations of one wavefront execute in program order */
+#  define LDS_FENCE()   asm volatile( "" ::: "memory" )
 #  define BCAST(x,l)    rkfd_bcast(x,l)
 #  define BALLOT(p)     __ballot(p)
 #endif
 
 #define RKFD_DEV_TOL RKFD_TOL
+
+/* optional in-kernel phase timing (diagnostic launches only: rkfdBatchProfile) */
+#define RKFD_NPROF 16
+#ifdef RKFD_EMU
+#  define RKFD_CLOCK() 0ull
+#else
+#  define RKFD_CLOCK() ( (unsigned long long)__builtin_amdgcn_s_memtime() )
+#endif
 
 /* ------------------------------------------------------------------------ */
 /* 3-vector helpers on plain arrays */
@@ -186,6 +222,7 @@ typedef struct {
   int *act, *typ, *lrg, *lel, *tgt, *cnt, *dofkind, *pivt;
   int *LI;                        /* [NL] packed link info (RKFD_LI_*)                    */
   int *CIp, *CFO;                 /* [NC] packed candidate info, first plane              */
+  int *CHI;                       /* [NL] children lists (CSR values; offsets in the schedule)     */
   int *PL;                        /* [NL*nlevel] ancestor at depth d (MLCP only)          */
   double *pivp, *min;             /* [NL] pivot prev torque, motor input                  */
 } rkfdLds;
@@ -211,7 +248,7 @@ RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int
   int *ip = (int *)d;
   L->act = ip; ip += NC; L->typ = ip; ip += NC; L->lrg = ip; ip += NC; L->lel = ip; ip += NC;
   L->tgt = ip; ip += NC; L->cnt = ip; ip += 8; L->dofkind = ip; ip += ND; L->pivt = ip; ip += NL;
-  L->LI = ip; ip += NL; L->CIp = ip; ip += NC; L->CFO = ip; ip += NC;
+  L->LI = ip; ip += NL; L->CIp = ip; ip += NC; L->CFO = ip; ip += NC; L->CHI = ip; ip += NL;
   L->PL = ip;
 }
 
@@ -487,83 +524,121 @@ RKFD_DEV void d_chol6_solve(const double *Lm, const double *b, double *x)
 
 /* ------------------------------------------------------------------------ */
 /* one schedule record: what one 8-lane group does in one sweep iteration */
-typedef struct { int i, li, nchild, c0, c1, c2, c3, coff; } rkfdRec;
+typedef struct { int i, li, nchild, flags, c0, c1, c2, c3, coff; } rkfdRec;
 RKFD_DEV rkfdRec rkfd_rec_load(const rkfdDevModel &m, int t, int g)
 {
   rkfdRec r;
-  if( t < 0 || t >= m.nsched ){ r.i = -1; r.li = 0; r.nchild = 0; r.c0 = r.c1 = r.c2 = r.c3 = -1; r.coff = 0; return r; }
+  if( t < 0 || t >= m.nsched ){ r.i = -1; r.li = 0; r.nchild = 0; r.flags = 0; r.c0 = r.c1 = r.c2 = r.c3 = -1; r.coff = 0; return r; }
   const int *p = m.sched + ( (size_t)t*8 + g )*8;
-  r.i = p[0]; r.li = p[1]; r.nchild = p[2]; r.c0 = p[3]; r.c1 = p[4]; r.c2 = p[5]; r.c3 = p[6]; r.coff = p[7];
+  r.i = p[0]; r.li = p[1]; r.nchild = p[2] & 0xFF; r.flags = p[2] >> 8;
+  r.c0 = p[3]; r.c1 = p[4]; r.c2 = p[5]; r.c3 = p[6]; r.coff = p[7];
   return r;
 }
 
-/* ABA sweep 2 (leaf to root), level-synchronous; 8 lanes per link, lane r = row r.
+/* per-lane operands of one sweep-2 iteration, fetched from LDS one iteration ahead */
+typedef struct { double row[6], S[6], c[6], S_r, pb, tau, jm, U_r, Dinv; } rkfdPre2;
+RKFD_DEV void rkfd_pre2_load(const rkfdLds &L, int i, int rr, bool full, rkfdPre2 &p)
+{
+#pragma unroll
+  for( int k=0; k<6; k++ ){ p.row[k] = L.IA[36*i+6*rr+k]; p.S[k] = L.S[6*i+k]; p.c[k] = L.C[6*i+k]; }
+  p.S_r = L.S[6*i+rr];
+  p.pb = L.PB[6*i+rr] - L.FE[6*i+rr];
+  p.tau = L.MS[4*i+2]; p.jm = L.MS[4*i+3];
+  p.U_r = full ? 0.0 : L.U[6*i+rr];
+  p.Dinv = full ? 0.0 : L.MS[4*i+0];
+}
+
+/* ABA sweep 2 (leaf to root), level-synchronous; 8 lanes per link, lane r = row r of the 6x6.
  * full = true : articulated inertia + bias (rkChainUpdateABI, backward part)
  * full = false: bias only, reusing Ia, U, Dinv (rkChainUpdateCachedABI, backward part).
- * The per-iteration work list comes from the model's schedule (prefetched one iteration
- * ahead); collectives (G8SUM, SYNC) are issued from wave-uniform control flow only. */
-RKFD_DEV void rkfd_phase_sweep2(const rkfdDevModel &m, const rkfdLds &L, bool full)
+ * Software-pipelined: schedule records are fetched two iterations ahead, the link's own LDS
+ * operands one iteration ahead, and along chains the child's (Ia row, pa) stay in registers
+ * (schedule flag bit 0), so the dependent path of an iteration is ALU + DPP + one swizzle. */
+RKFD_DEV void rkfd_phase_sweep2(const rkfdDevModel &m, const rkfdLds &L, bool full, bool prof, unsigned long long *pc)
 {
   const int lane = LANE();
   const int g = lane >> 3, r = lane & 7;
   const int rr = r < 6 ? r : 0;
-  rkfdRec nxt = rkfd_rec_load( m, m.nsched-1, g );
-  for( int t=m.nsched-1; t>=0; t-- ){
-    const rkfdRec rec = nxt;
-    nxt = rkfd_rec_load( m, t-1, g );
+  const int T = m.nsched;
+  rkfdRec rec1 = rkfd_rec_load( m, T-1, g ), rec2 = rkfd_rec_load( m, T-2, g );
+  rkfdPre2 pre1;
+  rkfd_pre2_load( L, rec1.i >= 0 ? rec1.i : 0, rr, full, pre1 );
+  double crow[6] = {0,0,0,0,0,0}, cpa = 0;
+  for( int t=T-1; t>=0; t-- ){
+    unsigned long long q0 = 0, q1;
+#define QST(k) do{ if( prof ){ q1 = RKFD_CLOCK(); pc[k] += q1 - q0; q0 = q1; } }while(0)
+    if( prof ) q0 = RKFD_CLOCK();
+    const rkfdRec rec = rec1;
+    const rkfdPre2 pre = pre1;
+    rec1 = rec2;
+    rec2 = rkfd_rec_load( m, t-2, g );
+    rkfd_pre2_load( L, rec1.i >= 0 ? rec1.i : 0, rr, full, pre1 );
+    QST(8);
     const bool onl = rec.i >= 0;
     const bool on = onl && r < 6;
     const int i = onl ? rec.i : 0;
     const int jt = onl ? RKFD_LI_JT( rec.li ) : RKFD_JOINT_FIXED;
     const bool is1 = jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM;
     const bool isf = jt == RKFD_JOINT_FLOAT;
-    double row[6], c[6], S[6], U_r = 0, Dinv = 0;
-    /* gather own + children */
-    double pr = L.PB[6*i+rr] - L.FE[6*i+rr];
+    double row[6], pr = pre.pb;
 #pragma unroll
-    for( int k=0; k<6; k++ ){ row[k] = L.IA[36*i+6*rr+k]; S[k] = L.S[6*i+k]; c[k] = L.C[6*i+k]; }
-    for( int cc=0; cc<rec.nchild; cc++ ){
-      const int ch = cc == 0 ? rec.c0 : ( cc == 1 ? rec.c1 : ( cc == 2 ? rec.c2 : ( cc == 3 ? rec.c3 : m.child_idx[rec.coff+cc] ) ) );
-      pr += L.PA[6*ch+rr];
-      if( full && RKFD_LI_JT( L.LI[ch] ) != RKFD_JOINT_FLOAT ){
+    for( int k=0; k<6; k++ ) row[k] = pre.row[k];
+    LDS_FENCE();   /* the children's write-backs of the previous iteration precede the gathers below */
+    if( rec.flags & 1 ){
+      pr += cpa;
+      if( full ){
 #pragma unroll
-        for( int k=0; k<6; k++ ) row[k] += L.IA[36*ch+6*rr+k];
+        for( int k=0; k<6; k++ ) row[k] += crow[k];
+      }
+    } else {
+      for( int cc=0; cc<rec.nchild; cc++ ){
+        const int ch = L.CHI[rec.coff+cc];
+        pr += L.PA[6*ch+rr];
+        if( full && RKFD_LI_JT( L.LI[ch] ) != RKFD_JOINT_FLOAT ){
+#pragma unroll
+          for( int k=0; k<6; k++ ) row[k] += L.IA[36*ch+6*rr+k];
+        }
       }
     }
-    const double S_r = S[rr];
+    QST(9);
+    const double S_r = pre.S_r;
+    double U_r, Dinv;
     if( full ){
-#pragma unroll
-      for( int k=0; k<6; k++ ) U_r += row[k]*S[k];
-      const double D = G8SUM( ( on && is1 ) ? S_r*U_r : 0.0 ) + L.MS[4*i+3];
-      Dinv = 1.0/D;
+      double u0 = row[0]*pre.S[0], u1 = row[1]*pre.S[1];
+      u0 = fma( row[2], pre.S[2], u0 ); u1 = fma( row[3], pre.S[3], u1 );
+      u0 = fma( row[4], pre.S[4], u0 ); u1 = fma( row[5], pre.S[5], u1 );
+      U_r = u0 + u1;
+      const double D = G8SUM( ( on && is1 ) ? S_r*U_r : 0.0 ) + pre.jm;
+      Dinv = RKFD_RCP( D );
     } else {
-      U_r = L.U[6*i+rr];
-      Dinv = L.MS[4*i+0];
+      U_r = pre.U_r; Dinv = pre.Dinv;
     }
-    const double u = L.MS[4*i+2] - G8SUM( ( on && is1 ) ? S_r*pr : 0.0 );
-    /* exchange U through LDS: every row needs every U[c] */
-    SYNC();
-    if( full && on && is1 ) L.U[6*i+rr] = U_r;
-    SYNC();
+    const double u = pre.tau - G8SUM( ( on && is1 ) ? S_r*pr : 0.0 );
+    QST(10);
+    if( full ){
+      /* rank-1 downdate Ia = IA - U U'/D: every row needs every U[k] */
+      const double tt = is1 ? U_r*Dinv : 0.0;
+      const double b0 = G8BCAST( U_r, 0 ), b1 = G8BCAST( U_r, 1 ), b2 = G8BCAST( U_r, 2 );
+      const double b3 = G8BCAST( U_r, 3 ), b4 = G8BCAST( U_r, 4 ), b5 = G8BCAST( U_r, 5 );
+      row[0] = fma( -tt, b0, row[0] ); row[1] = fma( -tt, b1, row[1] ); row[2] = fma( -tt, b2, row[2] );
+      row[3] = fma( -tt, b3, row[3] ); row[4] = fma( -tt, b4, row[4] ); row[5] = fma( -tt, b5, row[5] );
+    }
     double pa = pr;
     if( is1 ){
-      if( full ){
-        const double tt = U_r*Dinv;
-#pragma unroll
-        for( int k=0; k<6; k++ ) row[k] -= tt*L.U[6*i+k];
-      }
-      double sacc = 0;
-#pragma unroll
-      for( int k=0; k<6; k++ ) sacc += row[k]*c[k];
-      pa = pr + sacc + U_r*( u*Dinv );
+      double s0 = row[0]*pre.c[0], s1 = row[1]*pre.c[1];
+      s0 = fma( row[2], pre.c[2], s0 ); s1 = fma( row[3], pre.c[3], s1 );
+      s0 = fma( row[4], pre.c[4], s0 ); s1 = fma( row[5], pre.c[5], s1 );
+      pa = pr + ( s0 + s1 ) + U_r*( u*Dinv );
     } else if( isf ){
       pa = 0;
     }
-    /* write back: Ia row (float joints keep IA for the factorisation), pa, scalars */
+    QST(11);
+    /* write back (needed by later phases and by parents that gather from LDS) */
     if( on ){
       if( full ){
 #pragma unroll
         for( int k=0; k<6; k++ ) L.IA[36*i+6*rr+k] = row[k];
+        if( is1 ) L.U[6*i+rr] = U_r;
       }
       L.PA[6*i+rr] = pa;
       if( isf ) L.U[6*i+rr] = pr;   /* float: the U slot keeps the bias pA */
@@ -572,22 +647,42 @@ RKFD_DEV void rkfd_phase_sweep2(const rkfdDevModel &m, const rkfdLds &L, bool fu
         L.MS[4*i+1] = u;
       }
     }
-    SYNC();
+    LDS_FENCE();
+    QST(12);
     if( full && isf && onl && r == 0 ) d_chol6_inplace( &L.IA[36*i] );
-    SYNC();
+    QST(13);
+#undef QST
+#pragma unroll
+    for( int k=0; k<6; k++ ) crow[k] = row[k];
+    cpa = pa;
   }
+  SYNC();
 }
 
-/* ABA sweep 3 (root to leaf): accelerations and joint accelerations */
+/* ABA sweep 3 (root to leaf): accelerations and joint accelerations.  Same pipelining; along
+ * chains the parent's acceleration stays in registers (schedule flag bit 1). */
+typedef struct { double c_r, U_r, S_r, u, Dinv; } rkfdPre3;
+RKFD_DEV void rkfd_pre3_load(const rkfdLds &L, int i, int rr, rkfdPre3 &p)
+{
+  p.c_r = L.C[6*i+rr]; p.U_r = L.U[6*i+rr]; p.S_r = L.S[6*i+rr];
+  p.Dinv = L.MS[4*i+0]; p.u = L.MS[4*i+1];
+}
 RKFD_DEV void rkfd_phase_sweep3(const rkfdDevModel &m, const rkfdLds &L)
 {
   const int lane = LANE();
   const int g = lane >> 3, r = lane & 7;
   const int rr = r < 6 ? r : 0;
-  rkfdRec nxt = rkfd_rec_load( m, 0, g );
-  for( int t=0; t<m.nsched; t++ ){
-    const rkfdRec rec = nxt;
-    nxt = rkfd_rec_load( m, t+1, g );
+  const int T = m.nsched;
+  rkfdRec rec1 = rkfd_rec_load( m, 0, g ), rec2 = rkfd_rec_load( m, 1, g );
+  rkfdPre3 pre1;
+  rkfd_pre3_load( L, rec1.i >= 0 ? rec1.i : 0, rr, pre1 );
+  double ca = 0;
+  for( int t=0; t<T; t++ ){
+    const rkfdRec rec = rec1;
+    const rkfdPre3 pre = pre1;
+    rec1 = rec2;
+    rec2 = rkfd_rec_load( m, t+2, g );
+    rkfd_pre3_load( L, rec1.i >= 0 ? rec1.i : 0, rr, pre1 );
     const bool onl = rec.i >= 0;
     const bool on = onl && r < 6;
     const int i = onl ? rec.i : 0;
@@ -595,45 +690,53 @@ RKFD_DEV void rkfd_phase_sweep3(const rkfdDevModel &m, const rkfdLds &L)
     const bool is1 = jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM;
     const int par = onl ? RKFD_LI_PAR( rec.li ) : -1;
     const int off = RKFD_LI_OFF( rec.li );
-    const double ap = ( par >= 0 ) ? L.AC[6*par+rr] : 0.0;
-    const double y = ap + L.C[6*i+rr];
-    const double uy = G8SUM( ( on && is1 ) ? L.U[6*i+rr]*y : 0.0 );
+    double ap;
+    LDS_FENCE();   /* the parents' accelerations written in the previous iteration precede the loads below */
+    if( rec.flags & 2 ) ap = ca;
+    else ap = ( par >= 0 ) ? L.AC[6*par+rr] : 0.0;
+    const double y = ap + pre.c_r;
+    const double uy = G8SUM( ( on && is1 ) ? pre.U_r*y : 0.0 );
     double a = y;
     if( is1 ){
-      const double qdd = ( L.MS[4*i+1] - uy )*L.MS[4*i+0];
-      a = y + L.S[6*i+rr]*qdd;
+      const double qdd = ( pre.u - uy )*pre.Dinv;
+      a = fma( pre.S_r, qdd, y );
       if( on && rr == 0 ) L.acc[off] = qdd;
-    } else if( jt == RKFD_JOINT_FLOAT && onl && r == 0 ){
-      /* a = IA^-1 ( -pA ); joint acceleration from a - a_parent - c */
-      double rhs[6], x[6], d[6], R[9], Rj[9], Row[9], p[3], qq[3];
+    } else if( jt == RKFD_JOINT_FLOAT ){
+      if( onl && r == 0 ){
+        /* a = IA^-1 ( -pA ); joint acceleration from a - a_parent - c */
+        double rhs[6], x[6], d[6], R[9], Rj[9], Row[9], p[3], qq[3];
 #pragma unroll
-      for( int k=0; k<6; k++ ) rhs[k] = -L.U[6*i+k];
-      d_chol6_solve( &L.IA[36*i], rhs, x );
+        for( int k=0; k<6; k++ ) rhs[k] = -L.U[6*i+k];
+        d_chol6_solve( &L.IA[36*i], rhs, x );
 #pragma unroll
-      for( int k=0; k<6; k++ ){
-        L.AC[6*i+k] = x[k];
-        d[k] = x[k] - ( par >= 0 ? L.AC[6*par+k] : 0.0 ) - L.C[6*i+k];
+        for( int k=0; k<6; k++ ){
+          L.AC[6*i+k] = x[k];
+          d[k] = x[k] - ( par >= 0 ? L.AC[6*par+k] : 0.0 ) - L.C[6*i+k];
+        }
+#pragma unroll
+        for( int k=0; k<9; k++ ) R[k] = L.X[12*i+k];
+        p[0] = L.X[12*i+9]; p[1] = L.X[12*i+10]; p[2] = L.X[12*i+11];
+        qq[0] = L.q[off+3]; qq[1] = L.q[off+4]; qq[2] = L.q[off+5];
+        d_from_aa( qq, Rj );
+        {
+          double RjT[9] = { Rj[0],Rj[3],Rj[6], Rj[1],Rj[4],Rj[7], Rj[2],Rj[5],Rj[8] };
+          d_mul33( R, RjT, Row );
+        }
+        /* wdot_j = Row' alpha ; vdot_j = Row' ( a_O - p x alpha ) */
+        double t3[3], lin[3], o1[3], o2[3];
+        d_cross( p, d, t3 );
+        lin[0] = d[3]-t3[0]; lin[1] = d[4]-t3[1]; lin[2] = d[5]-t3[2];
+        d_tmulv( Row, lin, o1 ); d_tmulv( Row, d, o2 );
+        L.acc[off] = o1[0]; L.acc[off+1] = o1[1]; L.acc[off+2] = o1[2];
+        L.acc[off+3] = o2[0]; L.acc[off+4] = o2[1]; L.acc[off+5] = o2[2];
       }
-#pragma unroll
-      for( int k=0; k<9; k++ ) R[k] = L.X[12*i+k];
-      p[0] = L.X[12*i+9]; p[1] = L.X[12*i+10]; p[2] = L.X[12*i+11];
-      qq[0] = L.q[off+3]; qq[1] = L.q[off+4]; qq[2] = L.q[off+5];
-      d_from_aa( qq, Rj );
-      {
-        double RjT[9] = { Rj[0],Rj[3],Rj[6], Rj[1],Rj[4],Rj[7], Rj[2],Rj[5],Rj[8] };
-        d_mul33( R, RjT, Row );
-      }
-      /* wdot_j = Row' alpha ; vdot_j = Row' ( a_O - p x alpha ) */
-      double t3[3], lin[3], o1[3], o2[3];
-      d_cross( p, d, t3 );
-      lin[0] = d[3]-t3[0]; lin[1] = d[4]-t3[1]; lin[2] = d[5]-t3[2];
-      d_tmulv( Row, lin, o1 ); d_tmulv( Row, d, o2 );
-      L.acc[off] = o1[0]; L.acc[off+1] = o1[1]; L.acc[off+2] = o1[2];
-      L.acc[off+3] = o2[0]; L.acc[off+4] = o2[1]; L.acc[off+5] = o2[2];
     }
+    LDS_FENCE();
+    if( jt == RKFD_JOINT_FLOAT ) a = L.AC[6*i+rr];
     if( on && jt != RKFD_JOINT_FLOAT ) L.AC[6*i+rr] = a;
-    SYNC();
+    ca = a;
   }
+  SYNC();
 }
 
 /* ------------------------------------------------------------------------ */
@@ -1031,12 +1134,16 @@ RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L)
 /* one dynamics evaluation: _rkFDUpdate / _rkFDUpdateRef (reference src/rkfd_sim.c:533-549).
  * Input L.q, L.qd; output L.acc (and contact / pivot state).  Returns nonzero when the model
  * needs a rigid solver that is not available on the device (wave-uniform). */
-RKFD_DEV int rkfd_evaluate(const rkfdDevModel &m, const rkfdLds &L, bool doUpRef)
+RKFD_DEV int rkfd_evaluate(const rkfdDevModel &m, const rkfdLds &L, bool doUpRef, bool prof, unsigned long long *pc)
 {
   const int lane = LANE();
   int err = 0;
+  unsigned long long t0 = 0, t1;
+#define STAMP(k) do{ if( prof ){ t1 = RKFD_CLOCK(); pc[k] += t1 - t0; t0 = t1; } }while(0)
+  if( prof ) t0 = RKFD_CLOCK();
   if( lane < m.ndof ) L.acc[lane] = 0.0;
   rkfd_phase_kinematics( m, L );
+  STAMP(0);
   /* commit joint friction pivots (the reference does so inside rkFDJointFrictionRevolDC) */
   if( doUpRef && lane < m.nlink ){
     const int jt = RKFD_LI_JT( L.LI[lane] );
@@ -1054,16 +1161,20 @@ RKFD_DEV int rkfd_evaluate(const rkfdDevModel &m, const rkfdLds &L, bool doUpRef
     L.cnt[CNT_NRG] = 0; L.cnt[CNT_NEL] = 0;
   }
   SYNC();
+  STAMP(1);
   /* pass 0: rkChainUpdateABI (full sweeps; with rigid contacts this is rkFDUpdateAccBias);
    * pass 1 (only after the MLCP solve): rkChainUpdateCachedABI with the contact wrenches.
    * Written as a loop so that the sweep code exists once in the instruction stream. */
   int npass = 1;
   for( int pass=0; pass<npass; pass++ ){
-    rkfd_phase_sweep2( m, L, pass == 0 );
+    rkfd_phase_sweep2( m, L, pass == 0, prof, pc );
+    STAMP(2);
     rkfd_phase_sweep3( m, L );
+    STAMP(3);
     if( pass == 0 && L.cnt[CNT_NRG] > 0 ){
       if( m.solver == RKFD_SOLVER_MLCP ){
         rkfd_phase_mlcp( m, L );
+        STAMP(4);
         npass = 2;
       } else {
         err = 1;
@@ -1077,6 +1188,8 @@ RKFD_DEV int rkfd_evaluate(const rkfdDevModel &m, const rkfdLds &L, bool doUpRef
       L.pivp[lane] = drv - L.MS[4*lane+3]*L.acc[RKFD_LI_OFF( L.LI[lane] )];
   }
   SYNC();
+  STAMP(5);
+#undef STAMP
   return err;
 }
 
@@ -1123,6 +1236,7 @@ RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkfdDevState &st, int b
   if( lane < ND ){ q = st.dis[(size_t)b*ND+lane]; qd = st.vel[(size_t)b*ND+lane]; L.dofkind[lane] = 0; }
   if( lane < NL ){
     L.LI[lane]   = m.linfo[lane];
+    L.CHI[lane]  = m.child_idx[lane];
     L.min[lane]  = st.motor_in[(size_t)b*NL+lane];
     L.pivt[lane] = st.piv_type[(size_t)b*NL+lane];
     L.pivp[lane] = st.piv_prev[(size_t)b*NL+lane];
@@ -1147,6 +1261,11 @@ RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkfdDevState &st, int b
   }
   SYNC();
   int err = 0;
+  const bool prof = st.prof != 0;
+  unsigned long long pc[RKFD_NPROF];
+#pragma unroll
+  for( int k=0; k<RKFD_NPROF; k++ ) pc[k] = 0;
+  const unsigned long long tstart = prof ? RKFD_CLOCK() : 0ull;
   {
     /* rkFDUpdate = zODE2Update (Runge-Kutta-Gill, 4 stage evaluations) + the committing
      * evaluation at the new state (reference src/rkfd_sim.c:560-566).  All five evaluations
@@ -1182,7 +1301,7 @@ RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkfdDevState &st, int b
       if( stage == 4 ){ q = on ? L.q[lane] : 0.0; qd = xv; }
       SYNC();
       const bool doUp = mode == 0 ? stage == 4 : mode == 1;
-      err |= rkfd_evaluate( m, L, doUp );
+      err |= rkfd_evaluate( m, L, doUp, prof, pc );
       const double a = on ? L.acc[lane] : 0.0;
       if( stage == 0 ){ kv1 = xv; ka1 = a; }
       else if( stage == 1 ){ kv2 = xv; ka2 = a; }
@@ -1191,6 +1310,11 @@ RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkfdDevState &st, int b
       SYNC();
       stage++; if( stage == nst ) stage = 0;
     }
+  }
+  if( prof && lane == 0 ){
+    pc[7] = RKFD_CLOCK() - tstart;
+#pragma unroll
+    for( int k=0; k<RKFD_NPROF; k++ ) st.prof[(size_t)b*RKFD_NPROF+k] = pc[k];
   }
   /* store */
   if( lane < ND ){

@@ -96,24 +96,64 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
     if( cnf[j] > 255 ) FAIL( "a collision shape has more than 255 faces" );
     cinfo[j] = cA[j] | ( cB[j] << 8 ) | ( cci[j] << 16 ) | ( cnf[j] << 24 );
   }
-  /* sweep schedule: one iteration = up to 8 links of one level */
+  /* sweep schedule: one iteration = up to 8 links of one level.  Lane-group slots are kept stable
+   * along chains (a link takes the slot of its first child when possible) so that the sweeps can
+   * hand data from one iteration to the next in registers:
+   *   flag bit 0: the link's only child was processed in the NEXT iteration (sweep 2 runs the
+   *               schedule backwards, so "previous" there) by the same slot
+   *   flag bit 1: the link's parent was processed in the previous iteration by the same slot */
   std::vector<int> sched;
   int nsched = 0;
-  for( int d=0; d<nlevel; d++ )
-    for( int base=level_off[d]; base<level_off[d+1]; base+=8 ){
+  {
+    std::vector<int> slot( NL, -1 ), iter( NL, -1 );
+    std::vector<std::vector<int> > iters;          /* iteration -> 8 slots -> link */
+    std::vector<int> level_first_iter( nlevel+1, 0 );
+    /* assign slots bottom-up */
+    std::vector<std::vector<std::vector<int> > > per_level( nlevel );
+    for( int d=nlevel-1; d>=0; d-- ){
+      const int n = level_off[d+1] - level_off[d];
+      const int nch = ( n + 7 ) / 8;
+      per_level[d].assign( nch, std::vector<int>( 8, -1 ) );
+      std::vector<int> rest;
+      for( int k=level_off[d]; k<level_off[d+1]; k++ ){
+        const int i = level_link[k];
+        int pref = -1;
+        if( child_off[i+1] > child_off[i] ) pref = slot[child_idx[child_off[i]]];
+        if( nch == 1 && pref >= 0 && per_level[d][0][pref] < 0 ){ per_level[d][0][pref] = i; slot[i] = pref; }
+        else rest.push_back( i );
+      }
+      int c = 0, sidx = 0;
+      for( size_t k=0; k<rest.size(); k++ ){
+        while( per_level[d][c][sidx] >= 0 ){ sidx++; if( sidx == 8 ){ sidx = 0; c++; } }
+        per_level[d][c][sidx] = rest[k]; slot[rest[k]] = sidx;
+      }
+    }
+    for( int d=0; d<nlevel; d++ )
+      for( size_t c=0; c<per_level[d].size(); c++ ){
+        for( int g=0; g<8; g++ ) if( per_level[d][c][g] >= 0 ) iter[per_level[d][c][g]] = nsched;
+        iters.push_back( per_level[d][c] );
+        nsched++;
+      }
+    for( int t=0; t<nsched; t++ )
       for( int g=0; g<8; g++ ){
         int rec[8] = { -1, 0, 0, -1, -1, -1, -1, 0 };
-        if( base+g < level_off[d+1] ){
-          const int i = level_link[base+g];
+        const int i = iters[t][g];
+        if( i >= 0 ){
+          const int nchild = child_off[i+1] - child_off[i];
+          int flags = 0;
+          if( nchild == 1 ){
+            const int ch = child_idx[child_off[i]];
+            if( iter[ch] == t+1 && slot[ch] == g && m->jtype[ch] != RKFD_JOINT_FLOAT ) flags |= 1;
+          }
+          if( m->parent[i] >= 0 && iter[m->parent[i]] == t-1 && slot[m->parent[i]] == g ) flags |= 2;
           rec[0] = i; rec[1] = linfo[i];
-          rec[2] = child_off[i+1] - child_off[i];
-          for( int k=0; k<4 && k<rec[2]; k++ ) rec[3+k] = child_idx[child_off[i]+k];
+          rec[2] = nchild | ( flags << 8 );
+          for( int k=0; k<4 && k<nchild; k++ ) rec[3+k] = child_idx[child_off[i]+k];
           rec[7] = child_off[i];
         }
         sched.insert( sched.end(), rec, rec+8 );
       }
-      nsched++;
-    }
+  }
 
   Blob b;
   rkfdDevModel dm;
@@ -163,7 +203,7 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
     const size_t M = 3*(size_t)max_rigid;
     const size_t dbl = (size_t)4*ND + (size_t)NL*100 + (size_t)NC*24 + M*(M+1) + 2*M + 2*(size_t)nlevel*M + 2*(size_t)NL;
     const size_t ints = (size_t)5*NC + 8 + (size_t)ND + (size_t)NL      /* act typ lrg lel tgt, cnt, dofkind, pivt */
-                      + (size_t)NL + 2*(size_t)NC + ( max_rigid > 0 ? (size_t)NL*nlevel : 0 ); /* LI, CIp, CFO, PL */
+                      + 2*(size_t)NL + 2*(size_t)NC + ( max_rigid > 0 ? (size_t)NL*nlevel : 0 ); /* LI, CHI, CIp, CFO, PL */
     out->lds_bytes = dbl*sizeof(double) + ints*sizeof(int);
     out->lds_bytes = ( out->lds_bytes + 15 ) & ~(size_t)15;
   }

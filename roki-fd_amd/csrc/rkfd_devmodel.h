@@ -70,6 +70,7 @@ typedef struct {
   double *piv_prev;              /* [B][nlink]  */
   int    *cv_active, *cv_type;   /* [B][ncand]  */
   double *cv_ref, *cv_f;         /* [B][ncand*3]*/
+  unsigned long long *prof;      /* optional [B][8] phase cycle counters, may be NULL */
   double *dbg;                   /* optional debug dump, may be NULL */
   int dbg_stride;
   int batch;

@@ -31,6 +31,14 @@ double rkfd_emu_g8sum(double x)
   g_bar->arrive_and_wait();
   return r;
 }
+double rkfd_emu_g8bcast(double x, int k)
+{
+  g_xd[t_lane] = x;
+  g_bar->arrive_and_wait();
+  double r = g_xd[( t_lane & ~7 ) + k];
+  g_bar->arrive_and_wait();
+  return r;
+}
 double rkfd_emu_bcast(double x, int src)
 {
   g_xd[t_lane] = x;

@@ -1,0 +1,11 @@
+import sys; import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import rkfd_pkg; R = rkfd_pkg.load()
+import numpy as np
+warm = int(os.environ.get('WARM','20'))
+for cfg in sys.argv[1:]:
+    sc = R.scenarios.CONFIGS[cfg](batch=4096)
+    b = R.Batch(sc['world'], 4096, max_rigid=sc['max_rigid'])
+    b.set_state(sc['dis'], sc['vel']); b.update_init(); b.update(warm)
+    p = b.profile(5).astype(np.float64)/5
+    names=['kin','cd+pen','sweep2','sweep3','mlcp','tail','-','total','s2:pre','s2:gather','s2:UD','s2:rank1','s2:store','s2:chol','-','-']
+    act = b.get_contact()[0]; print(cfg, 'warm', warm, 'mean contacts', act.sum(1).mean(), 'lds', b.lds_bytes, ' '.join('%s=%.0f'%(n,x) for n,x in zip(names,p.mean(0))), 'sum', p[:,:6].sum(1).mean())
