@@ -13,7 +13,7 @@ static thread_local char g_err[512] = "";
   SETERR( "%s failed: %s", #call, hipGetErrorString( e_ ) ); return ret; } }while(0)
 
 /* one workgroup = one wavefront = one world instance; state lives in LDS for the whole launch */
-extern "C" __global__ void __launch_bounds__(RKFD_WAVE)
+extern "C" __global__ void __launch_bounds__(RKFD_WAVE, 2)
 rkfd_step_kernel(rkfdDevModel m, rkfdDevState st, int mode, int nsteps, int *errflag)
 {
   extern __shared__ __attribute__((aligned(16))) char lds[];

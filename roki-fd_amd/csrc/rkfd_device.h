@@ -37,6 +37,7 @@
 #  define SYNC()        rkfd_emu_sync()
    double rkfd_emu_g8bcast(double x, int k);
 #  define G8SUM(x)      rkfd_emu_g8sum(x)
+#  define G8SUM2(x,y)   do{ (x) = rkfd_emu_g8sum(x); (y) = rkfd_emu_g8sum(y); }while(0)
 #  define G8BCAST(x,k)  rkfd_emu_g8bcast(x,k)
 #  define RKFD_RCP(x)   ( 1.0/(x) )
 #  define LDS_FENCE()   rkfd_emu_sync()
@@ -79,6 +80,16 @@ RKFD_DEV double rkfd_g8sum(double x)
   x += rkfd_dpp_hmirror( x );
   return x;
 }
+/* two independent 8-lane sums, interleaved so that their DPP chains overlap */
+RKFD_DEV void rkfd_g8sum2(double &x, double &y)
+{
+  double a = rkfd_dpp_xor1( x ), b = rkfd_dpp_xor1( y );
+  x += a; y += b;
+  a = rkfd_dpp_xor2( x ); b = rkfd_dpp_xor2( y );
+  x += a; y += b;
+  a = rkfd_dpp_hmirror( x ); b = rkfd_dpp_hmirror( y );
+  x += a; y += b;
+}
 /* broadcast lane src (wave-uniform) to every lane */
 RKFD_DEV double rkfd_bcast(double x, int src)
 {
@@ -103,6 +114,7 @@ RKFD_DEV double rkfd_rcp(double x)
   return r;
 }
 #  define G8SUM(x)      rkfd_g8sum(x)
+#  define G8SUM2(x,y)   rkfd_g8sum2(x,y)
 #  define G8BCAST(x,k)  rkfd_g8bcast<k>(x)
 #  define RKFD_RCP(x)   rkfd_rcp(x)
 /* compiler-only fence: LDS operations of one wavefront execute in program order */
@@ -206,49 +218,57 @@ RKFD_DEV double d_clamp(double x, double lo, double hi){ return x < lo ? lo : ( 
 /* LDS carve-up for one instance */
 typedef struct {
   double *q, *qd, *acc, *tmp;     /* [ndof] each                                         */
-  double *X;                      /* [NL*12] world frame R(9) p(3)                        */
   double *S;                      /* [NL*6]  joint axis (ang, lin)                        */
   double *V;                      /* [NL*6]  spatial velocity                             */
   double *C;                      /* [NL*6]  velocity-product acceleration                */
-  double *IA;                     /* [NL*36] spatial / articulated inertia                */
-  double *PB;                     /* [NL*6]  own bias force                               */
-  double *FE;                     /* [NL*6]  external wrench                              */
+  double *PB;                     /* [NL*6]  own bias force minus the external wrenches   */
   double *PA;                     /* [NL*6]  bias force handed to the parent              */
+  double *AC;                     /* [NL*6]  spatial acceleration (adjacent to PA)        */
+  double *X;                      /* [NL*12] world frames R(9) p(3): ALIASES PA|AC, valid from the
+                                     kinematics phase to the end of the collision phase   */
   double *U;                      /* [NL*6]                                               */
-  double *AC;                     /* [NL*6]  spatial acceleration                         */
+  double *W;                      /* [NL*6]  Ia c, kept for the bias-only sweep           */
   double *MS;                     /* [NL*4]  Dinv, u, tau, jm                             */
+  double *IST;                    /* [NL*14] inertia staging: A = Iw + m(|r|^2 1 - r r') (xx,xy,xz,yy,yz,zz),
+                                     +m r (3), -m r (3), m, 0: every entry of the 6x6 is one of these */
+  double *POOL;                   /* [npool*36] Ia of links whose parent gathers through LDS */
+  double *CHOL;                   /* [nfloat*36] articulated inertia / Cholesky factor of float joints */
+  double *XF;                     /* [nfloat*12] world frame of float-joint links         */
   double *CX, *AX, *RW, *PRO, *REF, *CF; /* per candidate: 3, 9, 3, 3, 3, 3               */
-  double *MA, *MB, *MF, *PU;      /* MLCP: [M*(M+1)], [M], [M], [2*nlevel*M]              */
+  double *MA, *MB, *MF, *PU;      /* MLCP: [M*(M+1)] (ALIASES IST|POOL), [M], [M], [2*nlevel*M] */
   int *act, *typ, *lrg, *lel, *tgt, *cnt, *dofkind, *pivt;
   int *LI;                        /* [NL] packed link info (RKFD_LI_*)                    */
   int *CIp, *CFO;                 /* [NC] packed candidate info, first plane              */
   int *CHI;                       /* [NL] children lists (CSR values; offsets in the schedule)     */
+  int *PSL;                       /* [NL] pool slot of a link (-1 none)                   */
   int *PL;                        /* [NL*nlevel] ancestor at depth d (MLCP only)          */
   double *pivp, *min;             /* [NL] pivot prev torque, motor input                  */
 } rkfdLds;
 
-RKFD_DEV size_t rkfd_lds_doubles(int NL, int ND, int NC, int M, int nlevel)
-{
-  return (size_t)4*ND + (size_t)NL*( 12+6+6+6+36+6+6+6+6+6+4 ) + (size_t)NC*( 3+9+3+3+3+3 )
-       + (size_t)M*(M+1) + 2*(size_t)M + 2*(size_t)nlevel*M + 2*(size_t)NL;
-}
-
-RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int M, int nlevel)
+RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int M, int nlevel, int npool, int nfloat)
 /* must match the byte count computed in rkfd_devmodel.cpp */
 {
   double *d = (double *)base;
   L->q = d; d += ND; L->qd = d; d += ND; L->acc = d; d += ND; L->tmp = d; d += ND;
-  L->X = d; d += NL*12; L->S = d; d += NL*6; L->V = d; d += NL*6; L->C = d; d += NL*6;
-  L->IA = d; d += NL*36; L->PB = d; d += NL*6; L->FE = d; d += NL*6; L->PA = d; d += NL*6;
-  L->U = d; d += NL*6; L->AC = d; d += NL*6; L->MS = d; d += NL*4;
+  L->S = d; d += NL*6; L->V = d; d += NL*6; L->C = d; d += NL*6; L->PB = d; d += NL*6;
+  L->PA = d; L->X = d; d += NL*6; L->AC = d; d += NL*6;
+  L->U = d; d += NL*6; L->W = d; d += NL*6; L->MS = d; d += NL*4;
+  {
+    int stage = 14*NL + 36*npool;
+    L->IST = d; L->POOL = d + 14*NL; L->MA = d;
+    if( M*(M+1) > stage ) stage = M*(M+1);
+    d += stage;
+  }
+  L->CHOL = d; d += 36*nfloat; L->XF = d; d += 12*nfloat;
   L->CX = d; d += NC*3; L->AX = d; d += NC*9; L->RW = d; d += NC*3; L->PRO = d; d += NC*3;
   L->REF = d; d += NC*3; L->CF = d; d += NC*3;
-  L->MA = d; d += M*(M+1); L->MB = d; d += M; L->MF = d; d += M; L->PU = d; d += 2*nlevel*M;
+  L->MB = d; d += M; L->MF = d; d += M; L->PU = d; d += 2*nlevel*M;
   L->pivp = d; d += NL; L->min = d; d += NL;
   int *ip = (int *)d;
   L->act = ip; ip += NC; L->typ = ip; ip += NC; L->lrg = ip; ip += NC; L->lel = ip; ip += NC;
   L->tgt = ip; ip += NC; L->cnt = ip; ip += 8; L->dofkind = ip; ip += ND; L->pivt = ip; ip += NL;
   L->LI = ip; ip += NL; L->CIp = ip; ip += NC; L->CFO = ip; ip += NC; L->CHI = ip; ip += NL;
+  L->PSL = ip; ip += NL;
   L->PL = ip;
 }
 
@@ -405,33 +425,16 @@ RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, const rkfdLds &L)
       cw[0] += p[0]; cw[1] += p[1]; cw[2] += p[2];
       d_mul33( R, Ic, t9 ); d_mul33( t9, RT, Iw );
     }
-    /* I = [ Iw + m( |r|^2 1 - r r' )   m [r]x ;  m [r]x'   m 1 ] */
-    double I6[36];
-    {
-      const double r2 = d_dot( cw, cw );
-#pragma unroll
-      for( int a=0; a<3; a++ )
-#pragma unroll
-        for( int b=0; b<3; b++ ){
-          I6[6*a+b] = Iw[3*a+b] + ms*( ( a==b ? r2 : 0.0 ) - cw[a]*cw[b] );
-          I6[6*(3+a)+3+b] = ( a==b ? ms : 0.0 );
-        }
-      const double rx[9] = { 0,-cw[2],cw[1], cw[2],0,-cw[0], -cw[1],cw[0],0 };
-#pragma unroll
-      for( int a=0; a<3; a++ )
-#pragma unroll
-        for( int b=0; b<3; b++ ){
-          I6[6*a+3+b] = ms*rx[3*a+b];
-          I6[6*(3+a)+b] = ms*rx[3*b+a];
-        }
-    }
+    /* momentum h = I v about the world origin: h_lin = m ( v_O + w x r ), h_ang = Iw w + r x h_lin
+     * (the 6x6 itself is rebuilt row by row inside sweep 2 from the staged Iw, r, m) */
     double h[6], pb[6];
-#pragma unroll
-    for( int a=0; a<6; a++ ){
-      double s = 0;
-#pragma unroll
-      for( int b=0; b<6; b++ ) s += I6[6*a+b]*v[b];
-      h[a] = s;
+    {
+      double wxr[3], t3[3];
+      d_cross( v, cw, wxr );
+      h[3] = ms*( v[3]+wxr[0] ); h[4] = ms*( v[4]+wxr[1] ); h[5] = ms*( v[5]+wxr[2] );
+      d_mulv( Iw, v, t3 );
+      d_cross( cw, h+3, wxr );
+      h[0] = t3[0]+wxr[0]; h[1] = t3[1]+wxr[1]; h[2] = t3[2]+wxr[2];
     }
     d_crf( v, h, pb );
     /* gravity as an explicit force at the centre of mass: f = (r x mg, mg) */
@@ -440,11 +443,25 @@ RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, const rkfdLds &L)
       d_cross( cw, g, ng );
       pb[0] -= ng[0]; pb[1] -= ng[1]; pb[2] -= ng[2]; pb[5] -= g[2];
     }
+    /* float joints: remember the world frame for sweep 3 (the X region is reused by the sweeps) */
+    {
+      const unsigned long long fm = BALLOT( on && jt == RKFD_JOINT_FLOAT );
+      if( on && jt == RKFD_JOINT_FLOAT ){
+        const int fs = __builtin_popcountll( fm & ( lane == 0 ? 0ull : ( ~0ull >> ( 64-lane ) ) ) );
+#pragma unroll
+        for( int k=0; k<9; k++ ) L.XF[12*fs+k] = R[k];
+        L.XF[12*fs+9] = p[0]; L.XF[12*fs+10] = p[1]; L.XF[12*fs+11] = p[2];
+      }
+    }
     if( on ){
+      const double r2 = d_dot( cw, cw );
+      L.IST[14*i+0] = Iw[0] + ms*( r2 - cw[0]*cw[0] ); L.IST[14*i+1] = Iw[1] - ms*cw[0]*cw[1]; L.IST[14*i+2] = Iw[2] - ms*cw[0]*cw[2];
+      L.IST[14*i+3] = Iw[4] + ms*( r2 - cw[1]*cw[1] ); L.IST[14*i+4] = Iw[5] - ms*cw[1]*cw[2]; L.IST[14*i+5] = Iw[8] + ms*( r2 - cw[2]*cw[2] );
+      L.IST[14*i+6] = ms*cw[0]; L.IST[14*i+7] = ms*cw[1]; L.IST[14*i+8] = ms*cw[2];
+      L.IST[14*i+9] = -ms*cw[0]; L.IST[14*i+10] = -ms*cw[1]; L.IST[14*i+11] = -ms*cw[2];
+      L.IST[14*i+12] = ms; L.IST[14*i+13] = 0.0;
 #pragma unroll
-      for( int k=0; k<36; k++ ) L.IA[36*i+k] = I6[k];
-#pragma unroll
-      for( int k=0; k<6; k++ ){ L.C[6*i+k] = c[k]; L.PB[6*i+k] = pb[k]; L.FE[6*i+k] = 0; }
+      for( int k=0; k<6; k++ ){ L.C[6*i+k] = c[k]; L.PB[6*i+k] = pb[k]; }
     }
     /* joint friction and joint torque:
      * rkFDJointFriction / rkFDJointFrictionRevolDC (reference src/rkfd_util.c:318-387) */
@@ -488,18 +505,19 @@ RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, const rkfdLds &L)
 }
 
 /* ------------------------------------------------------------------------ */
-/* in-place Cholesky of the 6x6 at A (row-major, lower part used), one lane */
+/* in-place Cholesky of the 6x6 at A (row-major, lower part used), one lane.  The diagonal
+ * stores 1/L_jj so that the factorisation and the solves multiply instead of dividing. */
 RKFD_DEV void d_chol6_inplace(double *A)
 {
   for( int j=0; j<6; j++ ){
     double s = A[6*j+j];
     for( int k=0; k<j; k++ ) s -= A[6*j+k]*A[6*j+k];
-    s = sqrt( s );
-    A[6*j+j] = s;
+    const double inv = RKFD_RCP( sqrt( s ) );
+    A[6*j+j] = inv;
     for( int i=j+1; i<6; i++ ){
       double t = A[6*i+j];
       for( int k=0; k<j; k++ ) t -= A[6*i+k]*A[6*j+k];
-      A[6*i+j] = t / s;
+      A[6*i+j] = t*inv;
     }
   }
 }
@@ -511,14 +529,14 @@ RKFD_DEV void d_chol6_solve(const double *Lm, const double *b, double *x)
     double s = b[i];
 #pragma unroll
     for( int k=0; k<6; k++ ) if( k < i ) s -= Lm[6*i+k]*y[k];
-    y[i] = s / Lm[6*i+i];
+    y[i] = s*Lm[6*i+i];
   }
 #pragma unroll
   for( int i=5; i>=0; i-- ){
     double s = y[i];
 #pragma unroll
     for( int k=0; k<6; k++ ) if( k > i ) s -= Lm[6*k+i]*x[k];
-    x[i] = s / Lm[6*i+i];
+    x[i] = s*Lm[6*i+i];
   }
 }
 
@@ -527,25 +545,49 @@ RKFD_DEV void d_chol6_solve(const double *Lm, const double *b, double *x)
 typedef struct { int i, li, nchild, flags, c0, c1, c2, c3, coff; } rkfdRec;
 RKFD_DEV rkfdRec rkfd_rec_load(const rkfdDevModel &m, int t, int g)
 {
+  /* t in [-2, nsched+1]: the schedule is padded with two empty iterations on both sides */
   rkfdRec r;
-  if( t < 0 || t >= m.nsched ){ r.i = -1; r.li = 0; r.nchild = 0; r.flags = 0; r.c0 = r.c1 = r.c2 = r.c3 = -1; r.coff = 0; return r; }
-  const int *p = m.sched + ( (size_t)t*8 + g )*8;
+  const int *p = m.sched + ( (size_t)( t+2 )*8 + g )*8;
   r.i = p[0]; r.li = p[1]; r.nchild = p[2] & 0xFF; r.flags = p[2] >> 8;
   r.c0 = p[3]; r.c1 = p[4]; r.c2 = p[5]; r.c3 = p[6]; r.coff = p[7];
   return r;
 }
 
-/* per-lane operands of one sweep-2 iteration, fetched from LDS one iteration ahead */
-typedef struct { double row[6], S[6], c[6], S_r, pb, tau, jm, U_r, Dinv; } rkfdPre2;
-RKFD_DEV void rkfd_pre2_load(const rkfdLds &L, int i, int rr, bool full, rkfdPre2 &p)
+/* per-lane operands of one sweep-2 iteration, fetched from LDS one iteration ahead.
+ * row = row rr of the link's own spatial inertia about the world origin,
+ *   [ A   m [r]x ;  m [r]x'   m 1 ],   A = Iw + m( |r|^2 1 - r r' ):
+ * every entry is one of the 14 staged doubles (A sym, +m r, -m r, m, 0), so a row is six loads at
+ * lane-constant offsets ro[] (2.6x less LDS than staging the 6x6, no arithmetic). */
+typedef struct { double row[6], S[6], c[6], S_r, pb, tau, jm, U_r, Dinv, W_r; } rkfdPre2;
+RKFD_DEV void rkfd_row_offsets(int rr, int *ro)
+{
+  /* [r]x = [ 0 -z y ; z 0 -x ; -y x 0 ];  +m r at 6..8, -m r at 9..11, m at 12, 0 at 13 */
+  const int t[6][6] = { { 0, 1, 2, 13, 11, 7 }, { 1, 3, 4, 8, 13, 9 }, { 2, 4, 5, 10, 6, 13 },
+                        { 13, 8, 10, 12, 13, 13 }, { 11, 13, 6, 13, 12, 13 }, { 7, 9, 13, 13, 13, 12 } };
+#pragma unroll
+  for( int k=0; k<6; k++ ){
+    int v = t[0][k];
+#pragma unroll
+    for( int q=1; q<6; q++ ) v = rr == q ? t[q][k] : v;
+    ro[k] = v;
+  }
+}
+RKFD_DEV void rkfd_pre2_load(const rkfdLds &L, int i, int rr, const int *ro, bool full, rkfdPre2 &p)
 {
 #pragma unroll
-  for( int k=0; k<6; k++ ){ p.row[k] = L.IA[36*i+6*rr+k]; p.S[k] = L.S[6*i+k]; p.c[k] = L.C[6*i+k]; }
+  for( int k=0; k<6; k++ ){ p.S[k] = L.S[6*i+k]; p.c[k] = L.C[6*i+k]; }
   p.S_r = L.S[6*i+rr];
-  p.pb = L.PB[6*i+rr] - L.FE[6*i+rr];
+  p.pb = L.PB[6*i+rr];
   p.tau = L.MS[4*i+2]; p.jm = L.MS[4*i+3];
-  p.U_r = full ? 0.0 : L.U[6*i+rr];
-  p.Dinv = full ? 0.0 : L.MS[4*i+0];
+  if( full ){
+#pragma unroll
+    for( int k=0; k<6; k++ ) p.row[k] = L.IST[14*i+ro[k]];
+    p.U_r = 0.0; p.Dinv = 0.0; p.W_r = 0.0;
+  } else {
+#pragma unroll
+    for( int k=0; k<6; k++ ) p.row[k] = 0.0;
+    p.U_r = L.U[6*i+rr]; p.Dinv = L.MS[4*i+0]; p.W_r = L.W[6*i+rr];
+  }
 }
 
 /* ABA sweep 2 (leaf to root), level-synchronous; 8 lanes per link, lane r = row r of the 6x6.
@@ -562,7 +604,9 @@ RKFD_DEV void rkfd_phase_sweep2(const rkfdDevModel &m, const rkfdLds &L, bool fu
   const int T = m.nsched;
   rkfdRec rec1 = rkfd_rec_load( m, T-1, g ), rec2 = rkfd_rec_load( m, T-2, g );
   rkfdPre2 pre1;
-  rkfd_pre2_load( L, rec1.i >= 0 ? rec1.i : 0, rr, full, pre1 );
+  int ro[6];
+  rkfd_row_offsets( rr, ro );
+  rkfd_pre2_load( L, rec1.i >= 0 ? rec1.i : 0, rr, ro, full, pre1 );
   double crow[6] = {0,0,0,0,0,0}, cpa = 0;
   for( int t=T-1; t>=0; t-- ){
     unsigned long long q0 = 0, q1;
@@ -572,7 +616,7 @@ RKFD_DEV void rkfd_phase_sweep2(const rkfdDevModel &m, const rkfdLds &L, bool fu
     const rkfdPre2 pre = pre1;
     rec1 = rec2;
     rec2 = rkfd_rec_load( m, t-2, g );
-    rkfd_pre2_load( L, rec1.i >= 0 ? rec1.i : 0, rr, full, pre1 );
+    rkfd_pre2_load( L, rec1.i >= 0 ? rec1.i : 0, rr, ro, full, pre1 );
     QST(8);
     const bool onl = rec.i >= 0;
     const bool on = onl && r < 6;
@@ -594,26 +638,29 @@ RKFD_DEV void rkfd_phase_sweep2(const rkfdDevModel &m, const rkfdLds &L, bool fu
       for( int cc=0; cc<rec.nchild; cc++ ){
         const int ch = L.CHI[rec.coff+cc];
         pr += L.PA[6*ch+rr];
-        if( full && RKFD_LI_JT( L.LI[ch] ) != RKFD_JOINT_FLOAT ){
+        const int ps = L.PSL[ch];
+        if( full && ps >= 0 ){
 #pragma unroll
-          for( int k=0; k<6; k++ ) row[k] += L.IA[36*ch+6*rr+k];
+          for( int k=0; k<6; k++ ) row[k] += L.POOL[36*ps+6*rr+k];
         }
       }
     }
     QST(9);
     const double S_r = pre.S_r;
-    double U_r, Dinv;
+    double U_r, Dinv, u;
     if( full ){
       double u0 = row[0]*pre.S[0], u1 = row[1]*pre.S[1];
       u0 = fma( row[2], pre.S[2], u0 ); u1 = fma( row[3], pre.S[3], u1 );
       u0 = fma( row[4], pre.S[4], u0 ); u1 = fma( row[5], pre.S[5], u1 );
       U_r = u0 + u1;
-      const double D = G8SUM( ( on && is1 ) ? S_r*U_r : 0.0 ) + pre.jm;
-      Dinv = RKFD_RCP( D );
+      double dsum = ( on && is1 ) ? S_r*U_r : 0.0, usum = ( on && is1 ) ? S_r*pr : 0.0;
+      G8SUM2( dsum, usum );
+      Dinv = RKFD_RCP( dsum + pre.jm );
+      u = pre.tau - usum;
     } else {
       U_r = pre.U_r; Dinv = pre.Dinv;
+      u = pre.tau - G8SUM( ( on && is1 ) ? S_r*pr : 0.0 );
     }
-    const double u = pre.tau - G8SUM( ( on && is1 ) ? S_r*pr : 0.0 );
     QST(10);
     if( full ){
       /* rank-1 downdate Ia = IA - U U'/D: every row needs every U[k] */
@@ -623,12 +670,15 @@ RKFD_DEV void rkfd_phase_sweep2(const rkfdDevModel &m, const rkfdLds &L, bool fu
       row[0] = fma( -tt, b0, row[0] ); row[1] = fma( -tt, b1, row[1] ); row[2] = fma( -tt, b2, row[2] );
       row[3] = fma( -tt, b3, row[3] ); row[4] = fma( -tt, b4, row[4] ); row[5] = fma( -tt, b5, row[5] );
     }
-    double pa = pr;
+    double pa = pr, W_r = pre.W_r;
     if( is1 ){
-      double s0 = row[0]*pre.c[0], s1 = row[1]*pre.c[1];
-      s0 = fma( row[2], pre.c[2], s0 ); s1 = fma( row[3], pre.c[3], s1 );
-      s0 = fma( row[4], pre.c[4], s0 ); s1 = fma( row[5], pre.c[5], s1 );
-      pa = pr + ( s0 + s1 ) + U_r*( u*Dinv );
+      if( full ){
+        double s0 = row[0]*pre.c[0], s1 = row[1]*pre.c[1];
+        s0 = fma( row[2], pre.c[2], s0 ); s1 = fma( row[3], pre.c[3], s1 );
+        s0 = fma( row[4], pre.c[4], s0 ); s1 = fma( row[5], pre.c[5], s1 );
+        W_r = s0 + s1;
+      }
+      pa = pr + W_r + U_r*( u*Dinv );
     } else if( isf ){
       pa = 0;
     }
@@ -636,9 +686,17 @@ RKFD_DEV void rkfd_phase_sweep2(const rkfdDevModel &m, const rkfdLds &L, bool fu
     /* write back (needed by later phases and by parents that gather from LDS) */
     if( on ){
       if( full ){
+        /* Ia goes to LDS only where somebody will read it: a gathering parent (pool slot rec.c0)
+         * or the Cholesky of a float joint (slot rec.c1) */
+        if( rec.c0 >= 0 ){
 #pragma unroll
-        for( int k=0; k<6; k++ ) L.IA[36*i+6*rr+k] = row[k];
-        if( is1 ) L.U[6*i+rr] = U_r;
+          for( int k=0; k<6; k++ ) L.POOL[36*rec.c0+6*rr+k] = row[k];
+        }
+        if( isf ){
+#pragma unroll
+          for( int k=0; k<6; k++ ) L.CHOL[36*rec.c1+6*rr+k] = row[k];
+        }
+        if( is1 ){ L.U[6*i+rr] = U_r; L.W[6*i+rr] = W_r; }
       }
       L.PA[6*i+rr] = pa;
       if( isf ) L.U[6*i+rr] = pr;   /* float: the U slot keeps the bias pA */
@@ -649,7 +707,7 @@ RKFD_DEV void rkfd_phase_sweep2(const rkfdDevModel &m, const rkfdLds &L, bool fu
     }
     LDS_FENCE();
     QST(12);
-    if( full && isf && onl && r == 0 ) d_chol6_inplace( &L.IA[36*i] );
+    if( full && isf && onl && r == 0 ) d_chol6_inplace( &L.CHOL[36*rec.c1] );
     QST(13);
 #undef QST
 #pragma unroll
@@ -707,15 +765,15 @@ RKFD_DEV void rkfd_phase_sweep3(const rkfdDevModel &m, const rkfdLds &L)
         double rhs[6], x[6], d[6], R[9], Rj[9], Row[9], p[3], qq[3];
 #pragma unroll
         for( int k=0; k<6; k++ ) rhs[k] = -L.U[6*i+k];
-        d_chol6_solve( &L.IA[36*i], rhs, x );
+        d_chol6_solve( &L.CHOL[36*rec.c1], rhs, x );
 #pragma unroll
         for( int k=0; k<6; k++ ){
           L.AC[6*i+k] = x[k];
           d[k] = x[k] - ( par >= 0 ? L.AC[6*par+k] : 0.0 ) - L.C[6*i+k];
         }
 #pragma unroll
-        for( int k=0; k<9; k++ ) R[k] = L.X[12*i+k];
-        p[0] = L.X[12*i+9]; p[1] = L.X[12*i+10]; p[2] = L.X[12*i+11];
+        for( int k=0; k<9; k++ ) R[k] = L.XF[12*rec.c1+k];
+        p[0] = L.XF[12*rec.c1+9]; p[1] = L.XF[12*rec.c1+10]; p[2] = L.XF[12*rec.c1+11];
         qq[0] = L.q[off+3]; qq[1] = L.q[off+4]; qq[2] = L.q[off+5];
         d_from_aa( qq, Rj );
         {
@@ -842,8 +900,8 @@ RKFD_DEV void rkfd_push_wrenches(const rkfdDevModel &m, const rkfdLds &L, const 
         w = lane == 3 ? f[0] : ( lane == 4 ? f[1] : f[2] );
       }
       const int cinf = L.CIp[j];
-      L.FE[6*RKFD_CI_A( cinf )+lane] += w;
-      L.FE[6*RKFD_CI_B( cinf )+lane] -= w;
+      L.PB[6*RKFD_CI_A( cinf )+lane] -= w;     /* bias force = -external force */
+      L.PB[6*RKFD_CI_B( cinf )+lane] += w;
     }
   }
   SYNC();
@@ -908,8 +966,10 @@ RKFD_DEV void rkfd_phase_penalty(const rkfdDevModel &m, const rkfdLds &L, bool d
 /* MLCP rigid branch (reference src/rkfd_mlcp.c:287-297).  Preconditions: sweep 2 (full) and
  * sweep 3 have been run with the wrenches applied so far (rkFDUpdateAccBias), so AC holds
  * the free accelerations and IA/U/MS hold Ia, U, Dinv.  Adds the contact wrenches to FE. */
-RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L)
+RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L, bool prof, unsigned long long *pc)
 {
+  unsigned long long q0 = prof ? RKFD_CLOCK() : 0ull, q1;
+#define MST(k) do{ if( prof ){ q1 = RKFD_CLOCK(); pc[k] += q1 - q0; q0 = q1; } }while(0)
   const int lane = LANE();
   const int nc = L.cnt[CNT_NRG];
   const int M = 3*nc;
@@ -955,6 +1015,7 @@ RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L)
     }
   }
   SYNC();
+  MST(14);
   /* probes: lane = column k = 3c+i; unit force along axis i at contact c, applied to the
    * owner link (+) and the other link (-).  Linear response only (delta form of
    * rkFDChainUpdateCachedABIPair + _rkFDSolverRelativeAcc, reference src/rkfd_mlcp.c:76-122). */
@@ -999,7 +1060,10 @@ RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L)
             double rhs[6];
 #pragma unroll
             for( int k=0; k<6; k++ ) rhs[k] = -dp[k];
-            d_chol6_solve( &L.IA[36*i], rhs, droot[s] );
+            /* float slot = rank of link i among the float joints (same order as the host's) */
+            int fs = 0;
+            for( int q=0; q<i; q++ ) fs += RKFD_LI_JT( L.LI[q] ) == RKFD_JOINT_FLOAT;
+            d_chol6_solve( &L.CHOL[36*fs], rhs, droot[s] );
             rootl[s] = i;
             break;
           }
@@ -1009,6 +1073,7 @@ RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L)
       }
     }
     SYNC();
+    MST(15);
     /* response at every target link, then the column entries */
     const int nt = L.cnt[CNT_NTGT];
     if( on ){
@@ -1061,6 +1126,7 @@ RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L)
     }
     SYNC();
   }
+  MST(6);
   /* projected Gauss-Seidel, fixed max_iter sweeps, no warm start (_rkFDSolverMLCP, reference
    * src/rkfd_mlcp.c:190-249).  lane = row; the residual res = b + A f is kept up to date. */
   {
@@ -1068,6 +1134,8 @@ RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L)
     const int row = on ? lane : 0;
     double res = on ? L.MB[row] : 0.0, f = 0.0;
     const double diag = on ? L.MA[row*ld+row] : 1.0;
+    /* reciprocal diagonal; tangential rows with |a_kk| < zTOL are frozen at 0 (reference :220-221) */
+    const double idiag = ( ( row % 3 ) != 0 && fabs( diag ) < RKFD_DEV_TOL ) ? 0.0 : 1.0/diag;
     /* friction coefficient of this row's contact (type as of the start of the solve) */
     double murow = 0.0;
     if( on ){
@@ -1077,8 +1145,8 @@ RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L)
     for( int it=0; it<m.max_iter; it++ ){
       for( int c=0; c<nc; c++ ){
         const int k = 3*c;
-        const double rk = BCAST( res, k ), fk = BCAST( f, k ), akk = BCAST( diag, k );
-        double ff = -( rk - akk*fk )/akk;
+        const double rk = BCAST( res, k ), fk = BCAST( f, k ), ikk = BCAST( idiag, k );
+        double ff = fk - rk*ikk;          /* = -( b + a.f - a_kk f_k ) / a_kk */
         if( ff < RKFD_DEV_TOL ) ff = 0.0;
         const double dl = ff - fk;
         if( lane == k ) f = ff;
@@ -1086,11 +1154,11 @@ RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L)
       }
       for( int c=0; c<nc; c++ ){
         const int k1 = 3*c+1, k2 = 3*c+2;
-        const double r1 = BCAST( res, k1 ), f1 = BCAST( f, k1 ), a11 = BCAST( diag, k1 );
-        const double r2 = BCAST( res, k2 ), f2 = BCAST( f, k2 ), a22 = BCAST( diag, k2 );
+        const double r1 = BCAST( res, k1 ), f1 = BCAST( f, k1 ), i11 = BCAST( idiag, k1 );
+        const double r2 = BCAST( res, k2 ), f2 = BCAST( f, k2 ), i22 = BCAST( idiag, k2 );
         const double fn = BCAST( f, 3*c );
-        const double ff0 = fabs( a11 ) < RKFD_DEV_TOL ? 0.0 : -( r1 - a11*f1 )/a11;
-        const double ff1 = fabs( a22 ) < RKFD_DEV_TOL ? 0.0 : -( r2 - a22*f2 )/a22;
+        const double ff0 = f1 - r1*i11;   /* idiag is 0 where |a_kk| < zTOL, f starts at 0 */
+        const double ff1 = f2 - r2*i22;
         const double fnorm = ff0*ff0 + ff1*ff1;
         const double mu = BCAST( murow, k1 );
         double fs = mu*fn; fs = fs*fs;
@@ -1107,6 +1175,7 @@ RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L)
     if( on ) L.MF[row] = f/dt;
   }
   SYNC();
+  MST(7);
   /* _rkFDSolverSetForce (reference src/rkfd_mlcp.c:252-284) incl. quirks Q1 / Q2 */
   if( lane < nc ){
     const int j = L.lrg[lane], ci = RKFD_CI_CI( L.CIp[j] );
@@ -1173,7 +1242,7 @@ RKFD_DEV int rkfd_evaluate(const rkfdDevModel &m, const rkfdLds &L, bool doUpRef
     STAMP(3);
     if( pass == 0 && L.cnt[CNT_NRG] > 0 ){
       if( m.solver == RKFD_SOLVER_MLCP ){
-        rkfd_phase_mlcp( m, L );
+        rkfd_phase_mlcp( m, L, prof, pc );
         STAMP(4);
         npass = 2;
       } else {
@@ -1228,7 +1297,7 @@ RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkfdDevState &st, int b
   const int lane = LANE();
   const int ND = m.ndof, NL = m.nlink, NC = m.ncand;
   rkfdLds L;
-  rkfd_lds_carve( &L, ldsbase, NL, ND, NC, 3*m.maxrg, m.nlevel );
+  rkfd_lds_carve( &L, ldsbase, NL, ND, NC, 3*m.maxrg, m.nlevel, m.npool, m.nfloat );
   if( lane == 0 ) L.cnt[CNT_OVF] = 0;
 
   /* load persistent state */
@@ -1237,6 +1306,7 @@ RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkfdDevState &st, int b
   if( lane < NL ){
     L.LI[lane]   = m.linfo[lane];
     L.CHI[lane]  = m.child_idx[lane];
+    L.PSL[lane]  = m.pslot[lane];
     L.min[lane]  = st.motor_in[(size_t)b*NL+lane];
     L.pivt[lane] = st.piv_type[(size_t)b*NL+lane];
     L.pivp[lane] = st.piv_prev[(size_t)b*NL+lane];
@@ -1335,11 +1405,10 @@ RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkfdDevState &st, int b
     }
   }
   if( st.dbg ){
-    /* debug dump: world frames (12/link) then spatial accelerations (6/link) */
+    /* debug dump: spatial accelerations (6/link) */
     if( lane < NL ){
       double *o = st.dbg + (size_t)b*st.dbg_stride;
-      for( int k=0; k<12; k++ ) o[12*lane+k] = L.X[12*lane+k];
-      for( int k=0; k<6; k++ ) o[12*NL+6*lane+k] = L.AC[6*lane+k];
+      for( int k=0; k<6; k++ ) o[6*lane+k] = L.AC[6*lane+k];
     }
   }
   if( lane == 0 && errflag ){

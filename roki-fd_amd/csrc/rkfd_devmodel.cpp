@@ -102,8 +102,8 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
    *   flag bit 0: the link's only child was processed in the NEXT iteration (sweep 2 runs the
    *               schedule backwards, so "previous" there) by the same slot
    *   flag bit 1: the link's parent was processed in the previous iteration by the same slot */
-  std::vector<int> sched;
-  int nsched = 0;
+  std::vector<int> sched, pslot( NL, -1 ), fslot( NL, -1 );
+  int nsched = 0, npool = 0, nfloat = 0;
   {
     std::vector<int> slot( NL, -1 ), iter( NL, -1 );
     std::vector<std::vector<int> > iters;          /* iteration -> 8 slots -> link */
@@ -134,10 +134,30 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
         iters.push_back( per_level[d][c] );
         nsched++;
       }
-    for( int t=0; t<nsched; t++ )
+    /* two empty iterations before and after the real ones: the sweeps prefetch records two
+     * iterations ahead and read the padding instead of branching */
+    /* pool slots: a non-float link with a parent needs its Ia staged in LDS unless the parent takes
+     * it over in registers (flag bit 0 of the parent's record) */
+    {
+      std::vector<int> carried( NL, 0 );
+      for( int i=0; i<NL; i++ ){
+        const int nchild = child_off[i+1] - child_off[i];
+        if( nchild == 1 ){
+          const int ch = child_idx[child_off[i]];
+          if( iter[ch] == iter[i]+1 && slot[ch] == slot[i] && m->jtype[ch] != RKFD_JOINT_FLOAT ) carried[ch] = 1;
+        }
+      }
+      for( int i=0; i<NL; i++ ){
+        pslot[i] = -1;
+        if( m->parent[i] >= 0 && m->jtype[i] != RKFD_JOINT_FLOAT && !carried[i] ) pslot[i] = npool++;
+        fslot[i] = -1;
+        if( m->jtype[i] == RKFD_JOINT_FLOAT ) fslot[i] = nfloat++;
+      }
+    }
+    for( int t=-2; t<nsched+2; t++ )
       for( int g=0; g<8; g++ ){
         int rec[8] = { -1, 0, 0, -1, -1, -1, -1, 0 };
-        const int i = iters[t][g];
+        const int i = ( t >= 0 && t < nsched ) ? iters[t][g] : -1;
         if( i >= 0 ){
           const int nchild = child_off[i+1] - child_off[i];
           int flags = 0;
@@ -148,7 +168,8 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
           if( m->parent[i] >= 0 && iter[m->parent[i]] == t-1 && slot[m->parent[i]] == g ) flags |= 2;
           rec[0] = i; rec[1] = linfo[i];
           rec[2] = nchild | ( flags << 8 );
-          for( int k=0; k<4 && k<nchild; k++ ) rec[3+k] = child_idx[child_off[i]+k];
+          rec[3] = pslot[i];      /* own pool slot (-1: handed over in registers / not needed) */
+          rec[4] = fslot[i];      /* float-joint slot (-1: not a float joint)                  */
           rec[7] = child_off[i];
         }
         sched.insert( sched.end(), rec, rec+8 );
@@ -161,7 +182,7 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   dm.nlink = NL; dm.ndof = ND; dm.ncand = NC; dm.nlevel = nlevel; dm.nround = nround; dm.nci = m->nci;
   dm.solver = m->solver; dm.max_iter = m->max_iter; dm.maxrg = max_rigid;
   dm.dt = m->dt; dm.fric_w = m->friction_weight;
-  dm.nsched = nsched;
+  dm.nsched = nsched; dm.npool = npool; dm.nfloat = nfloat;
   if( nround > RKFD_MAX_ROUND ) FAIL( "tree too deep" );
   /* record offsets first (the vector may reallocate), then resolve */
   struct Ent { const void **slot; size_t off; };
@@ -183,6 +204,7 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   PUT( pathlink, pathlink.data(), sizeof(int)*pathlink.size() );
   PUT( linfo, linfo.data(), sizeof(int)*NL ); PUT( cinfo, cinfo.data(), sizeof(int)*NC );
   PUT( sched, sched.data(), sizeof(int)*sched.size() );
+  PUT( pslot, pslot.data(), sizeof(int)*NL );
   PUT( cand_linkA, cA.data(), sizeof(int)*NC ); PUT( cand_linkB, cB.data(), sizeof(int)*NC );
   PUT( cand_foff, cfo.data(), sizeof(int)*NC ); PUT( cand_nf, cnf.data(), sizeof(int)*NC );
   PUT( cand_ci, cci.data(), sizeof(int)*NC ); PUT( cand_vert, cv.data(), sizeof(double)*3*NC );
@@ -201,9 +223,12 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   /* LDS bytes one instance needs (must match rkfd_lds_carve in rkfd_device.h) */
   {
     const size_t M = 3*(size_t)max_rigid;
-    const size_t dbl = (size_t)4*ND + (size_t)NL*100 + (size_t)NC*24 + M*(M+1) + 2*M + 2*(size_t)nlevel*M + 2*(size_t)NL;
+    size_t stage = (size_t)14*NL + (size_t)36*npool;            /* inertia staging + Ia pool ...   */
+    if( M*(M+1) > stage ) stage = M*(M+1);                       /* ... shared with the MLCP matrix */
+    const size_t dbl = (size_t)4*ND + (size_t)NL*( 8*6 + 4 ) + stage + (size_t)48*nfloat
+                     + (size_t)NC*24 + 2*M + 2*(size_t)nlevel*M + 2*(size_t)NL;
     const size_t ints = (size_t)5*NC + 8 + (size_t)ND + (size_t)NL      /* act typ lrg lel tgt, cnt, dofkind, pivt */
-                      + 2*(size_t)NL + 2*(size_t)NC + ( max_rigid > 0 ? (size_t)NL*nlevel : 0 ); /* LI, CHI, CIp, CFO, PL */
+                      + 3*(size_t)NL + 2*(size_t)NC + ( max_rigid > 0 ? (size_t)NL*nlevel : 0 ); /* LI, CHI, PSL, CIp, CFO, PL */
     out->lds_bytes = dbl*sizeof(double) + ints*sizeof(int);
     out->lds_bytes = ( out->lds_bytes + 15 ) & ~(size_t)15;
   }
@@ -223,7 +248,7 @@ extern "C" void rkfd_devmodel_rebase(rkfdDevModel *dm, const void *from, const v
   RB(parent); RB(jtype); RB(dofoff); RB(mtype); RB(depth); RB(is_static);
   RB(org); RB(mass); RB(com); RB(inertia); RB(stiff); RB(visc); RB(coulomb); RB(sfric);
   RB(mot_k); RB(mot_admit); RB(mot_vmax); RB(mot_vmin); RB(mot_gear); RB(mot_inertia);
-  RB(anc); RB(level_off); RB(level_link); RB(child_off); RB(child_idx); RB(pathlink); RB(linfo); RB(sched); RB(cinfo);
+  RB(anc); RB(level_off); RB(level_link); RB(child_off); RB(child_idx); RB(pathlink); RB(linfo); RB(sched); RB(cinfo); RB(pslot);
   RB(cand_linkA); RB(cand_linkB); RB(cand_foff); RB(cand_nf); RB(cand_ci); RB(cand_vert); RB(planes);
   RB(ci_type); RB(ci_sf); RB(ci_kf); RB(ci_k); RB(ci_l); RB(ci_e); RB(ci_v);
 #undef RB

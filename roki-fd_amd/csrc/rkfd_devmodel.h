@@ -38,6 +38,9 @@ typedef struct {
    *   {link (-1 none), linfo[link], nchild, child0..child3, child_off[link]}            */
   int nsched;
   const int *sched;
+  int npool;             /* links whose articulated inertia must be staged in LDS for a gathering parent */
+  int nfloat;            /* float joints (each owns a 6x6 Cholesky slot and a saved frame)          */
+  const int *pslot;      /* [nlink] pool slot of the link, -1 when its Ia is handed over in registers */
   /* per candidate contact vertex */
   const int *cand_linkA, *cand_linkB, *cand_foff, *cand_nf, *cand_ci;
   const double *cand_vert; /* [ncand*3] vertex in link A's frame                         */

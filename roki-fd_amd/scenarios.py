@@ -146,7 +146,7 @@ def config3(batch=4096, model="humanoid30.ztk"):
     return dict(name="config3_humanoid_penalty", world=w, dis=dis, vel=vel, max_rigid=0, steps=1000)
 
 
-def config4(batch=4096, model="humanoid30.ztk", max_rigid=16):
+def config4(batch=4096, model="humanoid30.ztk", max_rigid=8):
     """30-DoF humanoid on flat ground, MLCP plugin, RIGID ground contact."""
     w, dis, vel = _humanoid(batch, "contact_rigid.ztk", B.SOLVER_MLCP, 0x5EED0004, model)
     return dict(name="config4_humanoid_mlcp", world=w, dis=dis, vel=vel, max_rigid=max_rigid, steps=1000)
