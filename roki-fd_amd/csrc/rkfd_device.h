@@ -234,18 +234,20 @@ typedef struct {
   double *POOL;                   /* [npool*36] Ia of links whose parent gathers through LDS */
   double *CHOL;                   /* [nfloat*36] articulated inertia / Cholesky factor of float joints */
   double *XF;                     /* [nfloat*12] world frame of float-joint links         */
-  double *CX, *AX, *RW, *PRO, *REF, *CF; /* per candidate: 3, 9, 3, 3, 3, 3               */
+  double *CX, *AX, *RW, *PRO;     /* per ACTIVE contact slot (capacity maxact): 3, 9, 3, 3 */
+  double *REF, *CF;               /* per candidate: stick anchor (state), contact force (output) */
   double *MA, *MB, *MF, *PU;      /* MLCP: [M*(M+1)] (ALIASES IST|POOL), [M], [M], [2*nlevel*M] */
   int *act, *typ, *lrg, *lel, *tgt, *cnt, *dofkind, *pivt;
+  int *asl;                       /* [NC] active-contact slot of a candidate              */
   int *LI;                        /* [NL] packed link info (RKFD_LI_*)                    */
   int *CIp, *CFO;                 /* [NC] packed candidate info, first plane              */
   int *CHI;                       /* [NL] children lists (CSR values; offsets in the schedule)     */
   int *PSL;                       /* [NL] pool slot of a link (-1 none)                   */
-  int *PL;                        /* [NL*nlevel] ancestor at depth d (MLCP only)          */
+  unsigned char *PL;              /* [NL*nlevel] ancestor at depth d (MLCP only), one byte each */
   double *pivp, *min;             /* [NL] pivot prev torque, motor input                  */
 } rkfdLds;
 
-RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int M, int nlevel, int npool, int nfloat)
+RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int M, int nlevel, int npool, int nfloat, int maxact, int nside)
 /* must match the byte count computed in rkfd_devmodel.cpp */
 {
   double *d = (double *)base;
@@ -260,16 +262,16 @@ RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int
     d += stage;
   }
   L->CHOL = d; d += 36*nfloat; L->XF = d; d += 12*nfloat;
-  L->CX = d; d += NC*3; L->AX = d; d += NC*9; L->RW = d; d += NC*3; L->PRO = d; d += NC*3;
+  L->CX = d; d += maxact*3; L->AX = d; d += maxact*9; L->RW = d; d += maxact*3; L->PRO = d; d += maxact*3;
   L->REF = d; d += NC*3; L->CF = d; d += NC*3;
-  L->MB = d; d += M; L->MF = d; d += M; L->PU = d; d += 2*nlevel*M;
+  L->MB = d; d += M; L->MF = d; d += M; L->PU = d; d += nside*nlevel*M;
   L->pivp = d; d += NL; L->min = d; d += NL;
   int *ip = (int *)d;
   L->act = ip; ip += NC; L->typ = ip; ip += NC; L->lrg = ip; ip += NC; L->lel = ip; ip += NC;
   L->tgt = ip; ip += NC; L->cnt = ip; ip += 8; L->dofkind = ip; ip += ND; L->pivt = ip; ip += NL;
   L->LI = ip; ip += NL; L->CIp = ip; ip += NC; L->CFO = ip; ip += NC; L->CHI = ip; ip += NL;
-  L->PSL = ip; ip += NL;
-  L->PL = ip;
+  L->PSL = ip; ip += NL; L->asl = ip; ip += NC;
+  L->PL = (unsigned char *)ip;
 }
 
 /* counters in L->cnt */
@@ -821,11 +823,15 @@ RKFD_DEV void rkfd_phase_collision(const rkfdDevModel &m, const rkfdLds &L)
   const int lane = LANE();
   const bool on = lane < m.ncand;
   const int j = on ? lane : 0;
-  int is_act = 0, is_rg = 0, is_el = 0;
+  int is_act = 0, is_rg = 0, is_el = 0, fbest = -1;
+  double x[3] = {0,0,0}, y[3] = {0,0,0}, smax = -HUGE_VAL, RB[9], pB[3];
+  const int cinf = L.CIp[j];
+#pragma unroll
+  for( int k=0; k<9; k++ ) RB[k] = 0;
+  pB[0] = pB[1] = pB[2] = 0;
   if( on ){
-    const int cinf = L.CIp[j];
     const int la = RKFD_CI_A( cinf ), lb = RKFD_CI_B( cinf );
-    double RA[9], pA[3], RB[9], pB[3], vl[3], x[3], y[3], rr[3];
+    double RA[9], pA[3], vl[3], rr[3];
 #pragma unroll
     for( int k=0; k<9; k++ ){ RA[k] = L.X[12*la+k]; RB[k] = L.X[12*lb+k]; }
 #pragma unroll
@@ -834,19 +840,27 @@ RKFD_DEV void rkfd_phase_collision(const rkfdDevModel &m, const rkfdLds &L)
     x[0] += pA[0]; x[1] += pA[1]; x[2] += pA[2];
     rr[0] = x[0]-pB[0]; rr[1] = x[1]-pB[1]; rr[2] = x[2]-pB[2];
     d_tmulv( RB, rr, y );
-    double smax = -HUGE_VAL; int fbest = -1;
     const int f0 = L.CFO[j], nf = RKFD_CI_NF( cinf );
     for( int f=f0; f<f0+nf; f++ ){
-      const double s = m.planes[4*f]*y[0] + m.planes[4*f+1]*y[1] + m.planes[4*f+2]*y[2] - m.planes[4*f+3];
-      if( s > smax ){ smax = s; fbest = f; }
+      const double sd = m.planes[4*f]*y[0] + m.planes[4*f+1]*y[1] + m.planes[4*f+2]*y[2] - m.planes[4*f+3];
+      if( sd > smax ){ smax = sd; fbest = f; }
     }
-    L.CX[3*j] = x[0]; L.CX[3*j+1] = x[1]; L.CX[3*j+2] = x[2];
     L.CF[3*j] = 0; L.CF[3*j+1] = 0; L.CF[3*j+2] = 0;
-    if( fbest >= 0 && smax < RKFD_DEV_TOL ){
-      double n[3] = { m.planes[4*fbest], m.planes[4*fbest+1], m.planes[4*fbest+2] };
-      double pro[3] = { y[0]-smax*n[0], y[1]-smax*n[1], y[2]-smax*n[2] };
+    is_act = fbest >= 0 && smax < RKFD_DEV_TOL;
+  }
+  /* active contacts get a slot in the per-contact arrays (capacity m.maxact) in candidate order */
+  const unsigned long long below = lane == 0 ? 0ull : ( ~0ull >> ( 64-lane ) );
+  const unsigned long long mact = BALLOT( is_act );
+  const int slot = __builtin_popcountll( mact & below );
+  if( is_act && slot >= m.maxact ){ is_act = 0; }
+  if( on ){
+    if( is_act ){
+      const double n[3] = { m.planes[4*fbest], m.planes[4*fbest+1], m.planes[4*fbest+2] };
+      const double pro[3] = { y[0]-smax*n[0], y[1]-smax*n[1], y[2]-smax*n[2] };
       double nw[3], t1[3], t2[3], ref[3], rw[3];
-      L.PRO[3*j] = pro[0]; L.PRO[3*j+1] = pro[1]; L.PRO[3*j+2] = pro[2];
+      L.asl[j] = slot;
+      L.CX[3*slot] = x[0]; L.CX[3*slot+1] = x[1]; L.CX[3*slot+2] = x[2];
+      L.PRO[3*slot] = pro[0]; L.PRO[3*slot+1] = pro[1]; L.PRO[3*slot+2] = pro[2];
       d_mulv( RB, n, nw );
       if( !L.act[j] ){
         L.act[j] = 1; L.typ[j] = RKFD_SF;
@@ -854,26 +868,25 @@ RKFD_DEV void rkfd_phase_collision(const rkfdDevModel &m, const rkfdLds &L)
       }
       ref[0] = L.REF[3*j]; ref[1] = L.REF[3*j+1]; ref[2] = L.REF[3*j+2];
       d_mulv( RB, ref, rw );
-      L.RW[3*j] = rw[0]+pB[0]; L.RW[3*j+1] = rw[1]+pB[1]; L.RW[3*j+2] = rw[2]+pB[2];
+      L.RW[3*slot] = rw[0]+pB[0]; L.RW[3*slot+1] = rw[1]+pB[1]; L.RW[3*slot+2] = rw[2]+pB[2];
       d_ortho_space( nw, t1, t2 );
 #pragma unroll
-      for( int k=0; k<3; k++ ){ L.AX[9*j+k] = nw[k]; L.AX[9*j+3+k] = t1[k]; L.AX[9*j+6+k] = t2[k]; }
-      is_act = 1;
+      for( int k=0; k<3; k++ ){ L.AX[9*slot+k] = nw[k]; L.AX[9*slot+3+k] = t1[k]; L.AX[9*slot+6+k] = t2[k]; }
       const int ct = m.ci_type[RKFD_CI_CI( cinf )];
       is_rg = ct == RKFD_CONTACT_RIGID; is_el = ct == RKFD_CONTACT_ELASTIC;
     } else {
       L.act[j] = 0;
+      L.asl[j] = 0;
     }
   }
-  (void)is_act;
   /* ordered compaction */
   const unsigned long long mrg = BALLOT( is_rg ), mel = BALLOT( is_el );
-  const unsigned long long below = lane == 0 ? 0ull : ( ~0ull >> ( 64-lane ) );
   if( is_rg && __builtin_popcountll( mrg & below ) < m.maxrg ) L.lrg[ __builtin_popcountll( mrg & below ) ] = j;
   if( is_el ) L.lel[ __builtin_popcountll( mel & below ) ] = j;
   if( lane == 0 ){
     int nrg = __builtin_popcountll( mrg );
     if( nrg > m.maxrg ){ nrg = m.maxrg; L.cnt[CNT_OVF] = 1; }   /* contact capacity exceeded */
+    if( __builtin_popcountll( mact ) > m.maxact ) L.cnt[CNT_OVF] = 1;
     L.cnt[CNT_NRG] = nrg;
     L.cnt[CNT_NEL] = __builtin_popcountll( mel );
   }
@@ -891,7 +904,7 @@ RKFD_DEV void rkfd_push_wrenches(const rkfdDevModel &m, const rkfdLds &L, const 
     for( int e=0; e<n; e++ ){
       const int j = list[e];
       const double f[3] = { L.CF[3*j], L.CF[3*j+1], L.CF[3*j+2] };
-      const double x[3] = { L.CX[3*j], L.CX[3*j+1], L.CX[3*j+2] };
+      const double x[3] = { L.CX[3*L.asl[j]], L.CX[3*L.asl[j]+1], L.CX[3*L.asl[j]+2] };
       double w;
       if( lane < 3 ){
         double t[3]; d_cross( x, f, t );
@@ -911,7 +924,7 @@ RKFD_DEV void rkfd_push_wrenches(const rkfdDevModel &m, const rkfdLds &L, const 
 RKFD_DEV void d_modify_friction(const rkfdDevModel &m, const rkfdLds &L, int j, const double *vr, double *f, bool doUpRef)
 {
   const int ci = RKFD_CI_CI( L.CIp[j] );
-  const double *ax = &L.AX[9*j];
+  const double *ax = &L.AX[9*L.asl[j]];
   const double fn = d_dot( f, ax );
   const double f1 = d_dot( f, ax+3 ), f2 = d_dot( f, ax+6 );
   const double fs = sqrt( f1*f1 + f2*f2 );
@@ -927,7 +940,7 @@ RKFD_DEV void d_modify_friction(const rkfdDevModel &m, const rkfdLds &L, int j, 
     }
     if( doUpRef ){
       L.typ[j] = RKFD_KF;
-      L.REF[3*j] = L.PRO[3*j]; L.REF[3*j+1] = L.PRO[3*j+1]; L.REF[3*j+2] = L.PRO[3*j+2];
+      L.REF[3*j] = L.PRO[3*L.asl[j]]; L.REF[3*j+1] = L.PRO[3*L.asl[j]+1]; L.REF[3*j+2] = L.PRO[3*L.asl[j]+2];
     }
   } else {
     if( doUpRef ) L.typ[j] = RKFD_SF;
@@ -941,7 +954,7 @@ RKFD_DEV void rkfd_phase_penalty(const rkfdDevModel &m, const rkfdLds &L, bool d
   const int nel = L.cnt[CNT_NEL];
   if( lane < nel ){
     const int j = L.lel[lane], cinf = L.CIp[j], ci = RKFD_CI_CI( cinf );
-    const double x[3] = { L.CX[3*j], L.CX[3*j+1], L.CX[3*j+2] };
+    const double x[3] = { L.CX[3*L.asl[j]], L.CX[3*L.asl[j]+1], L.CX[3*L.asl[j]+2] };
     double va[3], vb[3], vr[3], f[3];
     d_point_vel( &L.V[6*RKFD_CI_A( cinf )], x, va );
     d_point_vel( &L.V[6*RKFD_CI_B( cinf )], x, vb );
@@ -949,9 +962,9 @@ RKFD_DEV void rkfd_phase_penalty(const rkfdDevModel &m, const rkfdLds &L, bool d
 #pragma unroll
     for( int k=0; k<3; k++ ){
       vr[k] = va[k]-vb[k];
-      f[k] = -E*( x[k]-L.RW[3*j+k] ) + kv*vr[k];
+      f[k] = -E*( x[k]-L.RW[3*L.asl[j]+k] ) + kv*vr[k];
     }
-    if( d_dot( f, &L.AX[9*j] ) < 0.0 ){
+    if( d_dot( f, &L.AX[9*L.asl[j]] ) < 0.0 ){
       f[0] = f[1] = f[2] = 0;
     } else {
       d_modify_friction( m, L, j, vr, f, doUpRef );
@@ -996,19 +1009,19 @@ RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L, bool prof
   if( lane < nc ){
     const int j = L.lrg[lane], cinf = L.CIp[j], ci = RKFD_CI_CI( cinf );
     const int la = RKFD_CI_A( cinf ), lb = RKFD_CI_B( cinf );
-    const double x[3] = { L.CX[3*j], L.CX[3*j+1], L.CX[3*j+2] };
+    const double x[3] = { L.CX[3*L.asl[j]], L.CX[3*L.asl[j]+1], L.CX[3*L.asl[j]+2] };
     double aa[3], ab[3], va[3], vb[3], ra[3], rv[3], d[3];
     d_point_acc( &L.AC[6*la], &L.V[6*la], x, aa );
     d_point_acc( &L.AC[6*lb], &L.V[6*lb], x, ab );
     d_point_vel( &L.V[6*la], x, va );
     d_point_vel( &L.V[6*lb], x, vb );
 #pragma unroll
-    for( int k=0; k<3; k++ ){ ra[k] = aa[k]-ab[k]; rv[k] = va[k]-vb[k]; d[k] = x[k]-L.RW[3*j+k]; }
+    for( int k=0; k<3; k++ ){ ra[k] = aa[k]-ab[k]; rv[k] = va[k]-vb[k]; d[k] = x[k]-L.RW[3*L.asl[j]+k]; }
     const double mu = L.typ[j] == RKFD_SF ? m.ci_sf[ci] : m.ci_kf[ci];
     const double K = m.ci_k[ci];
 #pragma unroll
     for( int i=0; i<3; i++ ){
-      const double *ax = &L.AX[9*j+3*i];
+      const double *ax = &L.AX[9*L.asl[j]+3*i];
       double b = d_dot( ax, ra )*dt + d_dot( rv, ax );
       b += ( i == 0 ? K : K*mu )*d_dot( d, ax );
       L.MB[3*lane+i] = b;
@@ -1028,8 +1041,8 @@ RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L, bool prof
     double W[6], droot[2][6];
     int rootl[2] = { -1, -1 };
     {
-      const double x[3] = { L.CX[3*j], L.CX[3*j+1], L.CX[3*j+2] };
-      const double *ax = &L.AX[9*j+3*ia];
+      const double x[3] = { L.CX[3*L.asl[j]], L.CX[3*L.asl[j]+1], L.CX[3*L.asl[j]+2] };
+      const double *ax = &L.AX[9*L.asl[j]+3*ia];
       d_cross( x, ax, W );
       W[3] = ax[0]; W[4] = ax[1]; W[5] = ax[2];
     }
@@ -1051,7 +1064,7 @@ RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L, bool prof
             double du = 0;
 #pragma unroll
             for( int k=0; k<6; k++ ) du -= L.S[6*i+k]*dp[k];
-            L.PU[( s*NLV + RKFD_LI_DEPTH( lii ) )*M + lane] = du;
+            L.PU[( ( m.nside == 2 ? s : 0 )*NLV + RKFD_LI_DEPTH( lii ) )*M + lane] = du;
             const double t = du*L.MS[4*i+0];
 #pragma unroll
             for( int k=0; k<6; k++ ) dp[k] += L.U[6*i+k]*t;
@@ -1096,7 +1109,7 @@ RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L, bool prof
             for( int k=0; k<6; k++ ) da[k] = droot[side][k];
           } else if( jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM ){
             const bool onpath = d <= dsrc && L.PL[src*NLV+d] == i;
-            double du = onpath ? L.PU[( side*NLV + d )*M + lane] : 0.0;
+            double du = onpath ? L.PU[( ( m.nside == 2 ? side : 0 )*NLV + d )*M + lane] : 0.0;
             double ua = 0;
 #pragma unroll
             for( int k=0; k<6; k++ ) ua += L.U[6*i+k]*da[k];
@@ -1112,13 +1125,13 @@ RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L, bool prof
           if( RKFD_CI_A( L.CIp[jr] ) == T ) sgn = 1.0;
           else if( RKFD_CI_B( L.CIp[jr] ) == T ) sgn = -1.0;
           if( sgn == 0 ) continue;
-          const double x[3] = { L.CX[3*jr], L.CX[3*jr+1], L.CX[3*jr+2] };
+          const double x[3] = { L.CX[3*L.asl[jr]], L.CX[3*L.asl[jr]+1], L.CX[3*L.asl[jr]+2] };
           double t3[3], acc[3];
           d_cross( da, x, t3 );
           acc[0] = da[3]+t3[0]; acc[1] = da[4]+t3[1]; acc[2] = da[5]+t3[2];
 #pragma unroll
           for( int i2=0; i2<3; i2++ )
-            L.MA[(3*r+i2)*ld+lane] += sgn*d_dot( &L.AX[9*jr+3*i2], acc );
+            L.MA[(3*r+i2)*ld+lane] += sgn*d_dot( &L.AX[9*L.asl[jr]+3*i2], acc );
         }
       }
       /* relaxation on the diagonal */
@@ -1183,14 +1196,14 @@ RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L, bool prof
 #pragma unroll
     for( int i=0; i<3; i++ ){
       const double fi = L.MF[3*lane+i];
-      fw[0] += fi*L.AX[9*j+3*i]; fw[1] += fi*L.AX[9*j+3*i+1]; fw[2] += fi*L.AX[9*j+3*i+2];
+      fw[0] += fi*L.AX[9*L.asl[j]+3*i]; fw[1] += fi*L.AX[9*L.asl[j]+3*i+1]; fw[2] += fi*L.AX[9*L.asl[j]+3*i+2];
     }
     L.CF[3*j] = fw[0]; L.CF[3*j+1] = fw[1]; L.CF[3*j+2] = fw[2];
     const double fn = fw[0], fs = sqrt( fw[1]*fw[1] + fw[2]*fw[2] );
     const double mu = L.typ[j] == RKFD_SF ? m.ci_sf[ci] : m.ci_kf[ci];
     if( fs > mu*fn - RKFD_DEV_TOL ){
       L.typ[j] = RKFD_KF;
-      L.REF[3*j] = L.PRO[3*j]; L.REF[3*j+1] = L.PRO[3*j+1]; L.REF[3*j+2] = L.PRO[3*j+2];
+      L.REF[3*j] = L.PRO[3*L.asl[j]]; L.REF[3*j+1] = L.PRO[3*L.asl[j]+1]; L.REF[3*j+2] = L.PRO[3*L.asl[j]+2];
     } else {
       L.typ[j] = RKFD_SF;
     }
@@ -1297,7 +1310,7 @@ RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkfdDevState &st, int b
   const int lane = LANE();
   const int ND = m.ndof, NL = m.nlink, NC = m.ncand;
   rkfdLds L;
-  rkfd_lds_carve( &L, ldsbase, NL, ND, NC, 3*m.maxrg, m.nlevel, m.npool, m.nfloat );
+  rkfd_lds_carve( &L, ldsbase, NL, ND, NC, 3*m.maxrg, m.nlevel, m.npool, m.nfloat, m.maxact, m.nside );
   if( lane == 0 ) L.cnt[CNT_OVF] = 0;
 
   /* load persistent state */
@@ -1312,7 +1325,7 @@ RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkfdDevState &st, int b
     L.pivp[lane] = st.piv_prev[(size_t)b*NL+lane];
   }
   if( m.maxrg > 0 ){
-    for( int k=lane; k<NL*m.nlevel; k+=RKFD_WAVE ) L.PL[k] = m.pathlink[k];
+    for( int k=lane; k<NL*m.nlevel; k+=RKFD_WAVE ) L.PL[k] = (unsigned char)m.pathlink[k];
   }
   if( lane < NC ){
     L.CIp[lane] = m.cinfo[lane];

@@ -183,6 +183,13 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   dm.solver = m->solver; dm.max_iter = m->max_iter; dm.maxrg = max_rigid;
   dm.dt = m->dt; dm.fric_w = m->friction_weight;
   dm.nsched = nsched; dm.npool = npool; dm.nfloat = nfloat;
+  /* contact capacities */
+  int maxact = NC < 16 ? NC : 16;
+  if( max_rigid > maxact ) maxact = max_rigid < NC ? max_rigid : NC;
+  int nside = 1;
+  for( int j=0; j<NC; j++ )
+    if( m->ci_type[cci[j]] == RKFD_CONTACT_RIGID && !is_static[cA[j]] && !is_static[cB[j]] ) nside = 2;
+  dm.maxact = maxact; dm.nside = nside;
   if( nround > RKFD_MAX_ROUND ) FAIL( "tree too deep" );
   /* record offsets first (the vector may reallocate), then resolve */
   struct Ent { const void **slot; size_t off; };
@@ -226,9 +233,9 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
     size_t stage = (size_t)14*NL + (size_t)36*npool;            /* inertia staging + Ia pool ...   */
     if( M*(M+1) > stage ) stage = M*(M+1);                       /* ... shared with the MLCP matrix */
     const size_t dbl = (size_t)4*ND + (size_t)NL*( 8*6 + 4 ) + stage + (size_t)48*nfloat
-                     + (size_t)NC*24 + 2*M + 2*(size_t)nlevel*M + 2*(size_t)NL;
+                     + (size_t)maxact*18 + (size_t)NC*6 + 2*M + (size_t)nside*nlevel*M + 2*(size_t)NL;
     const size_t ints = (size_t)5*NC + 8 + (size_t)ND + (size_t)NL      /* act typ lrg lel tgt, cnt, dofkind, pivt */
-                      + 3*(size_t)NL + 2*(size_t)NC + ( max_rigid > 0 ? (size_t)NL*nlevel : 0 ); /* LI, CHI, PSL, CIp, CFO, PL */
+                      + 3*(size_t)NL + 3*(size_t)NC + ( max_rigid > 0 ? ( (size_t)NL*nlevel + 3 )/4 : 0 ); /* LI, CHI, PSL, CIp, CFO, asl, PL (bytes) */
     out->lds_bytes = dbl*sizeof(double) + ints*sizeof(int);
     out->lds_bytes = ( out->lds_bytes + 15 ) & ~(size_t)15;
   }

@@ -19,6 +19,8 @@ typedef struct {
   int nround;            /* pointer-jumping rounds = ceil(log2(nlevel))                 */
   int nci;
   int solver, max_iter;
+  int maxact;            /* capacity: active contact vertices (rigid + elastic) per instance        */
+  int nside;             /* 1 when every rigid-capable pair has a static cell (probe walks one-sided) else 2 */
   int maxrg;             /* capacity: rigid contact vertices solved per instance (3*maxrg <= 64) */
   double dt, fric_w;
   /* per link */
