@@ -31,7 +31,7 @@ const char *rkfdHipLastError(void);
  * Replaces, for the whole batch: rkFDCreate + rkFDChainReg* + rkFDUpdateInit's allocations
  * (reference src/rkfd_sim.c:32-54,188-235,552-558; rkFDCDUpdateInit src/rkfd_cd.c:22-31;
  * plugin _init src/rkfd_mlcp.c:312-325).  max_rigid = capacity of rigid contact vertices
- * solved per instance (3*max_rigid <= 64); exceeding it at run time is reported as an error
+ * solved per instance (3*max_rigid <= 128); exceeding it at run time is reported as an error
  * by rkfdBatchStatus. */
 rkfdBatch *rkfdBatchCreate(const rkfdModel *m, int batch, int device, int max_rigid);
 void rkfdBatchDestroy(rkfdBatch *b);

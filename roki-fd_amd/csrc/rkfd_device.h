@@ -821,74 +821,83 @@ RKFD_DEV void d_point_acc(const double *A, const double *V, const double *x, dou
 RKFD_DEV void rkfd_phase_collision(const rkfdDevModel &m, const rkfdLds &L)
 {
   const int lane = LANE();
-  const bool on = lane < m.ncand;
-  const int j = on ? lane : 0;
-  int is_act = 0, is_rg = 0, is_el = 0, fbest = -1;
-  double x[3] = {0,0,0}, y[3] = {0,0,0}, smax = -HUGE_VAL, RB[9], pB[3];
-  const int cinf = L.CIp[j];
-#pragma unroll
-  for( int k=0; k<9; k++ ) RB[k] = 0;
-  pB[0] = pB[1] = pB[2] = 0;
-  if( on ){
-    const int la = RKFD_CI_A( cinf ), lb = RKFD_CI_B( cinf );
-    double RA[9], pA[3], vl[3], rr[3];
-#pragma unroll
-    for( int k=0; k<9; k++ ){ RA[k] = L.X[12*la+k]; RB[k] = L.X[12*lb+k]; }
-#pragma unroll
-    for( int k=0; k<3; k++ ){ pA[k] = L.X[12*la+9+k]; pB[k] = L.X[12*lb+9+k]; vl[k] = m.cand_vert[3*j+k]; }
-    d_mulv( RA, vl, x );
-    x[0] += pA[0]; x[1] += pA[1]; x[2] += pA[2];
-    rr[0] = x[0]-pB[0]; rr[1] = x[1]-pB[1]; rr[2] = x[2]-pB[2];
-    d_tmulv( RB, rr, y );
-    const int f0 = L.CFO[j], nf = RKFD_CI_NF( cinf );
-    for( int f=f0; f<f0+nf; f++ ){
-      const double sd = m.planes[4*f]*y[0] + m.planes[4*f+1]*y[1] + m.planes[4*f+2]*y[2] - m.planes[4*f+3];
-      if( sd > smax ){ smax = sd; fbest = f; }
-    }
-    L.CF[3*j] = 0; L.CF[3*j+1] = 0; L.CF[3*j+2] = 0;
-    is_act = fbest >= 0 && smax < RKFD_DEV_TOL;
-  }
-  /* active contacts get a slot in the per-contact arrays (capacity m.maxact) in candidate order */
   const unsigned long long below = lane == 0 ? 0ull : ( ~0ull >> ( 64-lane ) );
-  const unsigned long long mact = BALLOT( is_act );
-  const int slot = __builtin_popcountll( mact & below );
-  if( is_act && slot >= m.maxact ){ is_act = 0; }
-  if( on ){
-    if( is_act ){
-      const double n[3] = { m.planes[4*fbest], m.planes[4*fbest+1], m.planes[4*fbest+2] };
-      const double pro[3] = { y[0]-smax*n[0], y[1]-smax*n[1], y[2]-smax*n[2] };
-      double nw[3], t1[3], t2[3], ref[3], rw[3];
-      L.asl[j] = slot;
-      L.CX[3*slot] = x[0]; L.CX[3*slot+1] = x[1]; L.CX[3*slot+2] = x[2];
-      L.PRO[3*slot] = pro[0]; L.PRO[3*slot+1] = pro[1]; L.PRO[3*slot+2] = pro[2];
-      d_mulv( RB, n, nw );
-      if( !L.act[j] ){
-        L.act[j] = 1; L.typ[j] = RKFD_SF;
-        L.REF[3*j] = pro[0]; L.REF[3*j+1] = pro[1]; L.REF[3*j+2] = pro[2];
-      }
-      ref[0] = L.REF[3*j]; ref[1] = L.REF[3*j+1]; ref[2] = L.REF[3*j+2];
-      d_mulv( RB, ref, rw );
-      L.RW[3*slot] = rw[0]+pB[0]; L.RW[3*slot+1] = rw[1]+pB[1]; L.RW[3*slot+2] = rw[2]+pB[2];
-      d_ortho_space( nw, t1, t2 );
+  int base_act = 0, base_rg = 0, base_el = 0, ovf = 0;
+  /* candidates are swept 64 at a time; slots and list positions keep candidate order */
+  for( int c0=0; c0<m.ncand; c0+=RKFD_WAVE ){
+    const bool on = c0+lane < m.ncand;
+    const int j = on ? c0+lane : 0;
+    int is_act = 0, is_rg = 0, is_el = 0, fbest = -1;
+    double x[3] = {0,0,0}, y[3] = {0,0,0}, smax = -HUGE_VAL, RB[9], pB[3];
+    const int cinf = L.CIp[j];
 #pragma unroll
-      for( int k=0; k<3; k++ ){ L.AX[9*slot+k] = nw[k]; L.AX[9*slot+3+k] = t1[k]; L.AX[9*slot+6+k] = t2[k]; }
-      const int ct = m.ci_type[RKFD_CI_CI( cinf )];
-      is_rg = ct == RKFD_CONTACT_RIGID; is_el = ct == RKFD_CONTACT_ELASTIC;
-    } else {
-      L.act[j] = 0;
-      L.asl[j] = 0;
+    for( int k=0; k<9; k++ ) RB[k] = 0;
+    pB[0] = pB[1] = pB[2] = 0;
+    if( on ){
+      const int la = RKFD_CI_A( cinf ), lb = RKFD_CI_B( cinf );
+      double RA[9], pA[3], vl[3], rr[3];
+#pragma unroll
+      for( int k=0; k<9; k++ ){ RA[k] = L.X[12*la+k]; RB[k] = L.X[12*lb+k]; }
+#pragma unroll
+      for( int k=0; k<3; k++ ){ pA[k] = L.X[12*la+9+k]; pB[k] = L.X[12*lb+9+k]; vl[k] = m.cand_vert[3*j+k]; }
+      d_mulv( RA, vl, x );
+      x[0] += pA[0]; x[1] += pA[1]; x[2] += pA[2];
+      rr[0] = x[0]-pB[0]; rr[1] = x[1]-pB[1]; rr[2] = x[2]-pB[2];
+      d_tmulv( RB, rr, y );
+      const int f0 = L.CFO[j], nf = RKFD_CI_NF( cinf );
+      for( int f=f0; f<f0+nf; f++ ){
+        const double sd = m.planes[4*f]*y[0] + m.planes[4*f+1]*y[1] + m.planes[4*f+2]*y[2] - m.planes[4*f+3];
+        if( sd > smax ){ smax = sd; fbest = f; }
+      }
+      L.CF[3*j] = 0; L.CF[3*j+1] = 0; L.CF[3*j+2] = 0;
+      is_act = fbest >= 0 && smax < RKFD_DEV_TOL;
     }
+    /* active contacts get a slot in the per-contact arrays (capacity m.maxact) in candidate order */
+    const unsigned long long mact = BALLOT( is_act );
+    const int slot = base_act + __builtin_popcountll( mact & below );
+    if( is_act && slot >= m.maxact ){ is_act = 0; }
+    if( on ){
+      if( is_act ){
+        const double n[3] = { m.planes[4*fbest], m.planes[4*fbest+1], m.planes[4*fbest+2] };
+        const double pro[3] = { y[0]-smax*n[0], y[1]-smax*n[1], y[2]-smax*n[2] };
+        double nw[3], t1[3], t2[3], ref[3], rw[3];
+        L.asl[j] = slot;
+        L.CX[3*slot] = x[0]; L.CX[3*slot+1] = x[1]; L.CX[3*slot+2] = x[2];
+        L.PRO[3*slot] = pro[0]; L.PRO[3*slot+1] = pro[1]; L.PRO[3*slot+2] = pro[2];
+        d_mulv( RB, n, nw );
+        if( !L.act[j] ){
+          L.act[j] = 1; L.typ[j] = RKFD_SF;
+          L.REF[3*j] = pro[0]; L.REF[3*j+1] = pro[1]; L.REF[3*j+2] = pro[2];
+        }
+        ref[0] = L.REF[3*j]; ref[1] = L.REF[3*j+1]; ref[2] = L.REF[3*j+2];
+        d_mulv( RB, ref, rw );
+        L.RW[3*slot] = rw[0]+pB[0]; L.RW[3*slot+1] = rw[1]+pB[1]; L.RW[3*slot+2] = rw[2]+pB[2];
+        d_ortho_space( nw, t1, t2 );
+#pragma unroll
+        for( int k=0; k<3; k++ ){ L.AX[9*slot+k] = nw[k]; L.AX[9*slot+3+k] = t1[k]; L.AX[9*slot+6+k] = t2[k]; }
+        const int ct = m.ci_type[RKFD_CI_CI( cinf )];
+        is_rg = ct == RKFD_CONTACT_RIGID; is_el = ct == RKFD_CONTACT_ELASTIC;
+      } else {
+        L.act[j] = 0;
+        L.asl[j] = 0;
+      }
+    }
+    /* ordered compaction */
+    const unsigned long long mrg = BALLOT( is_rg ), mel = BALLOT( is_el );
+    const int prg = base_rg + __builtin_popcountll( mrg & below ), pel = base_el + __builtin_popcountll( mel & below );
+    if( is_rg && prg < m.maxrg ) L.lrg[prg] = j;
+    if( is_el && pel < m.maxact ) L.lel[pel] = j;
+    if( __builtin_popcountll( mact ) + base_act > m.maxact ) ovf = 1;
+    base_act += __builtin_popcountll( mact );
+    if( base_act > m.maxact ) base_act = m.maxact;
+    base_rg += __builtin_popcountll( mrg );
+    base_el += __builtin_popcountll( mel );
   }
-  /* ordered compaction */
-  const unsigned long long mrg = BALLOT( is_rg ), mel = BALLOT( is_el );
-  if( is_rg && __builtin_popcountll( mrg & below ) < m.maxrg ) L.lrg[ __builtin_popcountll( mrg & below ) ] = j;
-  if( is_el ) L.lel[ __builtin_popcountll( mel & below ) ] = j;
   if( lane == 0 ){
-    int nrg = __builtin_popcountll( mrg );
-    if( nrg > m.maxrg ){ nrg = m.maxrg; L.cnt[CNT_OVF] = 1; }   /* contact capacity exceeded */
-    if( __builtin_popcountll( mact ) > m.maxact ) L.cnt[CNT_OVF] = 1;
-    L.cnt[CNT_NRG] = nrg;
-    L.cnt[CNT_NEL] = __builtin_popcountll( mel );
+    if( base_rg > m.maxrg ){ base_rg = m.maxrg; ovf = 1; }   /* contact capacity exceeded */
+    if( ovf ) L.cnt[CNT_OVF] = 1;
+    L.cnt[CNT_NRG] = base_rg;
+    L.cnt[CNT_NEL] = base_el < m.maxact ? base_el : m.maxact;
   }
   SYNC();
 }
@@ -1032,9 +1041,10 @@ RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L, bool prof
   /* probes: lane = column k = 3c+i; unit force along axis i at contact c, applied to the
    * owner link (+) and the other link (-).  Linear response only (delta form of
    * rkFDChainUpdateCachedABIPair + _rkFDSolverRelativeAcc, reference src/rkfd_mlcp.c:76-122). */
-  {
-    const bool on = lane < M;
-    const int c = on ? lane/3 : 0, ia = on ? lane%3 : 0;
+  for( int cb=0; cb<M; cb+=RKFD_WAVE ){      /* 64 probe columns at a time */
+    const int col = cb + lane;
+    const bool on = col < M;
+    const int c = on ? col/3 : 0, ia = on ? col%3 : 0;
     const int j = nc > 0 ? L.lrg[c] : 0;
     const int cinfk = L.CIp[j];
     const int lk[2] = { RKFD_CI_A( cinfk ), RKFD_CI_B( cinfk ) };
@@ -1064,7 +1074,7 @@ RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L, bool prof
             double du = 0;
 #pragma unroll
             for( int k=0; k<6; k++ ) du -= L.S[6*i+k]*dp[k];
-            L.PU[( ( m.nside == 2 ? s : 0 )*NLV + RKFD_LI_DEPTH( lii ) )*M + lane] = du;
+            L.PU[( ( m.nside == 2 ? s : 0 )*NLV + RKFD_LI_DEPTH( lii ) )*M + col] = du;
             const double t = du*L.MS[4*i+0];
 #pragma unroll
             for( int k=0; k<6; k++ ) dp[k] += L.U[6*i+k]*t;
@@ -1090,7 +1100,7 @@ RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L, bool prof
     /* response at every target link, then the column entries */
     const int nt = L.cnt[CNT_NTGT];
     if( on ){
-      for( int r=0; r<M; r++ ) L.MA[r*ld+lane] = 0.0;
+      for( int r=0; r<M; r++ ) L.MA[r*ld+col] = 0.0;
       for( int t=0; t<nt; t++ ){
         const int T = L.tgt[t];
         const int dT = RKFD_LI_DEPTH( L.LI[T] );
@@ -1109,7 +1119,7 @@ RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L, bool prof
             for( int k=0; k<6; k++ ) da[k] = droot[side][k];
           } else if( jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM ){
             const bool onpath = d <= dsrc && L.PL[src*NLV+d] == i;
-            double du = onpath ? L.PU[( ( m.nside == 2 ? side : 0 )*NLV + d )*M + lane] : 0.0;
+            double du = onpath ? L.PU[( ( m.nside == 2 ? side : 0 )*NLV + d )*M + col] : 0.0;
             double ua = 0;
 #pragma unroll
             for( int k=0; k<6; k++ ) ua += L.U[6*i+k]*da[k];
@@ -1131,61 +1141,75 @@ RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L, bool prof
           acc[0] = da[3]+t3[0]; acc[1] = da[4]+t3[1]; acc[2] = da[5]+t3[2];
 #pragma unroll
           for( int i2=0; i2<3; i2++ )
-            L.MA[(3*r+i2)*ld+lane] += sgn*d_dot( &L.AX[9*L.asl[jr]+3*i2], acc );
+            L.MA[(3*r+i2)*ld+col] += sgn*d_dot( &L.AX[9*L.asl[jr]+3*i2], acc );
         }
       }
       /* relaxation on the diagonal */
-      L.MA[lane*ld+lane] += m.ci_l[RKFD_CI_CI( cinfk )];
+      L.MA[col*ld+col] += m.ci_l[RKFD_CI_CI( cinfk )];
     }
     SYNC();
   }
   MST(6);
   /* projected Gauss-Seidel, fixed max_iter sweeps, no warm start (_rkFDSolverMLCP, reference
-   * src/rkfd_mlcp.c:190-249).  lane = row; the residual res = b + A f is kept up to date. */
+   * src/rkfd_mlcp.c:190-249).  lane = row (rows 64.. live in a second register set of the same
+   * lanes); the residual res = b + A f is kept up to date instead of re-forming the dot products. */
   {
-    const bool on = lane < M;
-    const int row = on ? lane : 0;
-    double res = on ? L.MB[row] : 0.0, f = 0.0;
-    const double diag = on ? L.MA[row*ld+row] : 1.0;
+    const int row0 = lane, row1 = lane + RKFD_WAVE;
+    const bool on0 = row0 < M, on1 = row1 < M;
+    const bool two = M > RKFD_WAVE;
+    double res0 = on0 ? L.MB[row0] : 0.0, res1 = on1 ? L.MB[row1] : 0.0, f0 = 0.0, f1 = 0.0;
+    const double diag0 = on0 ? L.MA[row0*ld+row0] : 1.0, diag1 = on1 ? L.MA[row1*ld+row1] : 1.0;
     /* reciprocal diagonal; tangential rows with |a_kk| < zTOL are frozen at 0 (reference :220-221) */
-    const double idiag = ( ( row % 3 ) != 0 && fabs( diag ) < RKFD_DEV_TOL ) ? 0.0 : 1.0/diag;
-    /* friction coefficient of this row's contact (type as of the start of the solve) */
-    double murow = 0.0;
-    if( on ){
-      const int jr_ = L.lrg[row/3], cir_ = RKFD_CI_CI( L.CIp[jr_] );
-      murow = L.typ[jr_] == RKFD_SF ? m.ci_sf[cir_] : m.ci_kf[cir_];
+    const double idiag0 = ( ( row0 % 3 ) != 0 && fabs( diag0 ) < RKFD_DEV_TOL ) ? 0.0 : 1.0/diag0;
+    const double idiag1 = ( ( row1 % 3 ) != 0 && fabs( diag1 ) < RKFD_DEV_TOL ) ? 0.0 : 1.0/diag1;
+    /* friction coefficient of each row's contact (type as of the start of the solve) */
+    double mu0 = 0.0, mu1 = 0.0;
+    if( on0 ){
+      const int jr_ = L.lrg[row0/3], cir_ = RKFD_CI_CI( L.CIp[jr_] );
+      mu0 = L.typ[jr_] == RKFD_SF ? m.ci_sf[cir_] : m.ci_kf[cir_];
     }
+    if( on1 ){
+      const int jr_ = L.lrg[row1/3], cir_ = RKFD_CI_CI( L.CIp[jr_] );
+      mu1 = L.typ[jr_] == RKFD_SF ? m.ci_sf[cir_] : m.ci_kf[cir_];
+    }
+#define ROWB(v0,v1,k) BCAST( ( (k) < RKFD_WAVE ) ? (v0) : (v1), (k) & ( RKFD_WAVE-1 ) )
+#define ROWSET(k,val) do{ if( lane == ( (k) & ( RKFD_WAVE-1 ) ) ){ if( (k) < RKFD_WAVE ) f0 = (val); else f1 = (val); } }while(0)
     for( int it=0; it<m.max_iter; it++ ){
       for( int c=0; c<nc; c++ ){
         const int k = 3*c;
-        const double rk = BCAST( res, k ), fk = BCAST( f, k ), ikk = BCAST( idiag, k );
+        const double rk = ROWB( res0, res1, k ), fk = ROWB( f0, f1, k ), ikk = ROWB( idiag0, idiag1, k );
         double ff = fk - rk*ikk;          /* = -( b + a.f - a_kk f_k ) / a_kk */
         if( ff < RKFD_DEV_TOL ) ff = 0.0;
         const double dl = ff - fk;
-        if( lane == k ) f = ff;
-        if( on ) res += L.MA[row*ld+k]*dl;
+        ROWSET( k, ff );
+        if( on0 ) res0 += L.MA[row0*ld+k]*dl;
+        if( two && on1 ) res1 += L.MA[row1*ld+k]*dl;
       }
       for( int c=0; c<nc; c++ ){
         const int k1 = 3*c+1, k2 = 3*c+2;
-        const double r1 = BCAST( res, k1 ), f1 = BCAST( f, k1 ), i11 = BCAST( idiag, k1 );
-        const double r2 = BCAST( res, k2 ), f2 = BCAST( f, k2 ), i22 = BCAST( idiag, k2 );
-        const double fn = BCAST( f, 3*c );
-        const double ff0 = f1 - r1*i11;   /* idiag is 0 where |a_kk| < zTOL, f starts at 0 */
-        const double ff1 = f2 - r2*i22;
+        const double r1 = ROWB( res0, res1, k1 ), f1_ = ROWB( f0, f1, k1 ), i11 = ROWB( idiag0, idiag1, k1 );
+        const double r2 = ROWB( res0, res1, k2 ), f2_ = ROWB( f0, f1, k2 ), i22 = ROWB( idiag0, idiag1, k2 );
+        const double fn = ROWB( f0, f1, 3*c );
+        const double ff0 = f1_ - r1*i11;   /* idiag is 0 where |a_kk| < zTOL, f starts at 0 */
+        const double ff1 = f2_ - r2*i22;
         const double fnorm = ff0*ff0 + ff1*ff1;
-        const double mu = BCAST( murow, k1 );
+        const double mu = ROWB( mu0, mu1, k1 );
         double fs = mu*fn; fs = fs*fs;
         double n1, n2;
         if( fnorm < RKFD_DEV_TOL || fs < RKFD_DEV_TOL ){ n1 = 0; n2 = 0; }
-        else if( fnorm > fs ){ const double s = fs/fnorm; n1 = ff0*s; n2 = ff1*s; }
+        else if( fnorm > fs ){ const double sc = fs/fnorm; n1 = ff0*sc; n2 = ff1*sc; }
         else { n1 = ff0; n2 = ff1; }
-        const double d1 = n1-f1, d2 = n2-f2;
-        if( lane == k1 ) f = n1;
-        if( lane == k2 ) f = n2;
-        if( on ) res += L.MA[row*ld+k1]*d1 + L.MA[row*ld+k2]*d2;
+        const double d1 = n1-f1_, d2 = n2-f2_;
+        ROWSET( k1, n1 );
+        ROWSET( k2, n2 );
+        if( on0 ) res0 += L.MA[row0*ld+k1]*d1 + L.MA[row0*ld+k2]*d2;
+        if( two && on1 ) res1 += L.MA[row1*ld+k1]*d1 + L.MA[row1*ld+k2]*d2;
       }
     }
-    if( on ) L.MF[row] = f/dt;
+#undef ROWB
+#undef ROWSET
+    if( on0 ) L.MF[row0] = f0/dt;
+    if( on1 ) L.MF[row1] = f1/dt;
   }
   SYNC();
   MST(7);
@@ -1327,13 +1351,13 @@ RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkfdDevState &st, int b
   if( m.maxrg > 0 ){
     for( int k=lane; k<NL*m.nlevel; k+=RKFD_WAVE ) L.PL[k] = (unsigned char)m.pathlink[k];
   }
-  if( lane < NC ){
-    L.CIp[lane] = m.cinfo[lane];
-    L.CFO[lane] = m.cand_foff[lane];
-    L.act[lane] = st.cv_active[(size_t)b*NC+lane];
-    L.typ[lane] = st.cv_type[(size_t)b*NC+lane];
+  for( int j=lane; j<NC; j+=RKFD_WAVE ){
+    L.CIp[j] = m.cinfo[j];
+    L.CFO[j] = m.cand_foff[j];
+    L.act[j] = st.cv_active[(size_t)b*NC+j];
+    L.typ[j] = st.cv_type[(size_t)b*NC+j];
 #pragma unroll
-    for( int k=0; k<3; k++ ) L.REF[3*lane+k] = st.cv_ref[((size_t)b*NC+lane)*3+k];
+    for( int k=0; k<3; k++ ) L.REF[3*j+k] = st.cv_ref[((size_t)b*NC+j)*3+k];
   }
   SYNC();
   if( lane < NL && RKFD_LI_JT( L.LI[lane] ) == RKFD_JOINT_FLOAT ){
@@ -1408,13 +1432,13 @@ RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkfdDevState &st, int b
     st.piv_type[(size_t)b*NL+lane] = L.pivt[lane];
     st.piv_prev[(size_t)b*NL+lane] = L.pivp[lane];
   }
-  if( lane < NC ){
-    st.cv_active[(size_t)b*NC+lane] = L.act[lane];
-    st.cv_type[(size_t)b*NC+lane] = L.typ[lane];
+  for( int j=lane; j<NC; j+=RKFD_WAVE ){
+    st.cv_active[(size_t)b*NC+j] = L.act[j];
+    st.cv_type[(size_t)b*NC+j] = L.typ[j];
 #pragma unroll
     for( int k=0; k<3; k++ ){
-      st.cv_ref[((size_t)b*NC+lane)*3+k] = L.REF[3*lane+k];
-      st.cv_f[((size_t)b*NC+lane)*3+k] = L.CF[3*lane+k];
+      st.cv_ref[((size_t)b*NC+j)*3+k] = L.REF[3*j+k];
+      st.cv_f[((size_t)b*NC+j)*3+k] = L.CF[3*j+k];
     }
   }
   if( st.dbg ){

@@ -10,8 +10,8 @@
 #define RKFD_WAVE        64
 #define RKFD_MAX_LINK    64
 #define RKFD_MAX_DOF     64
-#define RKFD_MAX_CAND    64
-#define RKFD_MAX_ROWS    64   /* 3 * (rigid contact vertices) handled by one wave */
+#define RKFD_MAX_CAND    256  /* candidate contact vertices per instance (swept 64 at a time) */
+#define RKFD_MAX_ROWS    128  /* 3 * (rigid contact vertices): two MLCP rows per lane at most */
 
 typedef struct {
   int nlink, ndof, ncand;
@@ -21,7 +21,7 @@ typedef struct {
   int solver, max_iter;
   int maxact;            /* capacity: active contact vertices (rigid + elastic) per instance        */
   int nside;             /* 1 when every rigid-capable pair has a static cell (probe walks one-sided) else 2 */
-  int maxrg;             /* capacity: rigid contact vertices solved per instance (3*maxrg <= 64) */
+  int maxrg;             /* capacity: rigid contact vertices solved per instance (3*maxrg <= 128) */
   double dt, fric_w;
   /* per link */
   const int *parent, *jtype, *dofoff, *mtype, *depth, *is_static;

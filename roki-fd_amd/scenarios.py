@@ -152,4 +152,36 @@ def config4(batch=4096, model="humanoid30.ztk", max_rigid=8):
     return dict(name="config4_humanoid_mlcp", world=w, dis=dis, vel=vel, max_rigid=max_rigid, steps=1000)
 
 
-CONFIGS = {"config1": config1, "config1b": config1_rigid, "config2": config2, "config3": config3, "config4": config4}
+def config5(batch=4096, max_rigid=24):
+    """config 4 + clutter: four small boxes resting on the floor around the feet; box-floor and
+    box-foot pairs are RIGID ('ground body' / 'body body' of contactinfo.ztk), box-box pairs are
+    unregistered (as the reference's box-drop drivers do).  54 joint coordinates, 34 links,
+    224 candidate contact vertices per instance.  Contact capacity 24 vertices = 72 MLCP rows (two
+    rows per lane)."""
+    w = B.World(solver=B.SOLVER_MLCP)
+    w.contact_info(_m("contactinfo.ztk"))
+    boxes = []
+    for _ in range(4):
+        c = w.reg_file(_m("box_small.ztk"))
+        w.pair_chain_unreg(c)          # drops the pairs with the boxes registered so far
+        boxes.append(c)
+    h = w.reg_file(_m("humanoid30.ztk"))
+    w.reg_file(_m("floor.ztk"))
+    init = w.init_dis(h)
+    n = init.shape[0]
+    u = splitmix64_uniform(0x5EED0005, batch * (n - 6)).reshape(batch, n - 6)
+    m = w.model.contents
+    dis = np.zeros((batch, m.ndof))
+    ho = w.dof_offset(h)
+    dis[:, ho:ho + n] = init
+    dis[:, ho + 6:ho + n] += (u - 0.5) * 0.1
+    for k, (sx, sy) in enumerate(((1, 1), (-1, 1), (-1, -1), (1, -1))):
+        o = w.dof_offset(boxes[k])
+        dis[:, o:o + 3] = (0.15 * sx, 0.15 * sy, 0.025 - SEAT_DEPTH)
+    for b in range(batch):
+        dis[b, ho + 2] -= lowest_vertex_z(m, dis[b], h) + SEAT_DEPTH
+    vel = np.zeros_like(dis)
+    return dict(name="config5_humanoid_clutter_mlcp", world=w, dis=dis, vel=vel, max_rigid=max_rigid, steps=1000)
+
+
+CONFIGS = {"config1": config1, "config1b": config1_rigid, "config2": config2, "config3": config3, "config4": config4, "config5": config5}

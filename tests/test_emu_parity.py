@@ -7,7 +7,7 @@ import pytest
 from emu import EmuBatch
 
 
-@pytest.mark.parametrize("cfg,B,nsteps", [("config2", 2, 2), ("config3", 2, 2), ("config4", 2, 2), ("config1b", 1, 2)])
+@pytest.mark.parametrize("cfg,B,nsteps", [("config2", 2, 2), ("config3", 2, 2), ("config4", 2, 2), ("config1b", 1, 2), ("config5", 1, 1)])
 def test_emulated_kernel_matches_oracle(R, oracle_cls, cfg, B, nsteps):
     sc = R.scenarios.CONFIGS[cfg](batch=B)
     eb = EmuBatch(sc["world"], B, max_rigid=sc["max_rigid"])

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["config1", "config1b", "config2", "config3", "config4"]
+CASES = ["config1", "config1b", "config2", "config3", "config4", "config5"]
 
 
 def load(cfg):

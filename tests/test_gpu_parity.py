@@ -22,7 +22,7 @@ def _oracle_run(Oracle, sc, i, nsteps):
     return o
 
 
-@pytest.mark.parametrize("cfg,B,nsteps", [("config2", 8, 5), ("config3", 8, 5), ("config4", 8, 5),
+@pytest.mark.parametrize("cfg,B,nsteps", [("config2", 8, 5), ("config3", 8, 5), ("config4", 8, 5), ("config5", 4, 5),
                                           ("config1", 1, 400), ("config1b", 1, 400)])
 def test_step_parity(R, oracle_cls, cfg, B, nsteps):
     sc = R.scenarios.CONFIGS[cfg](batch=B)
