@@ -27,6 +27,21 @@ ALG_BYTES = {  # algorithmic HBM bytes per instance-step (SURVEY.md 8d / DESIGN.
 HBM_PEAK_GBS = 8000.0
 
 
+def measured_traffic(workload, batch):
+    """HBM bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in
+    separate runs by tools/collect_traffic.sh and corrected as MI355X_MICROARCH.md prescribes);
+    None when no measurement for this workload/batch is on file."""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    try:
+        with open(path) as fp:
+            rec = json.load(fp).get(workload)
+        if rec and rec.get("batch") == batch:
+            return rec["hbm_bytes_per_launch"]
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline(R, name, seconds=10.0):
     """the oracle (CPU restatement, 'port') timed on one host core on a bounded sample"""
     import numpy as np
@@ -108,10 +123,10 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        # gather of final states only (RCCL over xGMI)
-        dis, vel, _ = b.get_state()
-        mine = torch.from_numpy(np.concatenate([dis, vel], axis=1)).cuda()
-        out = R.sharding.gather_final_states(dist, mine, total)
+        # the path's only collective: one all-gather of the final states (RCCL over xGMI), straight
+        # from the device-resident state
+        d_dis, d_vel, _ = b.dev_tensors()
+        out = R.sharding.gather_final_states(dist, torch.cat([d_dis, d_vel], dim=1), total)
         torch.cuda.synchronize()
         assert out.shape[0] == total
 
@@ -128,7 +143,7 @@ def main():
             "config": {"workload": sc["name"], "instances_per_gpu": Bn, "ndof": m.ndof, "nlink": m.nlink,
                        "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload, Bn),
                          "kernel": "rkfd_step_kernel", "kernel_ms": kernel_ms, "alg_bytes_per_instance_step": alg},
             "device_status": st,
         }

@@ -249,5 +249,15 @@ class Batch:
     def lds_bytes(self):
         return self._L.rkfdBatchLdsBytes(self._b)
 
+    def dev_tensors(self):
+        """torch tensors ALIASING the live device state [B, ndof] (dis, vel, acc): zero-copy views
+        for consumers on the device, e.g. the RCCL all-gather of final states."""
+        import torch
+
+        class _View:
+            def __init__(self, ptr, shape):
+                self.__cuda_array_interface__ = dict(shape=shape, typestr="<f8", data=(int(ptr), False), version=2, strides=None)
+        return tuple(torch.as_tensor(_View(p, (self.B, self.ndof)), device="cuda") for p in self.dev_ptrs())
+
     def dev_ptrs(self):
         return (self._L.rkfdBatchDevDis(self._b), self._L.rkfdBatchDevVel(self._b), self._L.rkfdBatchDevAcc(self._b))

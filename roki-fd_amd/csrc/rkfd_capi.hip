@@ -19,7 +19,17 @@ rkfd_step_kernel(rkfdDevModel m, rkfdDevState st, int mode, int nsteps, int *err
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int b = blockIdx.x;
   if( b >= st.batch ) return;
-  rkfd_instance( m, st, b, lds, mode, nsteps, errflag );
+  rkfd_instance<false>( m, st, b, lds, mode, nsteps, errflag );
+}
+
+/* diagnostic instantiation with in-kernel phase stamps (rkfdBatchProfile) */
+extern "C" __global__ void __launch_bounds__(RKFD_WAVE, 2)
+rkfd_step_kernel_prof(rkfdDevModel m, rkfdDevState st, int mode, int nsteps, int *errflag)
+{
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int b = blockIdx.x;
+  if( b >= st.batch ) return;
+  rkfd_instance<true>( m, st, b, lds, mode, nsteps, errflag );
 }
 
 struct rkfdBatch {
@@ -96,6 +106,7 @@ extern "C" rkfdBatch *rkfdBatchCreate(const rkfdModel *m, int batch, int device,
   if( bad ){ rkfdBatchDestroy( b ); return NULL; }
   if( b->lds_bytes > 64*1024 ){
     hipError_t e = hipFuncSetAttribute( (const void *)rkfd_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes );
+    if( e == hipSuccess ) e = hipFuncSetAttribute( (const void *)rkfd_step_kernel_prof, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes );
     if( e != hipSuccess ){ SETERR( "hipFuncSetAttribute(LDS=%zu) failed: %s", b->lds_bytes, hipGetErrorString( e ) ); rkfdBatchDestroy( b ); return NULL; }
   }
   return b;
@@ -184,8 +195,12 @@ static int launch(rkfdBatch *b, int mode, int nsteps, void *stream)
 {
   if( !b ){ SETERR( "null batch" ); return -1; }
   HIPCHK( hipSetDevice( b->device ), -1 );
-  hipLaunchKernelGGL( rkfd_step_kernel, dim3( b->batch ), dim3( RKFD_WAVE ), b->lds_bytes, (hipStream_t)stream,
-                      b->dm, b->st, mode, nsteps, b->d_err );
+  if( b->st.prof )
+    hipLaunchKernelGGL( rkfd_step_kernel_prof, dim3( b->batch ), dim3( RKFD_WAVE ), b->lds_bytes, (hipStream_t)stream,
+                        b->dm, b->st, mode, nsteps, b->d_err );
+  else
+    hipLaunchKernelGGL( rkfd_step_kernel, dim3( b->batch ), dim3( RKFD_WAVE ), b->lds_bytes, (hipStream_t)stream,
+                        b->dm, b->st, mode, nsteps, b->d_err );
   HIPCHK( hipGetLastError(), -1 );
   return 0;
 }

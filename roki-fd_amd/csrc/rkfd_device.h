@@ -162,6 +162,51 @@ RKFD_DEV void d_mul33(const double *a, const double *b, double *c)
 #pragma unroll
   for( int i=0; i<9; i++ ) c[i] = t[i];
 }
+/* ------------------------------------------------------------------------ */
+/* compact sin/cos and atan2 for joint-angle sized arguments.  The library versions inline a
+ * Payne-Hanek slow path (v_trig_preop) that costs registers and code for arguments a robot never
+ * has; these use a two-term Cody-Waite reduction by pi/2 and the classic fdlibm kernel
+ * polynomials (|error| < 1 ulp for |x| < 1e5), and an fdlibm-style atan. */
+RKFD_DEV void d_sincos(double x, double *sn, double *cs)
+{
+  const double k = rint( x*6.36619772367581382433e-01 );
+  double r = fma( -k, 1.57079632673412561417e+00, x );
+  r = fma( -k, 6.07710050650619224932e-11, r );
+  const double z = r*r;
+  const double ps = -1.66666666666666324348e-01 + z*( 8.33333333332248946124e-03 + z*( -1.98412698298579493134e-04
+                  + z*( 2.75573137070700676789e-06 + z*( -2.50507602534068634195e-08 + z*1.58969099521155010221e-10 ) ) ) );
+  const double pc = 4.16666666666666019037e-02 + z*( -1.38888888888741095749e-03 + z*( 2.48015872894767294178e-05
+                  + z*( -2.75573143513906633035e-07 + z*( 2.08757232129817482790e-09 + z*( -1.13596475577881948265e-11 ) ) ) ) );
+  const double s0 = fma( r*z, ps, r );
+  const double c0 = fma( z*z, pc, fma( -0.5, z, 1.0 ) );
+  const int q = (int)k & 3;
+  const double s1 = ( q & 1 ) ? c0 : s0, c1 = ( q & 1 ) ? s0 : c0;
+  *sn = ( q & 2 ) ? -s1 : s1;
+  *cs = ( ( q + 1 ) & 2 ) ? -c1 : c1;
+}
+RKFD_DEV double d_atan_pos(double x)   /* x >= 0 */
+{
+  /* fdlibm atan: reduce to |t| <= 7/16 around 0, 0.5, 1, 1.5, inf */
+  double hi, lo, t;
+  if( x < 0.4375 ){ hi = 0; lo = 0; t = x; }
+  else if( x < 0.6875 ){ hi = 4.63647609000806093515e-01; lo = 2.26987774529616870924e-17; t = ( 2.0*x - 1.0 )/( 2.0 + x ); }
+  else if( x < 1.1875 ){ hi = 7.85398163397448278999e-01; lo = 3.06161699786838301793e-17; t = ( x - 1.0 )/( x + 1.0 ); }
+  else if( x < 2.4375 ){ hi = 9.82793723247329054082e-01; lo = 1.39033110312309984516e-17; t = ( x - 1.5 )/( 1.0 + 1.5*x ); }
+  else { hi = 1.57079632679489655800e+00; lo = 6.12323399573676603587e-17; t = -1.0/x; }
+  const double z = t*t, w = z*z;
+  const double s1 = z*( 3.33333333333329318027e-01 + w*( 1.42857142725034663711e-01 + w*( 9.09088713343650656196e-02
+                  + w*( 6.66107313738753120669e-02 + w*( 4.97687799461593236017e-02 + w*1.62858201153657823623e-02 ) ) ) ) );
+  const double s2 = w*( -1.99999999998764832476e-01 + w*( -1.11111104054623557880e-01 + w*( -7.69187620504482999495e-02
+                  + w*( -5.83357013379057348645e-02 + w*( -3.65315727442169155270e-02 ) ) ) ) );
+  return hi - ( ( t*( s1 + s2 ) - lo ) - t );
+}
+RKFD_DEV double d_atan2_ypos(double y, double x)   /* y >= 0 */
+{
+  if( x > 0 ) return d_atan_pos( y/x );
+  if( x < 0 ) return 3.14159265358979311600e+00 - d_atan_pos( y/( -x ) );
+  return y > 0 ? 1.57079632679489655800e+00 : 0.0;
+}
+
 RKFD_DEV void d_from_aa(const double *aa, double *m)
 {
   double th = sqrt( d_dot( aa, aa ) );
@@ -169,8 +214,10 @@ RKFD_DEV void d_from_aa(const double *aa, double *m)
     m[0]=1; m[1]=0; m[2]=0; m[3]=0; m[4]=1; m[5]=0; m[6]=0; m[7]=0; m[8]=1;
     return;
   }
-  double s = sin(th), c = cos(th), k = 1-c;
-  double x = aa[0]/th, y = aa[1]/th, z = aa[2]/th;
+  double s, c;
+  d_sincos( th, &s, &c );
+  const double k = 1-c, ith = 1.0/th;
+  double x = aa[0]*ith, y = aa[1]*ith, z = aa[2]*ith;
   m[0] = c+k*x*x;   m[1] = k*x*y-s*z; m[2] = k*x*z+s*y;
   m[3] = k*x*y+s*z; m[4] = c+k*y*y;   m[5] = k*y*z-s*x;
   m[6] = k*x*z-s*y; m[7] = k*y*z+s*x; m[8] = c+k*z*z;
@@ -179,7 +226,7 @@ RKFD_DEV void d_to_aa(const double *m, double *aa)
 {
   double l[3] = { m[7]-m[5], m[2]-m[6], m[3]-m[1] };
   double a = sqrt( d_dot( l, l ) );
-  double th = atan2( a, m[0]+m[4]+m[8]-1.0 );
+  double th = d_atan2_ypos( a, m[0]+m[4]+m[8]-1.0 );
   if( a < RKFD_DEV_TOL ){ aa[0]=aa[1]=aa[2]=0; return; }
   double k = th/a;
   aa[0] = l[0]*k; aa[1] = l[1]*k; aa[2] = l[2]*k;
@@ -309,7 +356,8 @@ RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, const rkfdLds &L)
     for( int k=0; k<9; k++ ) R[k] = o[k];
     p[0]=o[9]; p[1]=o[10]; p[2]=o[11];
     if( jt == RKFD_JOINT_REVOL ){
-      double q = L.q[off], s = sin(q), c = cos(q);
+      double q = L.q[off], s, c;
+      d_sincos( q, &s, &c );
       double Rz[9] = { c,-s,0, s,c,0, 0,0,1 };
       d_mul33( o, Rz, R );
       qd1 = L.qd[off];
@@ -543,15 +591,20 @@ RKFD_DEV void d_chol6_solve(const double *Lm, const double *b, double *x)
 }
 
 /* ------------------------------------------------------------------------ */
-/* one schedule record: what one 8-lane group does in one sweep iteration */
-typedef struct { int i, li, nchild, flags, c0, c1, c2, c3, coff; } rkfdRec;
+/* one schedule record: what one 8-lane group does in one sweep iteration (packed by the host:
+ * link, packed link info, nchild | flags<<8 | pool slot<<16 | float slot<<24 (slots +1, 0 = none),
+ * offset of the children list) */
+typedef struct { int i, li, w, coff; } rkfdRec;
+#define REC_NCHILD(r) ( (r).w & 0xFF )
+#define REC_FLAGS(r)  ( ( (r).w >> 8 ) & 0xFF )
+#define REC_POOL(r)   ( ( ( (r).w >> 16 ) & 0xFF ) - 1 )
+#define REC_FSLOT(r)  ( ( ( (r).w >> 24 ) & 0xFF ) - 1 )
 RKFD_DEV rkfdRec rkfd_rec_load(const rkfdDevModel &m, int t, int g)
 {
   /* t in [-2, nsched+1]: the schedule is padded with two empty iterations on both sides */
   rkfdRec r;
-  const int *p = m.sched + ( (size_t)( t+2 )*8 + g )*8;
-  r.i = p[0]; r.li = p[1]; r.nchild = p[2] & 0xFF; r.flags = p[2] >> 8;
-  r.c0 = p[3]; r.c1 = p[4]; r.c2 = p[5]; r.c3 = p[6]; r.coff = p[7];
+  const int *p = m.sched + ( (size_t)( t+2 )*8 + g )*4;
+  r.i = p[0]; r.li = p[1]; r.w = p[2]; r.coff = p[3];
   return r;
 }
 
@@ -598,7 +651,7 @@ RKFD_DEV void rkfd_pre2_load(const rkfdLds &L, int i, int rr, const int *ro, boo
  * Software-pipelined: schedule records are fetched two iterations ahead, the link's own LDS
  * operands one iteration ahead, and along chains the child's (Ia row, pa) stay in registers
  * (schedule flag bit 0), so the dependent path of an iteration is ALU + DPP + one swizzle. */
-RKFD_DEV void rkfd_phase_sweep2(const rkfdDevModel &m, const rkfdLds &L, bool full, bool prof, unsigned long long *pc)
+template<bool prof> RKFD_DEV void rkfd_phase_sweep2(const rkfdDevModel &m, const rkfdLds &L, bool full, unsigned long long *pc)
 {
   const int lane = LANE();
   const int g = lane >> 3, r = lane & 7;
@@ -630,14 +683,14 @@ RKFD_DEV void rkfd_phase_sweep2(const rkfdDevModel &m, const rkfdLds &L, bool fu
 #pragma unroll
     for( int k=0; k<6; k++ ) row[k] = pre.row[k];
     LDS_FENCE();   /* the children's write-backs of the previous iteration precede the gathers below */
-    if( rec.flags & 1 ){
+    if( REC_FLAGS( rec ) & 1 ){
       pr += cpa;
       if( full ){
 #pragma unroll
         for( int k=0; k<6; k++ ) row[k] += crow[k];
       }
     } else {
-      for( int cc=0; cc<rec.nchild; cc++ ){
+      for( int cc=0; cc<REC_NCHILD( rec ); cc++ ){
         const int ch = L.CHI[rec.coff+cc];
         pr += L.PA[6*ch+rr];
         const int ps = L.PSL[ch];
@@ -688,15 +741,15 @@ RKFD_DEV void rkfd_phase_sweep2(const rkfdDevModel &m, const rkfdLds &L, bool fu
     /* write back (needed by later phases and by parents that gather from LDS) */
     if( on ){
       if( full ){
-        /* Ia goes to LDS only where somebody will read it: a gathering parent (pool slot rec.c0)
-         * or the Cholesky of a float joint (slot rec.c1) */
-        if( rec.c0 >= 0 ){
+        /* Ia goes to LDS only where somebody will read it: a gathering parent (pool slot REC_POOL( rec ))
+         * or the Cholesky of a float joint (slot REC_FSLOT( rec )) */
+        if( REC_POOL( rec ) >= 0 ){
 #pragma unroll
-          for( int k=0; k<6; k++ ) L.POOL[36*rec.c0+6*rr+k] = row[k];
+          for( int k=0; k<6; k++ ) L.POOL[36*REC_POOL( rec )+6*rr+k] = row[k];
         }
         if( isf ){
 #pragma unroll
-          for( int k=0; k<6; k++ ) L.CHOL[36*rec.c1+6*rr+k] = row[k];
+          for( int k=0; k<6; k++ ) L.CHOL[36*REC_FSLOT( rec )+6*rr+k] = row[k];
         }
         if( is1 ){ L.U[6*i+rr] = U_r; L.W[6*i+rr] = W_r; }
       }
@@ -709,7 +762,7 @@ RKFD_DEV void rkfd_phase_sweep2(const rkfdDevModel &m, const rkfdLds &L, bool fu
     }
     LDS_FENCE();
     QST(12);
-    if( full && isf && onl && r == 0 ) d_chol6_inplace( &L.CHOL[36*rec.c1] );
+    if( full && isf && onl && r == 0 ) d_chol6_inplace( &L.CHOL[36*REC_FSLOT( rec )] );
     QST(13);
 #undef QST
 #pragma unroll
@@ -752,7 +805,7 @@ RKFD_DEV void rkfd_phase_sweep3(const rkfdDevModel &m, const rkfdLds &L)
     const int off = RKFD_LI_OFF( rec.li );
     double ap;
     LDS_FENCE();   /* the parents' accelerations written in the previous iteration precede the loads below */
-    if( rec.flags & 2 ) ap = ca;
+    if( REC_FLAGS( rec ) & 2 ) ap = ca;
     else ap = ( par >= 0 ) ? L.AC[6*par+rr] : 0.0;
     const double y = ap + pre.c_r;
     const double uy = G8SUM( ( on && is1 ) ? pre.U_r*y : 0.0 );
@@ -767,15 +820,15 @@ RKFD_DEV void rkfd_phase_sweep3(const rkfdDevModel &m, const rkfdLds &L)
         double rhs[6], x[6], d[6], R[9], Rj[9], Row[9], p[3], qq[3];
 #pragma unroll
         for( int k=0; k<6; k++ ) rhs[k] = -L.U[6*i+k];
-        d_chol6_solve( &L.CHOL[36*rec.c1], rhs, x );
+        d_chol6_solve( &L.CHOL[36*REC_FSLOT( rec )], rhs, x );
 #pragma unroll
         for( int k=0; k<6; k++ ){
           L.AC[6*i+k] = x[k];
           d[k] = x[k] - ( par >= 0 ? L.AC[6*par+k] : 0.0 ) - L.C[6*i+k];
         }
 #pragma unroll
-        for( int k=0; k<9; k++ ) R[k] = L.XF[12*rec.c1+k];
-        p[0] = L.XF[12*rec.c1+9]; p[1] = L.XF[12*rec.c1+10]; p[2] = L.XF[12*rec.c1+11];
+        for( int k=0; k<9; k++ ) R[k] = L.XF[12*REC_FSLOT( rec )+k];
+        p[0] = L.XF[12*REC_FSLOT( rec )+9]; p[1] = L.XF[12*REC_FSLOT( rec )+10]; p[2] = L.XF[12*REC_FSLOT( rec )+11];
         qq[0] = L.q[off+3]; qq[1] = L.q[off+4]; qq[2] = L.q[off+5];
         d_from_aa( qq, Rj );
         {
@@ -988,7 +1041,7 @@ RKFD_DEV void rkfd_phase_penalty(const rkfdDevModel &m, const rkfdLds &L, bool d
 /* MLCP rigid branch (reference src/rkfd_mlcp.c:287-297).  Preconditions: sweep 2 (full) and
  * sweep 3 have been run with the wrenches applied so far (rkFDUpdateAccBias), so AC holds
  * the free accelerations and IA/U/MS hold Ia, U, Dinv.  Adds the contact wrenches to FE. */
-RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L, bool prof, unsigned long long *pc)
+template<bool prof> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L, unsigned long long *pc)
 {
   unsigned long long q0 = prof ? RKFD_CLOCK() : 0ull, q1;
 #define MST(k) do{ if( prof ){ q1 = RKFD_CLOCK(); pc[k] += q1 - q0; q0 = q1; } }while(0)
@@ -1240,7 +1293,7 @@ RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L, bool prof
 /* one dynamics evaluation: _rkFDUpdate / _rkFDUpdateRef (reference src/rkfd_sim.c:533-549).
  * Input L.q, L.qd; output L.acc (and contact / pivot state).  Returns nonzero when the model
  * needs a rigid solver that is not available on the device (wave-uniform). */
-RKFD_DEV int rkfd_evaluate(const rkfdDevModel &m, const rkfdLds &L, bool doUpRef, bool prof, unsigned long long *pc)
+template<bool prof> RKFD_DEV int rkfd_evaluate(const rkfdDevModel &m, const rkfdLds &L, bool doUpRef, unsigned long long *pc)
 {
   const int lane = LANE();
   int err = 0;
@@ -1273,13 +1326,13 @@ RKFD_DEV int rkfd_evaluate(const rkfdDevModel &m, const rkfdLds &L, bool doUpRef
    * Written as a loop so that the sweep code exists once in the instruction stream. */
   int npass = 1;
   for( int pass=0; pass<npass; pass++ ){
-    rkfd_phase_sweep2( m, L, pass == 0, prof, pc );
+    rkfd_phase_sweep2<prof>( m, L, pass == 0, pc );
     STAMP(2);
     rkfd_phase_sweep3( m, L );
     STAMP(3);
     if( pass == 0 && L.cnt[CNT_NRG] > 0 ){
       if( m.solver == RKFD_SOLVER_MLCP ){
-        rkfd_phase_mlcp( m, L, prof, pc );
+        rkfd_phase_mlcp<prof>( m, L, pc );
         STAMP(4);
         npass = 2;
       } else {
@@ -1328,7 +1381,7 @@ RKFD_DEV void rkfd_cat_dis(const rkfdDevModel &m, const rkfdLds &L, double q0, d
 /* the whole step for one instance: load state, nsteps x rkFDUpdate (or a single evaluation),
  * store state.  mode 0: rkFDUpdate x nsteps; mode 1: rkFDUpdateInit (committing evaluation);
  * mode 2: evaluation without commit. */
-RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkfdDevState &st, int b, void *ldsbase,
+template<bool prof> RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkfdDevState &st, int b, void *ldsbase,
                             int mode, int nsteps, int *errflag)
 {
   const int lane = LANE();
@@ -1368,10 +1421,10 @@ RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkfdDevState &st, int b
   }
   SYNC();
   int err = 0;
-  const bool prof = st.prof != 0;
-  unsigned long long pc[RKFD_NPROF];
+  /* phase-cycle counters exist only in the diagnostic instantiation (prof = true) */
+  unsigned long long pc[prof ? RKFD_NPROF : 1];
 #pragma unroll
-  for( int k=0; k<RKFD_NPROF; k++ ) pc[k] = 0;
+  for( int k=0; k<( prof ? RKFD_NPROF : 1 ); k++ ) pc[k] = 0;
   const unsigned long long tstart = prof ? RKFD_CLOCK() : 0ull;
   {
     /* rkFDUpdate = zODE2Update (Runge-Kutta-Gill, 4 stage evaluations) + the committing
@@ -1379,9 +1432,9 @@ RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkfdDevState &st, int b
      * run through ONE copy of rkfd_evaluate (stage loop) to keep the kernel inside the
      * instruction cache.  mode 1 / 2: a single evaluation at the current state. */
     const double h = m.dt;
-    const double s2 = sqrt( 2.0 );
-    const double c21 = ( s2-1.0 )/2.0, c22 = ( 2.0-s2 )/2.0, c31 = -s2/2.0, c32 = 1.0+s2/2.0;
-    const double w2 = 2.0-s2, w3 = 2.0+s2;
+    /* Gill coefficients: (sqrt2-1)/2, (2-sqrt2)/2, -sqrt2/2, 1+sqrt2/2, 2-sqrt2, 2+sqrt2 */
+    const double c21 = 0.20710678118654752440, c22 = 0.29289321881345247560, c31 = -0.70710678118654752440;
+    const double c32 = 1.70710678118654752440, w2 = 0.58578643762690495120, w3 = 3.41421356237309504880;
     const bool on = lane < ND;
     const int nst = mode == 0 ? 5 : 1;
     const int ntot = mode == 0 ? nsteps*5 : 1;
@@ -1408,7 +1461,7 @@ RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkfdDevState &st, int b
       if( stage == 4 ){ q = on ? L.q[lane] : 0.0; qd = xv; }
       SYNC();
       const bool doUp = mode == 0 ? stage == 4 : mode == 1;
-      err |= rkfd_evaluate( m, L, doUp, prof, pc );
+      err |= rkfd_evaluate<prof>( m, L, doUp, pc );
       const double a = on ? L.acc[lane] : 0.0;
       if( stage == 0 ){ kv1 = xv; ka1 = a; }
       else if( stage == 1 ){ kv2 = xv; ka2 = a; }
@@ -1418,10 +1471,10 @@ RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkfdDevState &st, int b
       stage++; if( stage == nst ) stage = 0;
     }
   }
-  if( prof && lane == 0 ){
-    pc[7] = RKFD_CLOCK() - tstart;
+  if( prof && lane == 0 && st.prof ){
+    pc[prof ? 7 : 0] = RKFD_CLOCK() - tstart;
 #pragma unroll
-    for( int k=0; k<RKFD_NPROF; k++ ) st.prof[(size_t)b*RKFD_NPROF+k] = pc[k];
+    for( int k=0; k<( prof ? RKFD_NPROF : 1 ); k++ ) st.prof[(size_t)b*RKFD_NPROF+k] = pc[k];
   }
   /* store */
   if( lane < ND ){

@@ -156,7 +156,7 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
     }
     for( int t=-2; t<nsched+2; t++ )
       for( int g=0; g<8; g++ ){
-        int rec[8] = { -1, 0, 0, -1, -1, -1, -1, 0 };
+        int rec[4] = { -1, 0, 0, 0 };
         const int i = ( t >= 0 && t < nsched ) ? iters[t][g] : -1;
         if( i >= 0 ){
           const int nchild = child_off[i+1] - child_off[i];
@@ -166,13 +166,12 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
             if( iter[ch] == t+1 && slot[ch] == g && m->jtype[ch] != RKFD_JOINT_FLOAT ) flags |= 1;
           }
           if( m->parent[i] >= 0 && iter[m->parent[i]] == t-1 && slot[m->parent[i]] == g ) flags |= 2;
+          if( nchild > 255 || pslot[i]+1 > 255 || fslot[i]+1 > 255 ) FAIL( "schedule record overflow" );
           rec[0] = i; rec[1] = linfo[i];
-          rec[2] = nchild | ( flags << 8 );
-          rec[3] = pslot[i];      /* own pool slot (-1: handed over in registers / not needed) */
-          rec[4] = fslot[i];      /* float-joint slot (-1: not a float joint)                  */
-          rec[7] = child_off[i];
+          rec[2] = nchild | ( flags << 8 ) | ( ( pslot[i]+1 ) << 16 ) | ( ( fslot[i]+1 ) << 24 );
+          rec[3] = child_off[i];
         }
-        sched.insert( sched.end(), rec, rec+8 );
+        sched.insert( sched.end(), rec, rec+4 );
       }
   }
 

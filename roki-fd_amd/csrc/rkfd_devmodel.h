@@ -36,8 +36,8 @@ typedef struct {
   const int *pathlink;   /* [nlink][nlevel]: ancestor of link at depth d (d<=depth)      */
   /* packed per-link ints (copied to LDS): see RKFD_LI_* */
   const int *linfo;      /* [nlink]                                                      */
-  /* sweep schedule: nsched iterations x 8 lane groups x 8 ints
-   *   {link (-1 none), linfo[link], nchild, child0..child3, child_off[link]}            */
+  /* sweep schedule: (nsched+4) iterations x 8 lane groups x 4 ints
+   *   {link (-1 none), linfo[link], nchild | flags<<8 | (pool slot+1)<<16 | (float slot+1)<<24, child_off[link]} */
   int nsched;
   const int *sched;
   int npool;             /* links whose articulated inertia must be staged in LDS for a gathering parent */

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence for one workload on the GPU box (run from the repo root):
+#   kernel trace + stats, then FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes, then SQ counters.
+# usage: tools/collect_traffic.sh <workload> <tag>
+set -e
+W=${1:-config4}; TAG=${2:-r01}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/prof_${TAG}_${W}
+ARGS="bench.py --workload $W --steps 20 --warmup 5 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT.trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ARGS > $OUT.fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ARGS > $OUT.write.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $OUT/sq1 -- python3 $ARGS > $OUT.sq1.log 2>&1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_F64 --output-format csv -d $OUT/sq2 -- python3 $ARGS > $OUT.sq2.log 2>&1 || true
+python3 tools/parse_prof.py $OUT $W

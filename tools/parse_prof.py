@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Summarises the rocprofv3 output of tools/collect_traffic.sh into one JSON + text file."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def rows(d, pat):
+    fs = glob.glob(os.path.join(d, "**", pat), recursive=True)
+    return list(csv.DictReader(open(fs[0]))) if fs else []
+
+
+def counters(d):
+    out = defaultdict(list)
+    for r in rows(d, "*counter_collection.csv"):
+        if "rkfd_step_kernel" in r["Kernel_Name"]:
+            out[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    # per-launch value of the timed steps: median over dispatches
+    res = {}
+    for k, v in out.items():
+        v = sorted(v)
+        res[k] = v[len(v) // 2]
+    return res
+
+
+def main():
+    base, wl = sys.argv[1], sys.argv[2]
+    summary = {"workload": wl}
+    st = [r for r in rows(os.path.join(base, "trace"), "*kernel_stats.csv") if "rkfd_step_kernel" in r["Name"]]
+    if st:
+        summary["kernel_stats"] = st[0]
+    tr = [r for r in rows(os.path.join(base, "trace"), "*kernel_trace.csv") if "rkfd_step_kernel" in r["Kernel_Name"]]
+    if tr:
+        d = sorted(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tr)
+        summary["kernel_ns_median"] = d[len(d) // 2]
+        summary["lds_bytes"] = tr[-1].get("LDS_Block_Size"); summary["vgpr"] = tr[-1].get("VGPR_Count")
+        summary["accum_vgpr"] = tr[-1].get("Accum_VGPR_Count"); summary["sgpr"] = tr[-1].get("SGPR_Count")
+        summary["grid"] = tr[-1].get("Grid_Size")
+    for sub in ("fetch", "write", "sq1", "sq2"):
+        summary.update(counters(os.path.join(base, sub)))
+    # MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KiB-units of 1024 B in rocprofv3's derived
+    # metric (bytes = value * 1024); on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x:
+    # report both the raw and the doubled read figure.
+    if "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
+        rd, wr = summary["FETCH_SIZE"] * 1024.0, summary["WRITE_SIZE"] * 1024.0
+        summary["hbm_read_bytes_raw"] = rd; summary["hbm_read_bytes_x2"] = 2 * rd; summary["hbm_write_bytes"] = wr
+        summary["hbm_bytes_per_launch"] = 2 * rd + wr
+    out = base + "_summary.json"
+    json.dump(summary, open(out, "w"), indent=1)
+    print(json.dumps(summary, indent=1))
+
+
+if __name__ == "__main__":
+    main()
