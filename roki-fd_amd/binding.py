@@ -241,7 +241,7 @@ class Batch:
 
     def profile(self, nsteps=1):
         """diagnostic launch with in-kernel phase stamps: [B, 8] cycles"""
-        out = np.zeros((self.B, 16), dtype=np.uint64)
+        out = np.zeros((self.B, 24), dtype=np.uint64)
         self._chk(self._L.rkfdBatchProfile(self._b, nsteps, _ptr(out)))
         return out
 

@@ -126,7 +126,7 @@ RKFD_DEV double rkfd_rcp(double x)
 #define RKFD_DEV_TOL RKFD_TOL
 
 /* optional in-kernel phase timing (diagnostic launches only: rkfdBatchProfile) */
-#define RKFD_NPROF 16
+#define RKFD_NPROF 24
 #ifdef RKFD_EMU
 #  define RKFD_CLOCK() 0ull
 #else
@@ -280,7 +280,7 @@ typedef struct {
                                      +m r (3), -m r (3), m, 0: every entry of the 6x6 is one of these */
   double *POOL;                   /* [npool*36] Ia of links whose parent gathers through LDS */
   double *CHOL;                   /* [nfloat*36] articulated inertia / Cholesky factor of float joints */
-  double *XF;                     /* [nfloat*12] world frame of float-joint links         */
+  double *XF;                     /* [nfloat*12] float joints: world orientation of the joint-origin frame (9), link position (3) */
   double *CX, *AX, *RW, *PRO;     /* per ACTIVE contact slot (capacity maxact): 3, 9, 3, 3 */
   double *REF, *CF;               /* per candidate: stick anchor (state), contact force (output) */
   double *MA, *MB, *MF, *PU;      /* MLCP: [M*(M+1)] (ALIASES IST|POOL), [M], [M], [2*nlevel*M] */
@@ -331,8 +331,10 @@ RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int
 /* phase: forward kinematics, link velocities, per-link spatial inertia and bias terms.
  * Mirrors _rkFDConnectJointState (reference src/rkfd_sim.c:290-302) + the per-link set-up
  * of RoKi's ABA.  lane = link. */
-RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, const rkfdLds &L)
+template<bool prof> RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, const rkfdLds &L, unsigned long long *pc)
 {
+  unsigned long long k0 = prof ? RKFD_CLOCK() : 0ull, k1;
+#define KST(k) do{ if( prof ){ k1 = RKFD_CLOCK(); pc[k] += k1 - k0; k0 = k1; } }while(0)
   const int lane = LANE();
   const int NL = m.nlink;
   const bool on = lane < NL;
@@ -381,6 +383,7 @@ RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, const rkfdLds &L)
     L.X[12*i+9] = p[0]; L.X[12*i+10] = p[1]; L.X[12*i+11] = p[2];
   }
   SYNC();
+  KST(16);
   /* pointer jumping: compose with the ancestor 2^r levels up */
 #pragma unroll
   for( int r=0; r<RKFD_MAX_ROUND; r++ ){
@@ -403,7 +406,9 @@ RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, const rkfdLds &L)
     }
     SYNC();
   }
+  KST(17);
   /* joint motion axis and joint velocity in world coordinates */
+  double Row[9] = {1,0,0, 0,1,0, 0,0,1};   /* float joints: world orientation of the joint-origin frame */
   {
     double z[3] = { R[2], R[5], R[8] }, S[6] = {0,0,0,0,0,0};
 #pragma unroll
@@ -418,7 +423,7 @@ RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, const rkfdLds &L)
       for( int k=0; k<6; k++ ) vJ[k] = S[k]*qd1;
     } else if( jt == RKFD_JOINT_FLOAT ){
       /* world orientation of the joint-origin frame: Row = R Rj' */
-      double Row[9], RjT[9] = { Rj[0],Rj[3],Rj[6], Rj[1],Rj[4],Rj[7], Rj[2],Rj[5],Rj[8] };
+      double RjT[9] = { Rj[0],Rj[3],Rj[6], Rj[1],Rj[4],Rj[7], Rj[2],Rj[5],Rj[8] };
       double vw[3], ww[3], t[3];
       d_mul33( R, RjT, Row );
       d_mulv( Row, qdf, vw ); d_mulv( Row, qdf+3, ww );
@@ -435,6 +440,7 @@ RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, const rkfdLds &L)
     }
   }
   SYNC();
+  KST(18);
   /* velocities: prefix sum of joint velocities along the path to the root */
   {
     double v[6];
@@ -455,6 +461,7 @@ RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, const rkfdLds &L)
       }
       SYNC();
     }
+    KST(19);
     /* velocity-product acceleration c = v x vJ (+ float-joint term) */
     double c[6];
     d_crm( v, vJ, c );
@@ -499,7 +506,7 @@ RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, const rkfdLds &L)
       if( on && jt == RKFD_JOINT_FLOAT ){
         const int fs = __builtin_popcountll( fm & ( lane == 0 ? 0ull : ( ~0ull >> ( 64-lane ) ) ) );
 #pragma unroll
-        for( int k=0; k<9; k++ ) L.XF[12*fs+k] = R[k];
+        for( int k=0; k<9; k++ ) L.XF[12*fs+k] = Row[k];
         L.XF[12*fs+9] = p[0]; L.XF[12*fs+10] = p[1]; L.XF[12*fs+11] = p[2];
       }
     }
@@ -552,6 +559,8 @@ RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, const rkfdLds &L)
     }
   }
   SYNC();
+  KST(20);
+#undef KST
 }
 
 /* ------------------------------------------------------------------------ */
@@ -817,7 +826,7 @@ RKFD_DEV void rkfd_phase_sweep3(const rkfdDevModel &m, const rkfdLds &L)
     } else if( jt == RKFD_JOINT_FLOAT ){
       if( onl && r == 0 ){
         /* a = IA^-1 ( -pA ); joint acceleration from a - a_parent - c */
-        double rhs[6], x[6], d[6], R[9], Rj[9], Row[9], p[3], qq[3];
+        double rhs[6], x[6], d[6], Row[9], p[3];
 #pragma unroll
         for( int k=0; k<6; k++ ) rhs[k] = -L.U[6*i+k];
         d_chol6_solve( &L.CHOL[36*REC_FSLOT( rec )], rhs, x );
@@ -827,14 +836,8 @@ RKFD_DEV void rkfd_phase_sweep3(const rkfdDevModel &m, const rkfdLds &L)
           d[k] = x[k] - ( par >= 0 ? L.AC[6*par+k] : 0.0 ) - L.C[6*i+k];
         }
 #pragma unroll
-        for( int k=0; k<9; k++ ) R[k] = L.XF[12*REC_FSLOT( rec )+k];
+        for( int k=0; k<9; k++ ) Row[k] = L.XF[12*REC_FSLOT( rec )+k];
         p[0] = L.XF[12*REC_FSLOT( rec )+9]; p[1] = L.XF[12*REC_FSLOT( rec )+10]; p[2] = L.XF[12*REC_FSLOT( rec )+11];
-        qq[0] = L.q[off+3]; qq[1] = L.q[off+4]; qq[2] = L.q[off+5];
-        d_from_aa( qq, Rj );
-        {
-          double RjT[9] = { Rj[0],Rj[3],Rj[6], Rj[1],Rj[4],Rj[7], Rj[2],Rj[5],Rj[8] };
-          d_mul33( R, RjT, Row );
-        }
         /* wdot_j = Row' alpha ; vdot_j = Row' ( a_O - p x alpha ) */
         double t3[3], lin[3], o1[3], o2[3];
         d_cross( p, d, t3 );
@@ -963,10 +966,14 @@ RKFD_DEV void rkfd_push_wrenches(const rkfdDevModel &m, const rkfdLds &L, const 
 {
   const int lane = LANE();
   if( lane < 6 ){
+    /* consecutive contacts usually act on the same two links (vertices of one shape pair): keep
+     * the running sums in registers and touch LDS only when the link changes */
+    int la = -1, lb = -1;
+    double sa = 0, sb = 0;
     for( int e=0; e<n; e++ ){
-      const int j = list[e];
+      const int j = list[e], sl = L.asl[j], cinf = L.CIp[j];
       const double f[3] = { L.CF[3*j], L.CF[3*j+1], L.CF[3*j+2] };
-      const double x[3] = { L.CX[3*L.asl[j]], L.CX[3*L.asl[j]+1], L.CX[3*L.asl[j]+2] };
+      const double x[3] = { L.CX[3*sl], L.CX[3*sl+1], L.CX[3*sl+2] };
       double w;
       if( lane < 3 ){
         double t[3]; d_cross( x, f, t );
@@ -974,10 +981,13 @@ RKFD_DEV void rkfd_push_wrenches(const rkfdDevModel &m, const rkfdLds &L, const 
       } else {
         w = lane == 3 ? f[0] : ( lane == 4 ? f[1] : f[2] );
       }
-      const int cinf = L.CIp[j];
-      L.PB[6*RKFD_CI_A( cinf )+lane] -= w;     /* bias force = -external force */
-      L.PB[6*RKFD_CI_B( cinf )+lane] += w;
+      const int a = RKFD_CI_A( cinf ), bq = RKFD_CI_B( cinf );
+      if( a != la ){ if( la >= 0 ) L.PB[6*la+lane] -= sa; la = a; sa = 0; }   /* bias force = -external force */
+      if( bq != lb ){ if( lb >= 0 ) L.PB[6*lb+lane] += sb; lb = bq; sb = 0; }
+      sa += w; sb += w;
     }
+    if( la >= 0 ) L.PB[6*la+lane] -= sa;
+    if( lb >= 0 ) L.PB[6*lb+lane] += sb;
   }
   SYNC();
 }
@@ -1204,65 +1214,55 @@ template<bool prof> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const r
   }
   MST(6);
   /* projected Gauss-Seidel, fixed max_iter sweeps, no warm start (_rkFDSolverMLCP, reference
-   * src/rkfd_mlcp.c:190-249).  lane = row (rows 64.. live in a second register set of the same
-   * lanes); the residual res = b + A f is kept up to date instead of re-forming the dot products. */
+   * src/rkfd_mlcp.c:190-249), same update order.  lane = contact: each lane keeps the three
+   * residuals res = b + A f, forces and inverse diagonals of ITS contact in registers, every lane
+   * evaluates its own Gauss-Seidel candidate, and only the increment of the contact whose turn it
+   * is gets broadcast (v_readlane) and applied to everybody's residuals. */
   {
-    const int row0 = lane, row1 = lane + RKFD_WAVE;
-    const bool on0 = row0 < M, on1 = row1 < M;
-    const bool two = M > RKFD_WAVE;
-    double res0 = on0 ? L.MB[row0] : 0.0, res1 = on1 ? L.MB[row1] : 0.0, f0 = 0.0, f1 = 0.0;
-    const double diag0 = on0 ? L.MA[row0*ld+row0] : 1.0, diag1 = on1 ? L.MA[row1*ld+row1] : 1.0;
-    /* reciprocal diagonal; tangential rows with |a_kk| < zTOL are frozen at 0 (reference :220-221) */
-    const double idiag0 = ( ( row0 % 3 ) != 0 && fabs( diag0 ) < RKFD_DEV_TOL ) ? 0.0 : 1.0/diag0;
-    const double idiag1 = ( ( row1 % 3 ) != 0 && fabs( diag1 ) < RKFD_DEV_TOL ) ? 0.0 : 1.0/diag1;
-    /* friction coefficient of each row's contact (type as of the start of the solve) */
-    double mu0 = 0.0, mu1 = 0.0;
-    if( on0 ){
-      const int jr_ = L.lrg[row0/3], cir_ = RKFD_CI_CI( L.CIp[jr_] );
-      mu0 = L.typ[jr_] == RKFD_SF ? m.ci_sf[cir_] : m.ci_kf[cir_];
+    const bool on = lane < nc;
+    const int r0 = on ? 3*lane : 0;
+    double rn = 0, r1 = 0, r2 = 0, fn = 0, f1 = 0, f2 = 0, in_ = 0, i1 = 0, i2 = 0, mu = 0;
+    if( on ){
+      rn = L.MB[r0]; r1 = L.MB[r0+1]; r2 = L.MB[r0+2];
+      const double dn = L.MA[r0*ld+r0], d1 = L.MA[(r0+1)*ld+r0+1], d2 = L.MA[(r0+2)*ld+r0+2];
+      in_ = 1.0/dn;
+      /* tangential rows with |a_kk| < zTOL are frozen at 0 (reference :220-221) */
+      i1 = fabs( d1 ) < RKFD_DEV_TOL ? 0.0 : 1.0/d1;
+      i2 = fabs( d2 ) < RKFD_DEV_TOL ? 0.0 : 1.0/d2;
+      const int jr_ = L.lrg[lane], cir_ = RKFD_CI_CI( L.CIp[jr_] );
+      mu = L.typ[jr_] == RKFD_SF ? m.ci_sf[cir_] : m.ci_kf[cir_];
     }
-    if( on1 ){
-      const int jr_ = L.lrg[row1/3], cir_ = RKFD_CI_CI( L.CIp[jr_] );
-      mu1 = L.typ[jr_] == RKFD_SF ? m.ci_sf[cir_] : m.ci_kf[cir_];
-    }
-#define ROWB(v0,v1,k) BCAST( ( (k) < RKFD_WAVE ) ? (v0) : (v1), (k) & ( RKFD_WAVE-1 ) )
-#define ROWSET(k,val) do{ if( lane == ( (k) & ( RKFD_WAVE-1 ) ) ){ if( (k) < RKFD_WAVE ) f0 = (val); else f1 = (val); } }while(0)
+    const double *Arow = &L.MA[r0*ld];
     for( int it=0; it<m.max_iter; it++ ){
       for( int c=0; c<nc; c++ ){
-        const int k = 3*c;
-        const double rk = ROWB( res0, res1, k ), fk = ROWB( f0, f1, k ), ikk = ROWB( idiag0, idiag1, k );
-        double ff = fk - rk*ikk;          /* = -( b + a.f - a_kk f_k ) / a_kk */
+        /* normal force of contact c: f_n <- max( 0, -( b + a.f - a_nn f_n ) / a_nn ) */
+        const double a0 = Arow[3*c], a1 = Arow[ld+3*c], a2 = Arow[2*ld+3*c];
+        double ff = fn - rn*in_;
         if( ff < RKFD_DEV_TOL ) ff = 0.0;
-        const double dl = ff - fk;
-        ROWSET( k, ff );
-        if( on0 ) res0 += L.MA[row0*ld+k]*dl;
-        if( two && on1 ) res1 += L.MA[row1*ld+k]*dl;
+        const double dl = BCAST( ff - fn, c );
+        if( lane == c ) fn = ff;
+        rn = fma( a0, dl, rn ); r1 = fma( a1, dl, r1 ); r2 = fma( a2, dl, r2 );
       }
       for( int c=0; c<nc; c++ ){
-        const int k1 = 3*c+1, k2 = 3*c+2;
-        const double r1 = ROWB( res0, res1, k1 ), f1_ = ROWB( f0, f1, k1 ), i11 = ROWB( idiag0, idiag1, k1 );
-        const double r2 = ROWB( res0, res1, k2 ), f2_ = ROWB( f0, f1, k2 ), i22 = ROWB( idiag0, idiag1, k2 );
-        const double fn = ROWB( f0, f1, 3*c );
-        const double ff0 = f1_ - r1*i11;   /* idiag is 0 where |a_kk| < zTOL, f starts at 0 */
-        const double ff1 = f2_ - r2*i22;
+        /* tangential forces of contact c: Gauss-Seidel value for both, then scaled onto the
+         * friction disc of radius mu f_n */
+        const double a0 = Arow[3*c+1], a1 = Arow[ld+3*c+1], a2 = Arow[2*ld+3*c+1];
+        const double b0 = Arow[3*c+2], b1 = Arow[ld+3*c+2], b2 = Arow[2*ld+3*c+2];
+        const double ff0 = f1 - r1*i1, ff1 = f2 - r2*i2;
         const double fnorm = ff0*ff0 + ff1*ff1;
-        const double mu = ROWB( mu0, mu1, k1 );
         double fs = mu*fn; fs = fs*fs;
         double n1, n2;
         if( fnorm < RKFD_DEV_TOL || fs < RKFD_DEV_TOL ){ n1 = 0; n2 = 0; }
-        else if( fnorm > fs ){ const double sc = fs/fnorm; n1 = ff0*sc; n2 = ff1*sc; }
+        else if( fnorm > fs ){ const double sc = fs*RKFD_RCP( fnorm ); n1 = ff0*sc; n2 = ff1*sc; }
         else { n1 = ff0; n2 = ff1; }
-        const double d1 = n1-f1_, d2 = n2-f2_;
-        ROWSET( k1, n1 );
-        ROWSET( k2, n2 );
-        if( on0 ) res0 += L.MA[row0*ld+k1]*d1 + L.MA[row0*ld+k2]*d2;
-        if( two && on1 ) res1 += L.MA[row1*ld+k1]*d1 + L.MA[row1*ld+k2]*d2;
+        const double d1 = BCAST( n1 - f1, c ), d2 = BCAST( n2 - f2, c );
+        if( lane == c ){ f1 = n1; f2 = n2; }
+        rn = fma( a0, d1, fma( b0, d2, rn ) );
+        r1 = fma( a1, d1, fma( b1, d2, r1 ) );
+        r2 = fma( a2, d1, fma( b2, d2, r2 ) );
       }
     }
-#undef ROWB
-#undef ROWSET
-    if( on0 ) L.MF[row0] = f0/dt;
-    if( on1 ) L.MF[row1] = f1/dt;
+    if( on ){ L.MF[r0] = fn/dt; L.MF[r0+1] = f1/dt; L.MF[r0+2] = f2/dt; }
   }
   SYNC();
   MST(7);
@@ -1301,7 +1301,7 @@ template<bool prof> RKFD_DEV int rkfd_evaluate(const rkfdDevModel &m, const rkfd
 #define STAMP(k) do{ if( prof ){ t1 = RKFD_CLOCK(); pc[k] += t1 - t0; t0 = t1; } }while(0)
   if( prof ) t0 = RKFD_CLOCK();
   if( lane < m.ndof ) L.acc[lane] = 0.0;
-  rkfd_phase_kinematics( m, L );
+  rkfd_phase_kinematics<prof>( m, L, pc );
   STAMP(0);
   /* commit joint friction pivots (the reference does so inside rkFDJointFrictionRevolDC) */
   if( doUpRef && lane < m.nlink ){
