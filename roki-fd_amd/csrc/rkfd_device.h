@@ -1397,9 +1397,10 @@ template<bool prof> RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkf
     L.LI[lane]   = m.linfo[lane];
     L.CHI[lane]  = m.child_idx[lane];
     L.PSL[lane]  = m.pslot[lane];
-    L.min[lane]  = st.motor_in[(size_t)b*NL+lane];
-    L.pivt[lane] = st.piv_type[(size_t)b*NL+lane];
-    L.pivp[lane] = st.piv_prev[(size_t)b*NL+lane];
+    const int lm = m.orig[lane];
+    L.min[lane]  = st.motor_in[(size_t)b*m.nlink_model+lm];
+    L.pivt[lane] = st.piv_type[(size_t)b*m.nlink_model+lm];
+    L.pivp[lane] = st.piv_prev[(size_t)b*m.nlink_model+lm];
   }
   if( m.maxrg > 0 ){
     for( int k=lane; k<NL*m.nlevel; k+=RKFD_WAVE ) L.PL[k] = (unsigned char)m.pathlink[k];
@@ -1482,8 +1483,9 @@ template<bool prof> RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkf
     st.acc[(size_t)b*ND+lane] = L.acc[lane];
   }
   if( lane < NL ){
-    st.piv_type[(size_t)b*NL+lane] = L.pivt[lane];
-    st.piv_prev[(size_t)b*NL+lane] = L.pivp[lane];
+    const int lm = m.orig[lane];
+    st.piv_type[(size_t)b*m.nlink_model+lm] = L.pivt[lane];
+    st.piv_prev[(size_t)b*m.nlink_model+lm] = L.pivp[lane];
   }
   for( int j=lane; j<NC; j+=RKFD_WAVE ){
     st.cv_active[(size_t)b*NC+j] = L.act[j];

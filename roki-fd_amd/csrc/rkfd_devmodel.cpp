@@ -24,24 +24,114 @@ struct Blob {
 
 extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevModelHost *out, char *err, int errlen)
 {
-  const int NL = m->nlink, ND = m->ndof, NC = m->ncand;
+  const int NLm = m->nlink, ND = m->ndof, NC = m->ncand;
+  std::vector<int> R_parent, R_jtype, R_dofoff, R_mtype;
+  std::vector<double> R_org;
 #define FAIL(...) do{ if( err ) snprintf( err, errlen, __VA_ARGS__ ); return -1; }while(0)
-  if( NL < 1 ) FAIL( "model has no links" );
-  if( NL > RKFD_MAX_LINK ) FAIL( "nlink %d exceeds the per-wave limit %d", NL, RKFD_MAX_LINK );
+  if( NLm < 1 ) FAIL( "model has no links" );
   if( ND > RKFD_MAX_DOF ) FAIL( "ndof %d exceeds the per-wave limit %d", ND, RKFD_MAX_DOF );
   if( NC > RKFD_MAX_CAND ) FAIL( "ncand %d exceeds the per-wave limit %d", NC, RKFD_MAX_CAND );
   if( max_rigid < 0 ) max_rigid = 0;
   if( 3*max_rigid > RKFD_MAX_ROWS ) FAIL( "3*max_rigid %d exceeds the per-wave limit %d", 3*max_rigid, RKFD_MAX_ROWS );
-  for( int i=0; i<NL; i++ )
+  for( int i=0; i<NLm; i++ )
     if( m->parent[i] >= i ) FAIL( "link %d: parent index must be smaller than the link index", i );
+
+  /* ---- merge rigidly attached links ------------------------------------------------------
+   * A link on a FIXED joint moves with its parent: it is folded into the nearest ancestor that is
+   * not such a link (composite rigid body: summed mass, combined centre of mass and inertia; its
+   * children, shapes and candidate vertices are re-expressed in that ancestor's frame).  The
+   * dynamics are unchanged, the sweeps get fewer links and levels.  Fixed ROOT links stay. */
+  std::vector<int> rep( NLm ), orig;                 /* model link -> device link, and back      */
+  std::vector<double> Trep( (size_t)12*NLm );        /* frame of model link i in its device link  */
+  struct Acc { double m; double mc[3]; std::vector<int> parts; };
+  std::vector<Acc> accs;
+  R_parent.clear(); R_jtype.clear(); R_dofoff.clear(); R_mtype.clear(); R_org.clear();
+  for( int i=0; i<NLm; i++ ){
+    const double *o = &m->org[12*i];
+    const int p = m->parent[i];
+    if( m->jtype[i] == RKFD_JOINT_FIXED && p >= 0 ){
+      /* T(rep<-i) = T(rep<-p) o org_i */
+      const double *Tp = &Trep[12*p];
+      double *T = &Trep[12*i];
+      for( int a=0; a<3; a++ ){
+        for( int b=0; b<3; b++ ) T[3*a+b] = Tp[3*a]*o[b] + Tp[3*a+1]*o[3+b] + Tp[3*a+2]*o[6+b];
+        T[9+a] = Tp[9+a] + Tp[3*a]*o[9] + Tp[3*a+1]*o[10] + Tp[3*a+2]*o[11];
+      }
+      rep[i] = rep[p];
+      accs[rep[i]].parts.push_back( i );
+    } else {
+      const int r = (int)orig.size();
+      rep[i] = r; orig.push_back( i );
+      double *T = &Trep[12*i];
+      for( int k=0; k<12; k++ ) T[k] = ( k == 0 || k == 4 || k == 8 ) ? 1.0 : 0.0;
+      Acc a; a.m = 0; a.mc[0] = a.mc[1] = a.mc[2] = 0; a.parts.push_back( i );
+      accs.push_back( a );
+      R_parent.push_back( p < 0 ? -1 : rep[p] );
+      R_jtype.push_back( m->jtype[i] ); R_dofoff.push_back( m->dofoff[i] ); R_mtype.push_back( m->mtype[i] );
+      /* org' = T(rep[p]<-p) o org_i */
+      double oo[12];
+      if( p < 0 ) for( int k=0; k<12; k++ ) oo[k] = o[k];
+      else {
+        const double *Tp = &Trep[12*p];
+        for( int a=0; a<3; a++ ){
+          for( int b=0; b<3; b++ ) oo[3*a+b] = Tp[3*a]*o[b] + Tp[3*a+1]*o[3+b] + Tp[3*a+2]*o[6+b];
+          oo[9+a] = Tp[9+a] + Tp[3*a]*o[9] + Tp[3*a+1]*o[10] + Tp[3*a+2]*o[11];
+        }
+      }
+      R_org.insert( R_org.end(), oo, oo+12 );
+    }
+  }
+  const int NL = (int)orig.size();
+  if( NL > RKFD_MAX_LINK ) FAIL( "nlink %d (after merging fixed links) exceeds the per-wave limit %d", NL, RKFD_MAX_LINK );
+  std::vector<double> R_mass( NL, 0.0 ), R_com( (size_t)3*NL, 0.0 ), R_inertia( (size_t)9*NL, 0.0 );
+  for( int r=0; r<NL; r++ ){
+    double M = 0, mc[3] = {0,0,0};
+    std::vector<double> cs;                         /* part centres of mass in the device link frame */
+    for( size_t q=0; q<accs[r].parts.size(); q++ ){
+      const int i = accs[r].parts[q];
+      const double *T = &Trep[12*i], *c = &m->com[3*i];
+      double cc[3];
+      for( int a=0; a<3; a++ ) cc[a] = T[9+a] + T[3*a]*c[0] + T[3*a+1]*c[1] + T[3*a+2]*c[2];
+      cs.insert( cs.end(), cc, cc+3 );
+      M += m->mass[i];
+      for( int a=0; a<3; a++ ) mc[a] += m->mass[i]*cc[a];
+    }
+    double com[3] = {0,0,0};
+    if( M > 0 ) for( int a=0; a<3; a++ ) com[a] = mc[a]/M;
+    else for( int a=0; a<3; a++ ) com[a] = cs[a];
+    double I[9] = {0,0,0,0,0,0,0,0,0};
+    for( size_t q=0; q<accs[r].parts.size(); q++ ){
+      const int i = accs[r].parts[q];
+      const double *T = &Trep[12*i], *Ii = &m->inertia[9*i];
+      double RI[9], RIRt[9];
+      for( int a=0; a<3; a++ ) for( int b=0; b<3; b++ ) RI[3*a+b] = T[3*a]*Ii[b] + T[3*a+1]*Ii[3+b] + T[3*a+2]*Ii[6+b];
+      for( int a=0; a<3; a++ ) for( int b=0; b<3; b++ ) RIRt[3*a+b] = RI[3*a]*T[3*b] + RI[3*a+1]*T[3*b+1] + RI[3*a+2]*T[3*b+2];
+      const double d[3] = { cs[3*q]-com[0], cs[3*q+1]-com[1], cs[3*q+2]-com[2] };
+      const double d2 = d[0]*d[0] + d[1]*d[1] + d[2]*d[2];
+      for( int a=0; a<3; a++ ) for( int b=0; b<3; b++ )
+        I[3*a+b] += RIRt[3*a+b] + m->mass[i]*( ( a == b ? d2 : 0.0 ) - d[a]*d[b] );
+    }
+    R_mass[r] = M;
+    for( int a=0; a<3; a++ ) R_com[3*r+a] = com[a];
+    for( int a=0; a<9; a++ ) R_inertia[9*r+a] = I[a];
+  }
+  /* 1-DoF joint parameters of the surviving links */
+  std::vector<double> R_stiff( NL ), R_visc( NL ), R_coulomb( NL ), R_sfric( NL ), R_mot_k( NL ), R_mot_admit( NL ),
+                      R_mot_vmax( NL ), R_mot_vmin( NL ), R_mot_gear( NL ), R_mot_inertia( NL );
+  for( int r=0; r<NL; r++ ){
+    const int i = orig[r];
+    R_stiff[r] = m->stiff[i]; R_visc[r] = m->visc[i]; R_coulomb[r] = m->coulomb[i]; R_sfric[r] = m->sfric[i];
+    R_mot_k[r] = m->mot_k[i]; R_mot_admit[r] = m->mot_admit[i]; R_mot_vmax[r] = m->mot_vmax[i]; R_mot_vmin[r] = m->mot_vmin[i];
+    R_mot_gear[r] = m->mot_gear[i]; R_mot_inertia[r] = m->mot_inertia[i];
+  }
 
   /* depth, levels */
   std::vector<int> depth( NL ), is_static( NL );
   int nlevel = 0;
   for( int i=0; i<NL; i++ ){
-    const int p = m->parent[i];
+    const int p = R_parent[i];
     depth[i] = p < 0 ? 0 : depth[p]+1;
-    is_static[i] = ( m->jtype[i] == RKFD_JOINT_FIXED ) && ( p < 0 || is_static[p] );
+    is_static[i] = ( R_jtype[i] == RKFD_JOINT_FIXED ) && ( p < 0 || is_static[p] );
     if( depth[i]+1 > nlevel ) nlevel = depth[i]+1;
   }
   int nround = 0;
@@ -55,7 +145,7 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   }
   /* ancestor tables for pointer jumping */
   std::vector<int> anc( (size_t)( nround ? nround : 1 )*NL, -1 );
-  for( int i=0; i<NL; i++ ) if( nround ) anc[i] = m->parent[i];
+  for( int i=0; i<NL; i++ ) if( nround ) anc[i] = R_parent[i];
   for( int r=1; r<nround; r++ )
     for( int i=0; i<NL; i++ ){
       const int a = anc[(size_t)(r-1)*NL+i];
@@ -63,35 +153,49 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
     }
   /* children CSR */
   std::vector<int> child_off( NL+1, 0 ), child_idx( NL );
-  for( int i=0; i<NL; i++ ) if( m->parent[i] >= 0 ) child_off[m->parent[i]+1]++;
+  for( int i=0; i<NL; i++ ) if( R_parent[i] >= 0 ) child_off[R_parent[i]+1]++;
   for( int i=0; i<NL; i++ ) child_off[i+1] += child_off[i];
   {
     std::vector<int> cur( child_off.begin(), child_off.end()-1 );
-    for( int i=0; i<NL; i++ ) if( m->parent[i] >= 0 ) child_idx[cur[m->parent[i]]++] = i;
+    for( int i=0; i<NL; i++ ) if( R_parent[i] >= 0 ) child_idx[cur[R_parent[i]]++] = i;
   }
   /* ancestor at depth d */
   std::vector<int> pathlink( (size_t)NL*nlevel, -1 );
   for( int i=0; i<NL; i++ ){
     int a = i;
-    while( a >= 0 ){ pathlink[(size_t)i*nlevel+depth[a]] = a; a = m->parent[a]; }
+    while( a >= 0 ){ pathlink[(size_t)i*nlevel+depth[a]] = a; a = R_parent[a]; }
   }
-  /* candidates */
+  /* candidates: owner / other link after merging, vertex in the owner device link's frame;
+   * planes of every shape re-expressed in its device link's frame */
+  const int nplane_m = m->nshape > 0 ? m->shape_foff[m->nshape] : 0;
+  std::vector<double> planes_d( (size_t)4*( nplane_m ? nplane_m : 1 ) );
+  for( int sh=0; sh<m->nshape; sh++ ){
+    const double *T = &Trep[12*m->shape_link[sh]];
+    for( int f=m->shape_foff[sh]; f<m->shape_foff[sh+1]; f++ ){
+      const double *pl = &m->planes[4*f];
+      double n[3];
+      for( int a=0; a<3; a++ ) n[a] = T[3*a]*pl[0] + T[3*a+1]*pl[1] + T[3*a+2]*pl[2];
+      planes_d[4*f] = n[0]; planes_d[4*f+1] = n[1]; planes_d[4*f+2] = n[2];
+      planes_d[4*f+3] = pl[3] + n[0]*T[9] + n[1]*T[10] + n[2]*T[11];
+    }
+  }
   std::vector<int> cA( NC ), cB( NC ), cfo( NC ), cnf( NC ), cci( NC );
   std::vector<double> cv( (size_t)3*NC );
   for( int j=0; j<NC; j++ ){
     const int pr = m->cand_pair[j], sd = m->cand_side[j];
     const int shA = m->pair_shape[2*pr+sd], shB = m->pair_shape[2*pr+1-sd];
-    cA[j] = m->shape_link[shA]; cB[j] = m->shape_link[shB];
+    cA[j] = rep[m->shape_link[shA]]; cB[j] = rep[m->shape_link[shB]];
     cfo[j] = m->shape_foff[shB]; cnf[j] = m->shape_foff[shB+1] - m->shape_foff[shB];
     cci[j] = m->pair_ci[pr];
-    for( int k=0; k<3; k++ ) cv[3*j+k] = m->verts[3*m->cand_vert[j]+k];
+    const double *T = &Trep[12*m->shape_link[shA]], *v = &m->verts[3*m->cand_vert[j]];
+    for( int a=0; a<3; a++ ) cv[3*j+a] = T[9+a] + T[3*a]*v[0] + T[3*a+1]*v[1] + T[3*a+2]*v[2];
   }
   const int nplane = m->nshape > 0 ? m->shape_foff[m->nshape] : 0;
   if( m->nci > 255 ) FAIL( "too many contact infos" );
   /* packed link / candidate info */
   std::vector<int> linfo( NL ), cinfo( NC );
   for( int i=0; i<NL; i++ )
-    linfo[i] = RKFD_LI_PACK( m->parent[i], m->jtype[i], depth[i], is_static[i], m->mtype[i], m->dofoff[i] );
+    linfo[i] = RKFD_LI_PACK( R_parent[i], R_jtype[i], depth[i], is_static[i], R_mtype[i], R_dofoff[i] );
   for( int j=0; j<NC; j++ ){
     if( cnf[j] > 255 ) FAIL( "a collision shape has more than 255 faces" );
     cinfo[j] = cA[j] | ( cB[j] << 8 ) | ( cci[j] << 16 ) | ( cnf[j] << 24 );
@@ -144,14 +248,14 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
         const int nchild = child_off[i+1] - child_off[i];
         if( nchild == 1 ){
           const int ch = child_idx[child_off[i]];
-          if( iter[ch] == iter[i]+1 && slot[ch] == slot[i] && m->jtype[ch] != RKFD_JOINT_FLOAT ) carried[ch] = 1;
+          if( iter[ch] == iter[i]+1 && slot[ch] == slot[i] && R_jtype[ch] != RKFD_JOINT_FLOAT ) carried[ch] = 1;
         }
       }
       for( int i=0; i<NL; i++ ){
         pslot[i] = -1;
-        if( m->parent[i] >= 0 && m->jtype[i] != RKFD_JOINT_FLOAT && !carried[i] ) pslot[i] = npool++;
+        if( R_parent[i] >= 0 && R_jtype[i] != RKFD_JOINT_FLOAT && !carried[i] ) pslot[i] = npool++;
         fslot[i] = -1;
-        if( m->jtype[i] == RKFD_JOINT_FLOAT ) fslot[i] = nfloat++;
+        if( R_jtype[i] == RKFD_JOINT_FLOAT ) fslot[i] = nfloat++;
       }
     }
     for( int t=-2; t<nsched+2; t++ )
@@ -163,9 +267,9 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
           int flags = 0;
           if( nchild == 1 ){
             const int ch = child_idx[child_off[i]];
-            if( iter[ch] == t+1 && slot[ch] == g && m->jtype[ch] != RKFD_JOINT_FLOAT ) flags |= 1;
+            if( iter[ch] == t+1 && slot[ch] == g && R_jtype[ch] != RKFD_JOINT_FLOAT ) flags |= 1;
           }
-          if( m->parent[i] >= 0 && iter[m->parent[i]] == t-1 && slot[m->parent[i]] == g ) flags |= 2;
+          if( R_parent[i] >= 0 && iter[R_parent[i]] == t-1 && slot[R_parent[i]] == g ) flags |= 2;
           if( nchild > 255 || pslot[i]+1 > 255 || fslot[i]+1 > 255 ) FAIL( "schedule record overflow" );
           rec[0] = i; rec[1] = linfo[i];
           rec[2] = nchild | ( flags << 8 ) | ( ( pslot[i]+1 ) << 16 ) | ( ( fslot[i]+1 ) << 24 );
@@ -178,7 +282,7 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   Blob b;
   rkfdDevModel dm;
   memset( &dm, 0, sizeof(dm) );
-  dm.nlink = NL; dm.ndof = ND; dm.ncand = NC; dm.nlevel = nlevel; dm.nround = nround; dm.nci = m->nci;
+  dm.nlink = NL; dm.nlink_model = NLm; dm.ndof = ND; dm.ncand = NC; dm.nlevel = nlevel; dm.nround = nround; dm.nci = m->nci;
   dm.solver = m->solver; dm.max_iter = m->max_iter; dm.maxrg = max_rigid;
   dm.dt = m->dt; dm.fric_w = m->friction_weight;
   dm.nsched = nsched; dm.npool = npool; dm.nfloat = nfloat;
@@ -194,16 +298,17 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   struct Ent { const void **slot; size_t off; };
   std::vector<Ent> ents;
 #define PUT(field, src, bytes) ents.push_back( Ent{ (const void **)&dm.field, b.put( src, bytes ) } )
-  PUT( parent, m->parent, sizeof(int)*NL ); PUT( jtype, m->jtype, sizeof(int)*NL );
-  PUT( dofoff, m->dofoff, sizeof(int)*NL ); PUT( mtype, m->mtype, sizeof(int)*NL );
+  PUT( parent, R_parent.data(), sizeof(int)*NL ); PUT( jtype, R_jtype.data(), sizeof(int)*NL );
+  PUT( dofoff, R_dofoff.data(), sizeof(int)*NL ); PUT( mtype, R_mtype.data(), sizeof(int)*NL );
+  PUT( orig, orig.data(), sizeof(int)*NL );
   PUT( depth, depth.data(), sizeof(int)*NL ); PUT( is_static, is_static.data(), sizeof(int)*NL );
-  PUT( org, m->org, sizeof(double)*12*NL ); PUT( mass, m->mass, sizeof(double)*NL );
-  PUT( com, m->com, sizeof(double)*3*NL ); PUT( inertia, m->inertia, sizeof(double)*9*NL );
-  PUT( stiff, m->stiff, sizeof(double)*NL ); PUT( visc, m->visc, sizeof(double)*NL );
-  PUT( coulomb, m->coulomb, sizeof(double)*NL ); PUT( sfric, m->sfric, sizeof(double)*NL );
-  PUT( mot_k, m->mot_k, sizeof(double)*NL ); PUT( mot_admit, m->mot_admit, sizeof(double)*NL );
-  PUT( mot_vmax, m->mot_vmax, sizeof(double)*NL ); PUT( mot_vmin, m->mot_vmin, sizeof(double)*NL );
-  PUT( mot_gear, m->mot_gear, sizeof(double)*NL ); PUT( mot_inertia, m->mot_inertia, sizeof(double)*NL );
+  PUT( org, R_org.data(), sizeof(double)*12*NL ); PUT( mass, R_mass.data(), sizeof(double)*NL );
+  PUT( com, R_com.data(), sizeof(double)*3*NL ); PUT( inertia, R_inertia.data(), sizeof(double)*9*NL );
+  PUT( stiff, R_stiff.data(), sizeof(double)*NL ); PUT( visc, R_visc.data(), sizeof(double)*NL );
+  PUT( coulomb, R_coulomb.data(), sizeof(double)*NL ); PUT( sfric, R_sfric.data(), sizeof(double)*NL );
+  PUT( mot_k, R_mot_k.data(), sizeof(double)*NL ); PUT( mot_admit, R_mot_admit.data(), sizeof(double)*NL );
+  PUT( mot_vmax, R_mot_vmax.data(), sizeof(double)*NL ); PUT( mot_vmin, R_mot_vmin.data(), sizeof(double)*NL );
+  PUT( mot_gear, R_mot_gear.data(), sizeof(double)*NL ); PUT( mot_inertia, R_mot_inertia.data(), sizeof(double)*NL );
   PUT( anc, anc.data(), sizeof(int)*anc.size() );
   PUT( level_off, level_off.data(), sizeof(int)*( nlevel+1 ) ); PUT( level_link, level_link.data(), sizeof(int)*NL );
   PUT( child_off, child_off.data(), sizeof(int)*( NL+1 ) ); PUT( child_idx, child_idx.data(), sizeof(int)*NL );
@@ -214,7 +319,7 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   PUT( cand_linkA, cA.data(), sizeof(int)*NC ); PUT( cand_linkB, cB.data(), sizeof(int)*NC );
   PUT( cand_foff, cfo.data(), sizeof(int)*NC ); PUT( cand_nf, cnf.data(), sizeof(int)*NC );
   PUT( cand_ci, cci.data(), sizeof(int)*NC ); PUT( cand_vert, cv.data(), sizeof(double)*3*NC );
-  PUT( planes, m->planes, sizeof(double)*4*nplane );
+  PUT( planes, planes_d.data(), sizeof(double)*4*nplane );
   PUT( ci_type, m->ci_type, sizeof(int)*m->nci );
   PUT( ci_sf, m->ci_sf, sizeof(double)*m->nci ); PUT( ci_kf, m->ci_kf, sizeof(double)*m->nci );
   PUT( ci_k, m->ci_k, sizeof(double)*m->nci ); PUT( ci_l, m->ci_l, sizeof(double)*m->nci );
@@ -254,7 +359,7 @@ extern "C" void rkfd_devmodel_rebase(rkfdDevModel *dm, const void *from, const v
   RB(parent); RB(jtype); RB(dofoff); RB(mtype); RB(depth); RB(is_static);
   RB(org); RB(mass); RB(com); RB(inertia); RB(stiff); RB(visc); RB(coulomb); RB(sfric);
   RB(mot_k); RB(mot_admit); RB(mot_vmax); RB(mot_vmin); RB(mot_gear); RB(mot_inertia);
-  RB(anc); RB(level_off); RB(level_link); RB(child_off); RB(child_idx); RB(pathlink); RB(linfo); RB(sched); RB(cinfo); RB(pslot);
+  RB(anc); RB(level_off); RB(level_link); RB(child_off); RB(child_idx); RB(pathlink); RB(linfo); RB(sched); RB(cinfo); RB(pslot); RB(orig);
   RB(cand_linkA); RB(cand_linkB); RB(cand_foff); RB(cand_nf); RB(cand_ci); RB(cand_vert); RB(planes);
   RB(ci_type); RB(ci_sf); RB(ci_kf); RB(ci_k); RB(ci_l); RB(ci_e); RB(ci_v);
 #undef RB

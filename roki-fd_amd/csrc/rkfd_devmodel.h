@@ -14,7 +14,8 @@
 #define RKFD_MAX_ROWS    128  /* 3 * (rigid contact vertices): two MLCP rows per lane at most */
 
 typedef struct {
-  int nlink, ndof, ncand;
+  int nlink, ndof, ncand;   /* nlink: device links (rigidly attached links are merged into their parents) */
+  int nlink_model;          /* links of the rkfdModel: stride of motor_in / piv_* state arrays        */
   int nlevel;            /* number of tree levels (max depth + 1)                       */
   int nround;            /* pointer-jumping rounds = ceil(log2(nlevel))                 */
   int nci;
@@ -25,6 +26,7 @@ typedef struct {
   double dt, fric_w;
   /* per link */
   const int *parent, *jtype, *dofoff, *mtype, *depth, *is_static;
+  const int *orig;       /* [nlink] model link of a device link                                       */
   const double *org, *mass, *com, *inertia;
   const double *stiff, *visc, *coulomb, *sfric;
   const double *mot_k, *mot_admit, *mot_vmax, *mot_vmin, *mot_gear, *mot_inertia;
