@@ -79,8 +79,10 @@ double *rkfdBatchDevDis(rkfdBatch *b);
 double *rkfdBatchDevVel(rkfdBatch *b);
 double *rkfdBatchDevAcc(rkfdBatch *b);
 
-/* kernel resource facts for measurement: LDS bytes per instance, grid size */
+/* kernel resource facts for measurement: LDS bytes per instance */
 int rkfdBatchLdsBytes(const rkfdBatch *b);
+/* the same figure computed on the host for a model and contact capacity (no GPU needed) */
+int rkfdLdsBytesFor(const rkfdModel *m, int max_rigid);
 
 #ifdef __cplusplus
 }

@@ -89,6 +89,7 @@ def lib():
     L.rkfdBatchUpdateInit.argtypes = [vp, vp]
     L.rkfdBatchUpdate.argtypes = [vp, C.c_int, vp]
     L.rkfdBatchEval.argtypes = [vp, C.c_int, vp]
+    L.rkfdLdsBytesFor.argtypes = [C.POINTER(RkfdModel), C.c_int]
     L.rkfdBatchStatus.argtypes = [vp, vp]
     L.rkfdBatchProfile.argtypes = [vp, C.c_int, vp]
     for f in ("rkfdBatchDevDis", "rkfdBatchDevVel", "rkfdBatchDevAcc"):

@@ -123,6 +123,17 @@ extern "C" void rkfdBatchDestroy(rkfdBatch *b)
   free( b );
 }
 
+/* host-only: LDS bytes one instance of world m would occupy (no GPU needed) */
+extern "C" int rkfdLdsBytesFor(const rkfdModel *m, int max_rigid)
+{
+  rkfdDevModelHost h;
+  char err[256];
+  if( !m || rkfd_devmodel_build( m, max_rigid, &h, err, sizeof(err) ) < 0 ){ SETERR( "rkfdLdsBytesFor: %s", m ? err : "null model" ); return -1; }
+  const int n = (int)h.lds_bytes;
+  rkfd_devmodel_free( &h );
+  return n;
+}
+
 extern "C" int rkfdBatchSize(const rkfdBatch *b){ return b ? b->batch : -1; }
 extern "C" int rkfdBatchDof(const rkfdBatch *b){ return b ? b->ndof : -1; }
 extern "C" int rkfdBatchLdsBytes(const rkfdBatch *b){ return b ? (int)b->lds_bytes : -1; }

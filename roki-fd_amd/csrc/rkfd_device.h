@@ -264,7 +264,8 @@ RKFD_DEV double d_clamp(double x, double lo, double hi){ return x < lo ? lo : ( 
 /* ------------------------------------------------------------------------ */
 /* LDS carve-up for one instance */
 typedef struct {
-  double *q, *qd, *acc, *tmp;     /* [ndof] each                                         */
+  double *q, *qd, *acc;           /* [ndof] each                                         */
+  double *tmp;                    /* [ndof] scratch of rkfd_cat_dis: ALIASES V (dead between evaluations) */
   double *S;                      /* [NL*6]  joint axis (ang, lin)                        */
   double *V;                      /* [NL*6]  spatial velocity                             */
   double *C;                      /* [NL*6]  velocity-product acceleration                */
@@ -274,7 +275,8 @@ typedef struct {
   double *X;                      /* [NL*12] world frames R(9) p(3): ALIASES PA|AC, valid from the
                                      kinematics phase to the end of the collision phase   */
   double *U;                      /* [NL*6]                                               */
-  double *W;                      /* [NL*6]  Ia c, kept for the bias-only sweep           */
+  double *W;                      /* [NL*6]  Ia c, kept for the bias-only sweep: ALIASES V (the link velocities are
+                                     dead once the contact phases and rkfd_phase_bvel are done) */
   double *MS;                     /* [NL*4]  Dinv, u, tau, jm                             */
   double *IST;                    /* [NL*14] inertia staging: A = Iw + m(|r|^2 1 - r r') (xx,xy,xz,yy,yz,zz),
                                      +m r (3), -m r (3), m, 0: every entry of the 6x6 is one of these */
@@ -282,26 +284,26 @@ typedef struct {
   double *CHOL;                   /* [nfloat*36] articulated inertia / Cholesky factor of float joints */
   double *XF;                     /* [nfloat*12] float joints: world orientation of the joint-origin frame (9), link position (3) */
   double *CX, *AX, *RW, *PRO;     /* per ACTIVE contact slot (capacity maxact): 3, 9, 3, 3 */
-  double *REF, *CF;               /* per candidate: stick anchor (state), contact force (output) */
+  double *REF;                    /* stick anchors (state): per active slot when ncand <= 64, else per candidate */
+  double *CF;                     /* contact forces (output): per active slot              */
   double *MA, *MB, *MF, *PU;      /* MLCP: [M*(M+1)] (ALIASES IST|POOL), [M], [M], [2*nlevel*M] */
-  int *act, *typ, *lrg, *lel, *tgt, *cnt, *dofkind, *pivt;
+  int *act, *typ, *lrg, *lel, *tgt, *cnt;
   int *asl;                       /* [NC] active-contact slot of a candidate              */
   int *LI;                        /* [NL] packed link info (RKFD_LI_*)                    */
   int *CIp, *CFO;                 /* [NC] packed candidate info, first plane              */
   int *CHI;                       /* [NL] children lists (CSR values; offsets in the schedule)     */
   int *PSL;                       /* [NL] pool slot of a link (-1 none)                   */
   unsigned char *PL;              /* [NL*nlevel] ancestor at depth d (MLCP only), one byte each */
-  double *pivp, *min;             /* [NL] pivot prev torque, motor input                  */
 } rkfdLds;
 
-RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int M, int nlevel, int npool, int nfloat, int maxact, int nside)
+RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int M, int nlevel, int npool, int nfloat, int maxact, int nside, int pu_alias)
 /* must match the byte count computed in rkfd_devmodel.cpp */
 {
   double *d = (double *)base;
-  L->q = d; d += ND; L->qd = d; d += ND; L->acc = d; d += ND; L->tmp = d; d += ND;
-  L->S = d; d += NL*6; L->V = d; d += NL*6; L->C = d; d += NL*6; L->PB = d; d += NL*6;
+  L->q = d; d += ND; L->qd = d; d += ND; L->acc = d; d += ND;
+  L->S = d; d += NL*6; L->V = d; L->tmp = d; d += NL*6; L->C = d; d += NL*6; L->PB = d; d += NL*6;
   L->PA = d; L->X = d; d += NL*6; L->AC = d; d += NL*6;
-  L->U = d; d += NL*6; L->W = d; d += NL*6; L->MS = d; d += NL*4;
+  L->U = d; d += NL*6; L->W = L->V; L->MS = d; d += NL*4;
   {
     int stage = 14*NL + 36*npool;
     L->IST = d; L->POOL = d + 14*NL; L->MA = d;
@@ -310,16 +312,23 @@ RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int
   }
   L->CHOL = d; d += 36*nfloat; L->XF = d; d += 12*nfloat;
   L->CX = d; d += maxact*3; L->AX = d; d += maxact*9; L->RW = d; d += maxact*3; L->PRO = d; d += maxact*3;
-  L->REF = d; d += NC*3; L->CF = d; d += NC*3;
-  L->MB = d; d += M; L->MF = d; d += M; L->PU = d; d += nside*nlevel*M;
-  L->pivp = d; d += NL; L->min = d; d += NL;
+  L->REF = d; d += ( NC <= RKFD_WAVE ? maxact : NC )*3; L->CF = d; d += maxact*3;
+  L->MB = d; d += M; L->MF = d; d += M;
+  /* probe scratch: lives between the computation of b and the bias-only sweep, when PA|AC are dead */
+  if( pu_alias ) L->PU = L->PA; else { L->PU = d; d += nside*nlevel*M; }
   int *ip = (int *)d;
-  L->act = ip; ip += NC; L->typ = ip; ip += NC; L->lrg = ip; ip += NC; L->lel = ip; ip += NC;
-  L->tgt = ip; ip += NC; L->cnt = ip; ip += 8; L->dofkind = ip; ip += ND; L->pivt = ip; ip += NL;
-  L->LI = ip; ip += NL; L->CIp = ip; ip += NC; L->CFO = ip; ip += NC; L->CHI = ip; ip += NL;
-  L->PSL = ip; ip += NL; L->asl = ip; ip += NC;
+  L->act = ip; ip += NC; L->typ = ip; ip += NC; L->asl = ip; ip += NC; L->CIp = ip; ip += NC; L->CFO = ip; ip += NC;
+  L->lrg = ip; ip += maxact; L->lel = ip; ip += maxact; L->tgt = ip; ip += 2*maxact; L->cnt = ip; ip += 8;
+  L->LI = ip; ip += NL; L->CHI = ip; ip += NL; L->PSL = ip; ip += NL;
   L->PL = (unsigned char *)ip;
 }
+
+/* per-lane state that only lane = link ever touches: kept in registers for the whole launch */
+typedef struct { double min, pivp; int pivt; } rkfdLaneLink;
+
+/* the stick anchors REF live per active-contact slot when all candidates fit one sweep of the
+ * wave (ncand <= 64), else per candidate */
+#define RIDX(j) ( m.ref_by_slot ? L.asl[j] : (j) )
 
 /* counters in L->cnt */
 #define CNT_NRG 0
@@ -331,7 +340,7 @@ RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int
 /* phase: forward kinematics, link velocities, per-link spatial inertia and bias terms.
  * Mirrors _rkFDConnectJointState (reference src/rkfd_sim.c:290-302) + the per-link set-up
  * of RoKi's ABA.  lane = link. */
-template<bool prof> RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, const rkfdLds &L, unsigned long long *pc)
+template<bool prof> RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, const rkfdLds &L, const rkfdLaneLink &ll, unsigned long long *pc)
 {
   unsigned long long k0 = prof ? RKFD_CLOCK() : 0ull, k1;
 #define KST(k) do{ if( prof ){ k1 = RKFD_CLOCK(); pc[k] += k1 - k0; k0 = k1; } }while(0)
@@ -527,15 +536,15 @@ template<bool prof> RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, c
       if( jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM ){
         const int mt = RKFD_LI_MT( li );
         double tin = 0, treg = 0, tf = 0;
-        const double in = L.min[i];
+        const double in = ll.min;
         if( mt == RKFD_MOTOR_DC ){
           const double gk = m.mot_gear[i]*m.mot_k[i];
           jm = m.mot_inertia[i]*m.mot_gear[i]*m.mot_gear[i];
           tin = m.mot_admit[i]*gk*d_clamp( in, m.mot_vmin[i], m.mot_vmax[i] );
           treg = m.mot_admit[i]*gk*gk*qd1;
-          tf = jm*( -qd1/m.dt ) - tin + treg + L.pivp[i];
+          tf = jm*( -qd1/m.dt ) - tin + treg + ll.pivp;
           double fmax;
-          if( L.pivt[i] == RKFD_SF ) fmax = m.sfric[i];
+          if( ll.pivt == RKFD_SF ) fmax = m.sfric[i];
           else {
             const double q = L.q[off];
             const double sg = qd1 > 0 ? 1.0 : ( qd1 < 0 ? -1.0 : 0.0 );
@@ -905,9 +914,13 @@ RKFD_DEV void rkfd_phase_collision(const rkfdDevModel &m, const rkfdLds &L)
         const double sd = m.planes[4*f]*y[0] + m.planes[4*f+1]*y[1] + m.planes[4*f+2]*y[2] - m.planes[4*f+3];
         if( sd > smax ){ smax = sd; fbest = f; }
       }
-      L.CF[3*j] = 0; L.CF[3*j+1] = 0; L.CF[3*j+2] = 0;
       is_act = fbest >= 0 && smax < RKFD_DEV_TOL;
     }
+    /* anchors of the contacts that persist, read at their OLD slots before anything is rewritten */
+    double oref[3] = {0,0,0};
+    const int was = on ? L.act[j] : 0;
+    if( was ){ const int ri = RIDX( j ); oref[0] = L.REF[3*ri]; oref[1] = L.REF[3*ri+1]; oref[2] = L.REF[3*ri+2]; }
+    LDS_FENCE();
     /* active contacts get a slot in the per-contact arrays (capacity m.maxact) in candidate order */
     const unsigned long long mact = BALLOT( is_act );
     const int slot = base_act + __builtin_popcountll( mact & below );
@@ -921,11 +934,15 @@ RKFD_DEV void rkfd_phase_collision(const rkfdDevModel &m, const rkfdLds &L)
         L.CX[3*slot] = x[0]; L.CX[3*slot+1] = x[1]; L.CX[3*slot+2] = x[2];
         L.PRO[3*slot] = pro[0]; L.PRO[3*slot+1] = pro[1]; L.PRO[3*slot+2] = pro[2];
         d_mulv( RB, n, nw );
-        if( !L.act[j] ){
+        if( !was ){
           L.act[j] = 1; L.typ[j] = RKFD_SF;
-          L.REF[3*j] = pro[0]; L.REF[3*j+1] = pro[1]; L.REF[3*j+2] = pro[2];
+          ref[0] = pro[0]; ref[1] = pro[1]; ref[2] = pro[2];
+        } else { ref[0] = oref[0]; ref[1] = oref[1]; ref[2] = oref[2]; }
+        {
+          const int ri = m.ref_by_slot ? slot : j;
+          L.REF[3*ri] = ref[0]; L.REF[3*ri+1] = ref[1]; L.REF[3*ri+2] = ref[2];
         }
-        ref[0] = L.REF[3*j]; ref[1] = L.REF[3*j+1]; ref[2] = L.REF[3*j+2];
+        L.CF[3*slot] = 0; L.CF[3*slot+1] = 0; L.CF[3*slot+2] = 0;
         d_mulv( RB, ref, rw );
         L.RW[3*slot] = rw[0]+pB[0]; L.RW[3*slot+1] = rw[1]+pB[1]; L.RW[3*slot+2] = rw[2]+pB[2];
         d_ortho_space( nw, t1, t2 );
@@ -972,7 +989,7 @@ RKFD_DEV void rkfd_push_wrenches(const rkfdDevModel &m, const rkfdLds &L, const 
     double sa = 0, sb = 0;
     for( int e=0; e<n; e++ ){
       const int j = list[e], sl = L.asl[j], cinf = L.CIp[j];
-      const double f[3] = { L.CF[3*j], L.CF[3*j+1], L.CF[3*j+2] };
+      const double f[3] = { L.CF[3*sl], L.CF[3*sl+1], L.CF[3*sl+2] };
       const double x[3] = { L.CX[3*sl], L.CX[3*sl+1], L.CX[3*sl+2] };
       double w;
       if( lane < 3 ){
@@ -1012,7 +1029,7 @@ RKFD_DEV void d_modify_friction(const rkfdDevModel &m, const rkfdLds &L, int j, 
     }
     if( doUpRef ){
       L.typ[j] = RKFD_KF;
-      L.REF[3*j] = L.PRO[3*L.asl[j]]; L.REF[3*j+1] = L.PRO[3*L.asl[j]+1]; L.REF[3*j+2] = L.PRO[3*L.asl[j]+2];
+      { const int ri = RIDX( j ), sl_ = L.asl[j]; L.REF[3*ri] = L.PRO[3*sl_]; L.REF[3*ri+1] = L.PRO[3*sl_+1]; L.REF[3*ri+2] = L.PRO[3*sl_+2]; }
     }
   } else {
     if( doUpRef ) L.typ[j] = RKFD_SF;
@@ -1041,17 +1058,44 @@ RKFD_DEV void rkfd_phase_penalty(const rkfdDevModel &m, const rkfdLds &L, bool d
     } else {
       d_modify_friction( m, L, j, vr, f, doUpRef );
     }
-    L.CF[3*j] = f[0]; L.CF[3*j+1] = f[1]; L.CF[3*j+2] = f[2];
+    { const int sl_ = L.asl[j]; L.CF[3*sl_] = f[0]; L.CF[3*sl_+1] = f[1]; L.CF[3*sl_+2] = f[2]; }
   }
   SYNC();
   rkfd_push_wrenches( m, L, L.lel, nel );
+}
+
+/* velocity-dependent parts of the MLCP bias for rigid contact `lane` (lane = position in the rigid
+ * list): bv[0..2] = axis . relative point velocity, bv[3..5] = axis . ( w x ( v_O + w x p ) of the
+ * owner link minus that of the other link ).  Evaluated before the sweeps so that the link
+ * velocities V need not outlive the contact phases (their LDS is reused for W = Ia c). */
+RKFD_DEV void rkfd_phase_bvel(const rkfdDevModel &m, const rkfdLds &L, double *bv)
+{
+  const int lane = LANE();
+  const int nc = L.cnt[CNT_NRG];
+#pragma unroll
+  for( int k=0; k<6; k++ ) bv[k] = 0;
+  if( lane < nc ){
+    const int j = L.lrg[lane], cinf = L.CIp[j], sl = L.asl[j];
+    const int la = RKFD_CI_A( cinf ), lb = RKFD_CI_B( cinf );
+    const double x[3] = { L.CX[3*sl], L.CX[3*sl+1], L.CX[3*sl+2] };
+    double va[3], vb[3], ca[3], cb[3];
+    d_point_vel( &L.V[6*la], x, va ); d_point_vel( &L.V[6*lb], x, vb );
+    d_cross( &L.V[6*la], va, ca ); d_cross( &L.V[6*lb], vb, cb );
+#pragma unroll
+    for( int i=0; i<3; i++ ){
+      const double *ax = &L.AX[9*sl+3*i];
+      bv[i]   = ax[0]*( va[0]-vb[0] ) + ax[1]*( va[1]-vb[1] ) + ax[2]*( va[2]-vb[2] );
+      bv[3+i] = ax[0]*( ca[0]-cb[0] ) + ax[1]*( ca[1]-cb[1] ) + ax[2]*( ca[2]-cb[2] );
+    }
+  }
+  SYNC();
 }
 
 /* ------------------------------------------------------------------------ */
 /* MLCP rigid branch (reference src/rkfd_mlcp.c:287-297).  Preconditions: sweep 2 (full) and
  * sweep 3 have been run with the wrenches applied so far (rkFDUpdateAccBias), so AC holds
  * the free accelerations and IA/U/MS hold Ia, U, Dinv.  Adds the contact wrenches to FE. */
-template<bool prof> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L, unsigned long long *pc)
+template<bool prof> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L, const double *bv, unsigned long long *pc)
 {
   unsigned long long q0 = prof ? RKFD_CLOCK() : 0ull, q1;
 #define MST(k) do{ if( prof ){ q1 = RKFD_CLOCK(); pc[k] += q1 - q0; q0 = q1; } }while(0)
@@ -1082,19 +1126,21 @@ template<bool prof> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const r
     const int j = L.lrg[lane], cinf = L.CIp[j], ci = RKFD_CI_CI( cinf );
     const int la = RKFD_CI_A( cinf ), lb = RKFD_CI_B( cinf );
     const double x[3] = { L.CX[3*L.asl[j]], L.CX[3*L.asl[j]+1], L.CX[3*L.asl[j]+2] };
-    double aa[3], ab[3], va[3], vb[3], ra[3], rv[3], d[3];
-    d_point_acc( &L.AC[6*la], &L.V[6*la], x, aa );
-    d_point_acc( &L.AC[6*lb], &L.V[6*lb], x, ab );
-    d_point_vel( &L.V[6*la], x, va );
-    d_point_vel( &L.V[6*lb], x, vb );
+    double ta[3], tb[3], ra[3], d[3];
+    /* spatial-acceleration part of the point accelerations: a_O + alpha x p (the velocity-product
+     * part and the relative velocity come from rkfd_phase_bvel) */
+    d_cross( &L.AC[6*la], x, ta ); d_cross( &L.AC[6*lb], x, tb );
 #pragma unroll
-    for( int k=0; k<3; k++ ){ ra[k] = aa[k]-ab[k]; rv[k] = va[k]-vb[k]; d[k] = x[k]-L.RW[3*L.asl[j]+k]; }
+    for( int k=0; k<3; k++ ){
+      ra[k] = ( L.AC[6*la+3+k] + ta[k] ) - ( L.AC[6*lb+3+k] + tb[k] );
+      d[k] = x[k]-L.RW[3*L.asl[j]+k];
+    }
     const double mu = L.typ[j] == RKFD_SF ? m.ci_sf[ci] : m.ci_kf[ci];
     const double K = m.ci_k[ci];
 #pragma unroll
     for( int i=0; i<3; i++ ){
       const double *ax = &L.AX[9*L.asl[j]+3*i];
-      double b = d_dot( ax, ra )*dt + d_dot( rv, ax );
+      double b = ( d_dot( ax, ra ) + bv[3+i] )*dt + bv[i];
       b += ( i == 0 ? K : K*mu )*d_dot( d, ax );
       L.MB[3*lane+i] = b;
     }
@@ -1275,12 +1321,12 @@ template<bool prof> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const r
       const double fi = L.MF[3*lane+i];
       fw[0] += fi*L.AX[9*L.asl[j]+3*i]; fw[1] += fi*L.AX[9*L.asl[j]+3*i+1]; fw[2] += fi*L.AX[9*L.asl[j]+3*i+2];
     }
-    L.CF[3*j] = fw[0]; L.CF[3*j+1] = fw[1]; L.CF[3*j+2] = fw[2];
+    { const int sl_ = L.asl[j]; L.CF[3*sl_] = fw[0]; L.CF[3*sl_+1] = fw[1]; L.CF[3*sl_+2] = fw[2]; }
     const double fn = fw[0], fs = sqrt( fw[1]*fw[1] + fw[2]*fw[2] );
     const double mu = L.typ[j] == RKFD_SF ? m.ci_sf[ci] : m.ci_kf[ci];
     if( fs > mu*fn - RKFD_DEV_TOL ){
       L.typ[j] = RKFD_KF;
-      L.REF[3*j] = L.PRO[3*L.asl[j]]; L.REF[3*j+1] = L.PRO[3*L.asl[j]+1]; L.REF[3*j+2] = L.PRO[3*L.asl[j]+2];
+      { const int ri = RIDX( j ), sl_ = L.asl[j]; L.REF[3*ri] = L.PRO[3*sl_]; L.REF[3*ri+1] = L.PRO[3*sl_+1]; L.REF[3*ri+2] = L.PRO[3*sl_+2]; }
     } else {
       L.typ[j] = RKFD_SF;
     }
@@ -1293,7 +1339,7 @@ template<bool prof> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const r
 /* one dynamics evaluation: _rkFDUpdate / _rkFDUpdateRef (reference src/rkfd_sim.c:533-549).
  * Input L.q, L.qd; output L.acc (and contact / pivot state).  Returns nonzero when the model
  * needs a rigid solver that is not available on the device (wave-uniform). */
-template<bool prof> RKFD_DEV int rkfd_evaluate(const rkfdDevModel &m, const rkfdLds &L, bool doUpRef, unsigned long long *pc)
+template<bool prof> RKFD_DEV int rkfd_evaluate(const rkfdDevModel &m, const rkfdLds &L, rkfdLaneLink &ll, bool doUpRef, unsigned long long *pc)
 {
   const int lane = LANE();
   int err = 0;
@@ -1301,13 +1347,13 @@ template<bool prof> RKFD_DEV int rkfd_evaluate(const rkfdDevModel &m, const rkfd
 #define STAMP(k) do{ if( prof ){ t1 = RKFD_CLOCK(); pc[k] += t1 - t0; t0 = t1; } }while(0)
   if( prof ) t0 = RKFD_CLOCK();
   if( lane < m.ndof ) L.acc[lane] = 0.0;
-  rkfd_phase_kinematics<prof>( m, L, pc );
+  rkfd_phase_kinematics<prof>( m, L, ll, pc );
   STAMP(0);
   /* commit joint friction pivots (the reference does so inside rkFDJointFrictionRevolDC) */
   if( doUpRef && lane < m.nlink ){
     const int jt = RKFD_LI_JT( L.LI[lane] );
     if( ( jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM ) && RKFD_LI_MT( L.LI[lane] ) == RKFD_MOTOR_DC )
-      L.pivt[lane] = (int)L.MS[4*lane+1];
+      ll.pivt = (int)L.MS[4*lane+1];
   }
   /* MS slot 0 carries (driving torque + friction) until sweep 2 overwrites it: keep a copy */
   double drv = 0;
@@ -1320,6 +1366,8 @@ template<bool prof> RKFD_DEV int rkfd_evaluate(const rkfdDevModel &m, const rkfd
     L.cnt[CNT_NRG] = 0; L.cnt[CNT_NEL] = 0;
   }
   SYNC();
+  double bv[6];
+  rkfd_phase_bvel( m, L, bv );
   STAMP(1);
   /* pass 0: rkChainUpdateABI (full sweeps; with rigid contacts this is rkFDUpdateAccBias);
    * pass 1 (only after the MLCP solve): rkChainUpdateCachedABI with the contact wrenches.
@@ -1332,7 +1380,7 @@ template<bool prof> RKFD_DEV int rkfd_evaluate(const rkfdDevModel &m, const rkfd
     STAMP(3);
     if( pass == 0 && L.cnt[CNT_NRG] > 0 ){
       if( m.solver == RKFD_SOLVER_MLCP ){
-        rkfd_phase_mlcp<prof>( m, L, pc );
+        rkfd_phase_mlcp<prof>( m, L, bv, pc );
         STAMP(4);
         npass = 2;
       } else {
@@ -1344,7 +1392,7 @@ template<bool prof> RKFD_DEV int rkfd_evaluate(const rkfdDevModel &m, const rkfd
   if( doUpRef && lane < m.nlink ){
     const int jt = RKFD_LI_JT( L.LI[lane] );
     if( jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM )
-      L.pivp[lane] = drv - L.MS[4*lane+3]*L.acc[RKFD_LI_OFF( L.LI[lane] )];
+      ll.pivp = drv - L.MS[4*lane+3]*L.acc[RKFD_LI_OFF( L.LI[lane] )];
   }
   SYNC();
   STAMP(5);
@@ -1355,11 +1403,11 @@ template<bool prof> RKFD_DEV int rkfd_evaluate(const rkfdDevModel &m, const rkfd
 /* rkFDODECatDefault (reference src/rkfd_sim.c:306-320): q = q0 (+) k v.  lane = dof.
  * q0 and v are per-lane registers; the rotational part of float joints is composed by the
  * lane of the first angular dof (dofkind 1) through LDS. */
-RKFD_DEV void rkfd_cat_dis(const rkfdDevModel &m, const rkfdLds &L, double q0, double k, double v)
+RKFD_DEV void rkfd_cat_dis(const rkfdDevModel &m, const rkfdLds &L, int dofkind, double q0, double k, double v)
 {
   const int lane = LANE();
   const bool on = lane < m.ndof;
-  const int kind = on ? L.dofkind[lane] : 0;
+  const int kind = on ? dofkind : 0;
   if( on ){
     L.q[lane] = q0 + k*v;
     L.tmp[lane] = v;
@@ -1387,38 +1435,49 @@ template<bool prof> RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkf
   const int lane = LANE();
   const int ND = m.ndof, NL = m.nlink, NC = m.ncand;
   rkfdLds L;
-  rkfd_lds_carve( &L, ldsbase, NL, ND, NC, 3*m.maxrg, m.nlevel, m.npool, m.nfloat, m.maxact, m.nside );
+  rkfd_lds_carve( &L, ldsbase, NL, ND, NC, 3*m.maxrg, m.nlevel, m.npool, m.nfloat, m.maxact, m.nside, m.pu_alias );
   if( lane == 0 ) L.cnt[CNT_OVF] = 0;
 
   /* load persistent state */
   double q = 0, qd = 0;
-  if( lane < ND ){ q = st.dis[(size_t)b*ND+lane]; qd = st.vel[(size_t)b*ND+lane]; L.dofkind[lane] = 0; }
+  int dofkind = 0;      /* 1: first angular coordinate of a float joint, 2: the other two */
+  if( lane < ND ){ q = st.dis[(size_t)b*ND+lane]; qd = st.vel[(size_t)b*ND+lane]; dofkind = m.dofkind[lane]; }
+  rkfdLaneLink ll; ll.min = 0; ll.pivp = 0; ll.pivt = 0;
   if( lane < NL ){
     L.LI[lane]   = m.linfo[lane];
     L.CHI[lane]  = m.child_idx[lane];
     L.PSL[lane]  = m.pslot[lane];
     const int lm = m.orig[lane];
-    L.min[lane]  = st.motor_in[(size_t)b*m.nlink_model+lm];
-    L.pivt[lane] = st.piv_type[(size_t)b*m.nlink_model+lm];
-    L.pivp[lane] = st.piv_prev[(size_t)b*m.nlink_model+lm];
+    ll.min  = st.motor_in[(size_t)b*m.nlink_model+lm];
+    ll.pivt = st.piv_type[(size_t)b*m.nlink_model+lm];
+    ll.pivp = st.piv_prev[(size_t)b*m.nlink_model+lm];
   }
   if( m.maxrg > 0 ){
     for( int k=lane; k<NL*m.nlevel; k+=RKFD_WAVE ) L.PL[k] = (unsigned char)m.pathlink[k];
   }
-  for( int j=lane; j<NC; j+=RKFD_WAVE ){
-    L.CIp[j] = m.cinfo[j];
-    L.CFO[j] = m.cand_foff[j];
-    L.act[j] = st.cv_active[(size_t)b*NC+j];
-    L.typ[j] = st.cv_type[(size_t)b*NC+j];
+  for( int c0=0; c0<NC; c0+=RKFD_WAVE ){
+    const int j = c0 + lane;
+    const bool onj = j < NC;
+    int a = 0;
+    if( onj ){
+      L.CIp[j] = m.cinfo[j];
+      L.CFO[j] = m.cand_foff[j];
+      a = st.cv_active[(size_t)b*NC+j];
+      L.typ[j] = st.cv_type[(size_t)b*NC+j];
+    }
+    /* slots of the contacts alive at launch (candidate order; re-assigned by every collision pass) */
+    const unsigned long long ma = BALLOT( a != 0 );
+    int sl = __builtin_popcountll( ma & ( lane == 0 ? 0ull : ( ~0ull >> ( 64-lane ) ) ) );
+    if( m.ref_by_slot && a && sl >= m.maxact ) a = 0;
+    if( onj ){
+      L.act[j] = a;
+      L.asl[j] = m.ref_by_slot ? sl : 0;
+      if( a ){
+        const int ri = m.ref_by_slot ? sl : j;
 #pragma unroll
-    for( int k=0; k<3; k++ ) L.REF[3*j+k] = st.cv_ref[((size_t)b*NC+j)*3+k];
-  }
-  SYNC();
-  if( lane < NL && RKFD_LI_JT( L.LI[lane] ) == RKFD_JOINT_FLOAT ){
-    const int o_ = RKFD_LI_OFF( L.LI[lane] );
-    L.dofkind[o_+3] = 1;
-    L.dofkind[o_+4] = 2;
-    L.dofkind[o_+5] = 2;
+        for( int k=0; k<3; k++ ) L.REF[3*ri+k] = st.cv_ref[((size_t)b*NC+j)*3+k];
+      }
+    }
   }
   SYNC();
   int err = 0;
@@ -1456,13 +1515,13 @@ template<bool prof> RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkf
         if( on ) L.q[lane] = q;
         SYNC();
       } else {
-        rkfd_cat_dis( m, L, q, k, tv );
+        rkfd_cat_dis( m, L, dofkind, q, k, tv );
       }
       if( on ) L.qd[lane] = xv;
       if( stage == 4 ){ q = on ? L.q[lane] : 0.0; qd = xv; }
       SYNC();
       const bool doUp = mode == 0 ? stage == 4 : mode == 1;
-      err |= rkfd_evaluate<prof>( m, L, doUp, pc );
+      err |= rkfd_evaluate<prof>( m, L, ll, doUp, pc );
       const double a = on ? L.acc[lane] : 0.0;
       if( stage == 0 ){ kv1 = xv; ka1 = a; }
       else if( stage == 1 ){ kv2 = xv; ka2 = a; }
@@ -1484,16 +1543,16 @@ template<bool prof> RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkf
   }
   if( lane < NL ){
     const int lm = m.orig[lane];
-    st.piv_type[(size_t)b*m.nlink_model+lm] = L.pivt[lane];
-    st.piv_prev[(size_t)b*m.nlink_model+lm] = L.pivp[lane];
+    st.piv_type[(size_t)b*m.nlink_model+lm] = ll.pivt;
+    st.piv_prev[(size_t)b*m.nlink_model+lm] = ll.pivp;
   }
   for( int j=lane; j<NC; j+=RKFD_WAVE ){
     st.cv_active[(size_t)b*NC+j] = L.act[j];
     st.cv_type[(size_t)b*NC+j] = L.typ[j];
 #pragma unroll
     for( int k=0; k<3; k++ ){
-      st.cv_ref[((size_t)b*NC+j)*3+k] = L.REF[3*j+k];
-      st.cv_f[((size_t)b*NC+j)*3+k] = L.CF[3*j+k];
+      if( L.act[j] ) st.cv_ref[((size_t)b*NC+j)*3+k] = L.REF[3*RIDX( j )+k];
+      st.cv_f[((size_t)b*NC+j)*3+k] = L.act[j] ? L.CF[3*L.asl[j]+k] : 0.0;
     }
   }
   if( st.dbg ){

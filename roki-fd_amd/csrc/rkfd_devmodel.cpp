@@ -292,7 +292,12 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   int nside = 1;
   for( int j=0; j<NC; j++ )
     if( m->ci_type[cci[j]] == RKFD_CONTACT_RIGID && !is_static[cA[j]] && !is_static[cB[j]] ) nside = 2;
-  dm.maxact = maxact; dm.nside = nside;
+  dm.maxact = maxact; dm.nside = nside; dm.ref_by_slot = NC <= RKFD_WAVE ? 1 : 0;
+  const size_t Mrows = 3*(size_t)max_rigid;
+  dm.pu_alias = ( (size_t)nside*nlevel*Mrows <= (size_t)12*NL ) ? 1 : 0;
+  std::vector<int> dofkind( ND ? ND : 1, 0 );
+  for( int i=0; i<NL; i++ )
+    if( R_jtype[i] == RKFD_JOINT_FLOAT ){ dofkind[R_dofoff[i]+3] = 1; dofkind[R_dofoff[i]+4] = 2; dofkind[R_dofoff[i]+5] = 2; }
   if( nround > RKFD_MAX_ROUND ) FAIL( "tree too deep" );
   /* record offsets first (the vector may reallocate), then resolve */
   struct Ent { const void **slot; size_t off; };
@@ -301,6 +306,7 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   PUT( parent, R_parent.data(), sizeof(int)*NL ); PUT( jtype, R_jtype.data(), sizeof(int)*NL );
   PUT( dofoff, R_dofoff.data(), sizeof(int)*NL ); PUT( mtype, R_mtype.data(), sizeof(int)*NL );
   PUT( orig, orig.data(), sizeof(int)*NL );
+  PUT( dofkind, dofkind.data(), sizeof(int)*( ND ? ND : 1 ) );
   PUT( depth, depth.data(), sizeof(int)*NL ); PUT( is_static, is_static.data(), sizeof(int)*NL );
   PUT( org, R_org.data(), sizeof(double)*12*NL ); PUT( mass, R_mass.data(), sizeof(double)*NL );
   PUT( com, R_com.data(), sizeof(double)*3*NL ); PUT( inertia, R_inertia.data(), sizeof(double)*9*NL );
@@ -336,10 +342,10 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
     const size_t M = 3*(size_t)max_rigid;
     size_t stage = (size_t)14*NL + (size_t)36*npool;            /* inertia staging + Ia pool ...   */
     if( M*(M+1) > stage ) stage = M*(M+1);                       /* ... shared with the MLCP matrix */
-    const size_t dbl = (size_t)4*ND + (size_t)NL*( 8*6 + 4 ) + stage + (size_t)48*nfloat
-                     + (size_t)maxact*18 + (size_t)NC*6 + 2*M + (size_t)nside*nlevel*M + 2*(size_t)NL;
-    const size_t ints = (size_t)5*NC + 8 + (size_t)ND + (size_t)NL      /* act typ lrg lel tgt, cnt, dofkind, pivt */
-                      + 3*(size_t)NL + 3*(size_t)NC + ( max_rigid > 0 ? ( (size_t)NL*nlevel + 3 )/4 : 0 ); /* LI, CHI, PSL, CIp, CFO, asl, PL (bytes) */
+    const size_t dbl = (size_t)3*ND + (size_t)NL*( 7*6 + 4 ) + stage + (size_t)48*nfloat
+                     + (size_t)maxact*21 + (size_t)( NC <= RKFD_WAVE ? maxact : NC )*3 + 2*M + ( dm.pu_alias ? 0 : (size_t)nside*nlevel*M );
+    const size_t ints = (size_t)5*NC + (size_t)4*maxact + 8 + 3*(size_t)NL     /* act typ asl CIp CFO, lrg lel tgt, cnt, LI CHI PSL */
+                      + ( max_rigid > 0 ? ( (size_t)NL*nlevel + 3 )/4 : 0 );   /* PL (bytes) */
     out->lds_bytes = dbl*sizeof(double) + ints*sizeof(int);
     out->lds_bytes = ( out->lds_bytes + 15 ) & ~(size_t)15;
   }
@@ -359,7 +365,7 @@ extern "C" void rkfd_devmodel_rebase(rkfdDevModel *dm, const void *from, const v
   RB(parent); RB(jtype); RB(dofoff); RB(mtype); RB(depth); RB(is_static);
   RB(org); RB(mass); RB(com); RB(inertia); RB(stiff); RB(visc); RB(coulomb); RB(sfric);
   RB(mot_k); RB(mot_admit); RB(mot_vmax); RB(mot_vmin); RB(mot_gear); RB(mot_inertia);
-  RB(anc); RB(level_off); RB(level_link); RB(child_off); RB(child_idx); RB(pathlink); RB(linfo); RB(sched); RB(cinfo); RB(pslot); RB(orig);
+  RB(anc); RB(level_off); RB(level_link); RB(child_off); RB(child_idx); RB(pathlink); RB(linfo); RB(sched); RB(cinfo); RB(pslot); RB(orig); RB(dofkind);
   RB(cand_linkA); RB(cand_linkB); RB(cand_foff); RB(cand_nf); RB(cand_ci); RB(cand_vert); RB(planes);
   RB(ci_type); RB(ci_sf); RB(ci_kf); RB(ci_k); RB(ci_l); RB(ci_e); RB(ci_v);
 #undef RB

@@ -21,11 +21,14 @@ typedef struct {
   int nci;
   int solver, max_iter;
   int maxact;            /* capacity: active contact vertices (rigid + elastic) per instance        */
+  int ref_by_slot;       /* 1: stick anchors are stored per active-contact slot (ncand <= 64)          */
+  int pu_alias;          /* 1: the probe scratch PU fits in (and aliases) the PA|AC region              */
   int nside;             /* 1 when every rigid-capable pair has a static cell (probe walks one-sided) else 2 */
   int maxrg;             /* capacity: rigid contact vertices solved per instance (3*maxrg <= 128) */
   double dt, fric_w;
   /* per link */
   const int *parent, *jtype, *dofoff, *mtype, *depth, *is_static;
+  const int *dofkind;    /* [ndof] 1: first angular coordinate of a float joint, 2: the other two, else 0 */
   const int *orig;       /* [nlink] model link of a device link                                       */
   const double *org, *mass, *com, *inertia;
   const double *stiff, *visc, *coulomb, *sfric;
