@@ -676,20 +676,20 @@ template<bool prof> RKFD_DEV void rkfd_phase_sweep2(const rkfdDevModel &m, const
   const int rr = r < 6 ? r : 0;
   const int T = m.nsched;
   rkfdRec rec1 = rkfd_rec_load( m, T-1, g ), rec2 = rkfd_rec_load( m, T-2, g );
-  rkfdPre2 pre1;
   int ro[6];
   rkfd_row_offsets( rr, ro );
-  rkfd_pre2_load( L, rec1.i >= 0 ? rec1.i : 0, rr, ro, full, pre1 );
   double crow[6] = {0,0,0,0,0,0}, cpa = 0;
   for( int t=T-1; t>=0; t-- ){
     unsigned long long q0 = 0, q1;
 #define QST(k) do{ if( prof ){ q1 = RKFD_CLOCK(); pc[k] += q1 - q0; q0 = q1; } }while(0)
     if( prof ) q0 = RKFD_CLOCK();
     const rkfdRec rec = rec1;
-    const rkfdPre2 pre = pre1;
     rec1 = rec2;
     rec2 = rkfd_rec_load( m, t-2, g );
-    rkfd_pre2_load( L, rec1.i >= 0 ? rec1.i : 0, rr, ro, full, pre1 );
+    /* operands of this iteration (with two waves per SIMD the other wave covers the LDS latency;
+     * a second, prefetched operand set would cost ~60 VGPRs) */
+    rkfdPre2 pre;
+    rkfd_pre2_load( L, rec.i >= 0 ? rec.i : 0, rr, ro, full, pre );
     QST(8);
     const bool onl = rec.i >= 0;
     const bool on = onl && r < 6;
@@ -805,15 +805,13 @@ RKFD_DEV void rkfd_phase_sweep3(const rkfdDevModel &m, const rkfdLds &L)
   const int rr = r < 6 ? r : 0;
   const int T = m.nsched;
   rkfdRec rec1 = rkfd_rec_load( m, 0, g ), rec2 = rkfd_rec_load( m, 1, g );
-  rkfdPre3 pre1;
-  rkfd_pre3_load( L, rec1.i >= 0 ? rec1.i : 0, rr, pre1 );
   double ca = 0;
   for( int t=0; t<T; t++ ){
     const rkfdRec rec = rec1;
-    const rkfdPre3 pre = pre1;
     rec1 = rec2;
     rec2 = rkfd_rec_load( m, t+2, g );
-    rkfd_pre3_load( L, rec1.i >= 0 ? rec1.i : 0, rr, pre1 );
+    rkfdPre3 pre;
+    rkfd_pre3_load( L, rec.i >= 0 ? rec.i : 0, rr, pre );
     const bool onl = rec.i >= 0;
     const bool on = onl && r < 6;
     const int i = onl ? rec.i : 0;
