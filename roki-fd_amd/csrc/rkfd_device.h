@@ -125,6 +125,17 @@ RKFD_DEV double rkfd_rcp(double x)
 
 #define RKFD_DEV_TOL RKFD_TOL
 
+/* RELOAD(p): makes the compiler forget what it knows about pointer p.  The per-lane model constants
+ * (link frames, inertias, motor data ...) are the same in every evaluation, so LLVM hoists their
+ * loads out of the step loop and then has to SPILL ~35 doubles per lane to scratch - HBM write
+ * traffic an order of magnitude above the algorithmic bytes.  Re-reading them from L2 is cheaper. */
+#ifdef RKFD_EMU
+#  define RELOAD(p) (p)
+#else
+template<class T> RKFD_DEV const T *rkfd_reload(const T *p){ asm volatile( "" : "+s"(p) ); return p; }
+#  define RELOAD(p) rkfd_reload(p)
+#endif
+
 /* optional in-kernel phase timing (diagnostic launches only: rkfdBatchProfile) */
 #define RKFD_NPROF 24
 #ifdef RKFD_EMU
@@ -353,12 +364,15 @@ template<bool prof> RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, c
   const int off = RKFD_LI_OFF( li );
   double R[9], p[3], Rj[9], vJ[6], qd1 = 0, qdf[6] = {0,0,0,0,0,0};
   int anc[RKFD_MAX_ROUND];
+  {
+    const int *ancp = RELOAD( m.anc );
 #pragma unroll
-  for( int r=0; r<RKFD_MAX_ROUND; r++ ) anc[r] = ( on && r < m.nround ) ? m.anc[r*NL+i] : -1;
+    for( int r=0; r<RKFD_MAX_ROUND; r++ ) anc[r] = ( on && r < m.nround ) ? ancp[r*NL+i] : -1;
+  }
 
   /* local (adjacent) transform = org frame * joint transform */
   {
-    const double *Ro = &m.org[12*i];
+    const double *Ro = &RELOAD( m.org )[12*i];
     double o[12];
 #pragma unroll
     for( int k=0; k<12; k++ ) o[k] = Ro[k];
@@ -480,10 +494,10 @@ template<bool prof> RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, c
       c[3] += t[0]; c[4] += t[1]; c[5] += t[2];
     }
     /* spatial inertia about the world origin and bias force */
-    const double ms = m.mass[i];
+    const double ms = RELOAD( m.mass )[i];
     double cw[3], Iw[9], t9[9], Ic[9], RT[9] = { R[0],R[3],R[6], R[1],R[4],R[7], R[2],R[5],R[8] };
     {
-      const double *cm = &m.com[3*i], *I0 = &m.inertia[9*i];
+      const double *cm = &RELOAD( m.com )[3*i], *I0 = &RELOAD( m.inertia )[9*i];
       double cl[3] = { cm[0], cm[1], cm[2] };
 #pragma unroll
       for( int k=0; k<9; k++ ) Ic[k] = I0[k];
@@ -538,17 +552,18 @@ template<bool prof> RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, c
         double tin = 0, treg = 0, tf = 0;
         const double in = ll.min;
         if( mt == RKFD_MOTOR_DC ){
-          const double gk = m.mot_gear[i]*m.mot_k[i];
-          jm = m.mot_inertia[i]*m.mot_gear[i]*m.mot_gear[i];
-          tin = m.mot_admit[i]*gk*d_clamp( in, m.mot_vmin[i], m.mot_vmax[i] );
-          treg = m.mot_admit[i]*gk*gk*qd1;
+          const double gear = RELOAD( m.mot_gear )[i], admit = RELOAD( m.mot_admit )[i];
+          const double gk = gear*RELOAD( m.mot_k )[i];
+          jm = RELOAD( m.mot_inertia )[i]*gear*gear;
+          tin = admit*gk*d_clamp( in, RELOAD( m.mot_vmin )[i], RELOAD( m.mot_vmax )[i] );
+          treg = admit*gk*gk*qd1;
           tf = jm*( -qd1/m.dt ) - tin + treg + ll.pivp;
           double fmax;
-          if( ll.pivt == RKFD_SF ) fmax = m.sfric[i];
+          if( ll.pivt == RKFD_SF ) fmax = RELOAD( m.sfric )[i];
           else {
             const double q = L.q[off];
             const double sg = qd1 > 0 ? 1.0 : ( qd1 < 0 ? -1.0 : 0.0 );
-            fmax = -m.stiff[i]*q - m.visc[i]*qd1 - m.coulomb[i]*sg;
+            fmax = -RELOAD( m.stiff )[i]*q - RELOAD( m.visc )[i]*qd1 - RELOAD( m.coulomb )[i]*sg;
           }
           fmax = fabs( fmax );
           int newt;
@@ -557,7 +572,7 @@ template<bool prof> RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, c
           /* the pivot type is committed by the caller when doUpRef (stored in MS slot 1 as a flag) */
           L.MS[4*i+1] = (double)newt;
         } else if( mt == RKFD_MOTOR_TRQ ){
-          tin = d_clamp( in, m.mot_vmin[i], m.mot_vmax[i] );
+          tin = d_clamp( in, RELOAD( m.mot_vmin )[i], RELOAD( m.mot_vmax )[i] );
         }
         tau = tin - treg + tf;
         /* driving torque without the inertia term + friction, for rkFDUpdateJointPrevDrivingTrq */
@@ -902,7 +917,7 @@ RKFD_DEV void rkfd_phase_collision(const rkfdDevModel &m, const rkfdLds &L)
 #pragma unroll
       for( int k=0; k<9; k++ ){ RA[k] = L.X[12*la+k]; RB[k] = L.X[12*lb+k]; }
 #pragma unroll
-      for( int k=0; k<3; k++ ){ pA[k] = L.X[12*la+9+k]; pB[k] = L.X[12*lb+9+k]; vl[k] = m.cand_vert[3*j+k]; }
+      for( int k=0; k<3; k++ ){ pA[k] = L.X[12*la+9+k]; pB[k] = L.X[12*lb+9+k]; vl[k] = RELOAD( m.cand_vert )[3*j+k]; }
       d_mulv( RA, vl, x );
       x[0] += pA[0]; x[1] += pA[1]; x[2] += pA[2];
       rr[0] = x[0]-pB[0]; rr[1] = x[1]-pB[1]; rr[2] = x[2]-pB[2];
@@ -1489,31 +1504,28 @@ template<bool prof> RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkf
      * evaluation at the new state (reference src/rkfd_sim.c:560-566).  All five evaluations
      * run through ONE copy of rkfd_evaluate (stage loop) to keep the kernel inside the
      * instruction cache.  mode 1 / 2: a single evaluation at the current state. */
-    const double h = m.dt;
     /* Gill coefficients: (sqrt2-1)/2, (2-sqrt2)/2, -sqrt2/2, 1+sqrt2/2, 2-sqrt2, 2+sqrt2 */
     const double c21 = 0.20710678118654752440, c22 = 0.29289321881345247560, c31 = -0.70710678118654752440;
     const double c32 = 1.70710678118654752440, w2 = 0.58578643762690495120, w3 = 3.41421356237309504880;
     const bool on = lane < ND;
     const int nst = mode == 0 ? 5 : 1;
     const int ntot = mode == 0 ? nsteps*5 : 1;
-    double kv1 = 0, kv2 = 0, kv3 = 0, ka1 = 0, ka2 = 0, ka3 = 0, ka4 = 0, kv4 = 0;
+    /* running sums instead of the four stage derivatives: F = weighted sum for the final update,
+     * T = tangent of the next stage state, P = the part of the tangent after next known so far */
+    double Fv = 0, Fa = 0, Tv = 0, Ta = 0, Pv = 0, Pa = 0;
     int stage = 0;
     for( int it=0; it<ntot; it++ ){
-      double k = 0, tv = 0, xv = qd;
-      if( mode == 0 ){
-        if( stage == 1 ){ k = 0.5*h; tv = kv1; xv = qd + 0.5*h*ka1; }
-        else if( stage == 2 ){ k = h; tv = c21*kv1 + c22*kv2; xv = qd + h*( c21*ka1 + c22*ka2 ); }
-        else if( stage == 3 ){ k = h; tv = c31*kv2 + c32*kv3; xv = qd + h*( c31*ka2 + c32*ka3 ); }
-        else if( stage == 4 ){
-          k = h/6.0; tv = kv1 + w2*kv2 + w3*kv3 + kv4;
-          xv = qd + h/6.0*( ka1 + w2*ka2 + w3*ka3 + ka4 );
-        }
-      }
+      double h = m.dt;
+#ifndef RKFD_EMU
+      asm volatile( "" : "+s"(h) );   /* keep h*coefficient products out of long-lived registers */
+#endif
+      const double k = stage == 1 ? 0.5*h : ( stage == 4 ? h/6.0 : h );
+      const double xv = ( mode == 0 && stage > 0 ) ? fma( k, Ta, qd ) : qd;
       if( stage == 0 ){
         if( on ) L.q[lane] = q;
         SYNC();
       } else {
-        rkfd_cat_dis( m, L, dofkind, q, k, tv );
+        rkfd_cat_dis( m, L, dofkind, q, k, Tv );
       }
       if( on ) L.qd[lane] = xv;
       if( stage == 4 ){ q = on ? L.q[lane] : 0.0; qd = xv; }
@@ -1521,10 +1533,10 @@ template<bool prof> RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkf
       const bool doUp = mode == 0 ? stage == 4 : mode == 1;
       err |= rkfd_evaluate<prof>( m, L, ll, doUp, pc );
       const double a = on ? L.acc[lane] : 0.0;
-      if( stage == 0 ){ kv1 = xv; ka1 = a; }
-      else if( stage == 1 ){ kv2 = xv; ka2 = a; }
-      else if( stage == 2 ){ kv3 = xv; ka3 = a; }
-      else if( stage == 3 ){ kv4 = xv; ka4 = a; }
+      if( stage == 0 ){ Fv = xv; Fa = a; Tv = xv; Ta = a; Pv = c21*xv; Pa = c21*a; }
+      else if( stage == 1 ){ Fv = fma( w2, xv, Fv ); Fa = fma( w2, a, Fa ); Tv = fma( c22, xv, Pv ); Ta = fma( c22, a, Pa ); Pv = c31*xv; Pa = c31*a; }
+      else if( stage == 2 ){ Fv = fma( w3, xv, Fv ); Fa = fma( w3, a, Fa ); Tv = fma( c32, xv, Pv ); Ta = fma( c32, a, Pa ); }
+      else if( stage == 3 ){ Fv += xv; Fa += a; Tv = Fv; Ta = Fa; }
       SYNC();
       stage++; if( stage == nst ) stage = 0;
     }
