@@ -178,16 +178,36 @@ RKFD_DEV void d_mul33(const double *a, const double *b, double *c)
  * Payne-Hanek slow path (v_trig_preop) that costs registers and code for arguments a robot never
  * has; these use a two-term Cody-Waite reduction by pi/2 and the classic fdlibm kernel
  * polynomials (|error| < 1 ulp for |x| < 1e5), and an fdlibm-style atan. */
+/* the polynomial coefficients live in constant memory and are fetched with scalar loads when a
+ * function runs: as 64-bit literals the compiler materialises them in VGPR pairs, hoists them out
+ * of the step loop and then spills them to scratch */
+#ifdef RKFD_EMU
+static const double rkfd_kc[] = {
+#else
+__constant__ double rkfd_kc[] = {
+#endif
+  /*  0 */ 6.36619772367581382433e-01, 1.57079632673412561417e+00, 6.07710050650619224932e-11,
+  /*  3 sin */ -1.66666666666666324348e-01, 8.33333333332248946124e-03, -1.98412698298579493134e-04,
+               2.75573137070700676789e-06, -2.50507602534068634195e-08, 1.58969099521155010221e-10,
+  /*  9 cos */ 4.16666666666666019037e-02, -1.38888888888741095749e-03, 2.48015872894767294178e-05,
+               -2.75573143513906633035e-07, 2.08757232129817482790e-09, -1.13596475577881948265e-11,
+  /* 15 atan hi/lo */ 4.63647609000806093515e-01, 2.26987774529616870924e-17, 7.85398163397448278999e-01, 3.06161699786838301793e-17,
+               9.82793723247329054082e-01, 1.39033110312309984516e-17, 1.57079632679489655800e+00, 6.12323399573676603587e-17,
+  /* 23 atan odd */ 3.33333333333329318027e-01, 1.42857142725034663711e-01, 9.09088713343650656196e-02,
+               6.66107313738753120669e-02, 4.97687799461593236017e-02, 1.62858201153657823623e-02,
+  /* 29 atan even */ -1.99999999998764832476e-01, -1.11111104054623557880e-01, -7.69187620504482999495e-02,
+               -5.83357013379057348645e-02, -3.65315727442169155270e-02,
+  /* 34 */ 3.14159265358979311600e+00
+};
 RKFD_DEV void d_sincos(double x, double *sn, double *cs)
 {
-  const double k = rint( x*6.36619772367581382433e-01 );
-  double r = fma( -k, 1.57079632673412561417e+00, x );
-  r = fma( -k, 6.07710050650619224932e-11, r );
+  const double *K = RELOAD( (const double *)rkfd_kc );
+  const double k = rint( x*K[0] );
+  double r = fma( -k, K[1], x );
+  r = fma( -k, K[2], r );
   const double z = r*r;
-  const double ps = -1.66666666666666324348e-01 + z*( 8.33333333332248946124e-03 + z*( -1.98412698298579493134e-04
-                  + z*( 2.75573137070700676789e-06 + z*( -2.50507602534068634195e-08 + z*1.58969099521155010221e-10 ) ) ) );
-  const double pc = 4.16666666666666019037e-02 + z*( -1.38888888888741095749e-03 + z*( 2.48015872894767294178e-05
-                  + z*( -2.75573143513906633035e-07 + z*( 2.08757232129817482790e-09 + z*( -1.13596475577881948265e-11 ) ) ) ) );
+  const double ps = K[3] + z*( K[4] + z*( K[5] + z*( K[6] + z*( K[7] + z*K[8] ) ) ) );
+  const double pc = K[9] + z*( K[10] + z*( K[11] + z*( K[12] + z*( K[13] + z*K[14] ) ) ) );
   const double s0 = fma( r*z, ps, r );
   const double c0 = fma( z*z, pc, fma( -0.5, z, 1.0 ) );
   const int q = (int)k & 3;
@@ -198,24 +218,24 @@ RKFD_DEV void d_sincos(double x, double *sn, double *cs)
 RKFD_DEV double d_atan_pos(double x)   /* x >= 0 */
 {
   /* fdlibm atan: reduce to |t| <= 7/16 around 0, 0.5, 1, 1.5, inf */
+  const double *K = RELOAD( (const double *)rkfd_kc );
   double hi, lo, t;
   if( x < 0.4375 ){ hi = 0; lo = 0; t = x; }
-  else if( x < 0.6875 ){ hi = 4.63647609000806093515e-01; lo = 2.26987774529616870924e-17; t = ( 2.0*x - 1.0 )/( 2.0 + x ); }
-  else if( x < 1.1875 ){ hi = 7.85398163397448278999e-01; lo = 3.06161699786838301793e-17; t = ( x - 1.0 )/( x + 1.0 ); }
-  else if( x < 2.4375 ){ hi = 9.82793723247329054082e-01; lo = 1.39033110312309984516e-17; t = ( x - 1.5 )/( 1.0 + 1.5*x ); }
-  else { hi = 1.57079632679489655800e+00; lo = 6.12323399573676603587e-17; t = -1.0/x; }
+  else if( x < 0.6875 ){ hi = K[15]; lo = K[16]; t = ( 2.0*x - 1.0 )/( 2.0 + x ); }
+  else if( x < 1.1875 ){ hi = K[17]; lo = K[18]; t = ( x - 1.0 )/( x + 1.0 ); }
+  else if( x < 2.4375 ){ hi = K[19]; lo = K[20]; t = ( x - 1.5 )/( 1.0 + 1.5*x ); }
+  else { hi = K[21]; lo = K[22]; t = -1.0/x; }
   const double z = t*t, w = z*z;
-  const double s1 = z*( 3.33333333333329318027e-01 + w*( 1.42857142725034663711e-01 + w*( 9.09088713343650656196e-02
-                  + w*( 6.66107313738753120669e-02 + w*( 4.97687799461593236017e-02 + w*1.62858201153657823623e-02 ) ) ) ) );
-  const double s2 = w*( -1.99999999998764832476e-01 + w*( -1.11111104054623557880e-01 + w*( -7.69187620504482999495e-02
-                  + w*( -5.83357013379057348645e-02 + w*( -3.65315727442169155270e-02 ) ) ) ) );
+  const double s1 = z*( K[23] + w*( K[24] + w*( K[25] + w*( K[26] + w*( K[27] + w*K[28] ) ) ) ) );
+  const double s2 = w*( K[29] + w*( K[30] + w*( K[31] + w*( K[32] + w*K[33] ) ) ) );
   return hi - ( ( t*( s1 + s2 ) - lo ) - t );
 }
 RKFD_DEV double d_atan2_ypos(double y, double x)   /* y >= 0 */
 {
+  const double *K = RELOAD( (const double *)rkfd_kc );
   if( x > 0 ) return d_atan_pos( y/x );
-  if( x < 0 ) return 3.14159265358979311600e+00 - d_atan_pos( y/( -x ) );
-  return y > 0 ? 1.57079632679489655800e+00 : 0.0;
+  if( x < 0 ) return K[34] - d_atan_pos( y/( -x ) );
+  return y > 0 ? K[21] : 0.0;
 }
 
 RKFD_DEV void d_from_aa(const double *aa, double *m)
