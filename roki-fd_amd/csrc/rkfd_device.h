@@ -1015,15 +1015,23 @@ RKFD_DEV void rkfd_phase_collision(const rkfdDevModel &m, const rkfdLds &L)
 RKFD_DEV void rkfd_push_wrenches(const rkfdDevModel &m, const rkfdLds &L, const int *list, int n)
 {
   const int lane = LANE();
-  if( lane < 6 ){
+  if( lane < 6 && n > 0 ){
     /* consecutive contacts usually act on the same two links (vertices of one shape pair): keep
-     * the running sums in registers and touch LDS only when the link changes */
+     * the running sums in registers and touch LDS only when the link changes.  The next contact's
+     * operands are fetched while the current one is summed. */
     int la = -1, lb = -1;
     double sa = 0, sb = 0;
+    int jn = list[0], sln = L.asl[jn], cinfn = L.CIp[jn];
+    double fn0 = L.CF[3*sln], fn1 = L.CF[3*sln+1], fn2 = L.CF[3*sln+2];
+    double xn0 = L.CX[3*sln], xn1 = L.CX[3*sln+1], xn2 = L.CX[3*sln+2];
     for( int e=0; e<n; e++ ){
-      const int j = list[e], sl = L.asl[j], cinf = L.CIp[j];
-      const double f[3] = { L.CF[3*sl], L.CF[3*sl+1], L.CF[3*sl+2] };
-      const double x[3] = { L.CX[3*sl], L.CX[3*sl+1], L.CX[3*sl+2] };
+      const int cinf = cinfn;
+      const double f[3] = { fn0, fn1, fn2 }, x[3] = { xn0, xn1, xn2 };
+      if( e+1 < n ){
+        jn = list[e+1]; sln = L.asl[jn]; cinfn = L.CIp[jn];
+        fn0 = L.CF[3*sln]; fn1 = L.CF[3*sln+1]; fn2 = L.CF[3*sln+2];
+        xn0 = L.CX[3*sln]; xn1 = L.CX[3*sln+1]; xn2 = L.CX[3*sln+2];
+      }
       double w;
       if( lane < 3 ){
         double t[3]; d_cross( x, f, t );
@@ -1209,9 +1217,10 @@ template<bool prof> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const r
         const double sg = s == 0 ? -1.0 : 1.0;
 #pragma unroll
         for( int k=0; k<6; k++ ) dp[k] = sg*W[k];
+        int lii = L.LI[i];
         for(;;){
-          const int lii = L.LI[i];
           const int jt = RKFD_LI_JT( lii ), par = RKFD_LI_PAR( lii );
+          const int lin = L.LI[par >= 0 ? par : 0];     /* the parent's record, fetched under this link's arithmetic */
           if( jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM ){
             double du = 0;
 #pragma unroll
@@ -1233,7 +1242,7 @@ template<bool prof> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const r
             break;
           }
           if( par < 0 ){ rootl[s] = i; break; }  /* fixed / 1-DoF root: world does not move */
-          i = par;
+          i = par; lii = lin;
         }
       }
     }
@@ -1253,9 +1262,11 @@ template<bool prof> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const r
         else if( rootl[1] >= 0 && L.PL[lk[1]*NLV] == rt ) side = 1;
         if( side < 0 ) continue;
         const int src = lk[side], dsrc = RKFD_LI_DEPTH( L.LI[src] );
+        int i = L.PL[T*NLV], lii = L.LI[i];
         for( int d=0; d<=dT; d++ ){
-          const int i = L.PL[T*NLV+d];
-          const int jt = RKFD_LI_JT( L.LI[i] );
+          const int in_ = L.PL[T*NLV + ( d < dT ? d+1 : d )];
+          const int lin = L.LI[in_];                     /* next level, fetched under this level's arithmetic */
+          const int jt = RKFD_LI_JT( lii );
           if( jt == RKFD_JOINT_FLOAT ){
 #pragma unroll
             for( int k=0; k<6; k++ ) da[k] = droot[side][k];
@@ -1269,6 +1280,7 @@ template<bool prof> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const r
 #pragma unroll
             for( int k=0; k<6; k++ ) da[k] += L.S[6*i+k]*qdd;
           }
+          i = in_; lii = lin;
         }
         /* entries for the contacts that touch T */
         for( int r=0; r<nc; r++ ){
