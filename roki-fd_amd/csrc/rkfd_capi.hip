@@ -1,5 +1,6 @@
 /* rkfd_capi.hip - C ABI (include/rkfd_hip.h) over the gfx950 kernel in rkfd_device.h. */
 #include <hip/hip_runtime.h>
+#include <vector>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -172,8 +173,19 @@ extern "C" int rkfdBatchGetContact(rkfdBatch *b, int *active, int *type, double 
   if( !b ){ SETERR( "null batch" ); return -1; }
   HIPCHK( hipSetDevice( b->device ), -1 );
   const size_t n = (size_t)b->batch*b->ncand;
-  D2H( active, b->st.cv_active, sizeof(int)*n ); D2H( type, b->st.cv_type, sizeof(int)*n );
+  std::vector<int> act( n );
+  HIPCHK( hipMemcpy( act.data(), b->st.cv_active, sizeof(int)*n, hipMemcpyDeviceToHost ), -1 );
+  D2H( type, b->st.cv_type, sizeof(int)*n );
   D2H( ref, b->st.cv_ref, sizeof(double)*3*n ); D2H( f, b->st.cv_f, sizeof(double)*3*n );
+  /* a candidate out of contact has no state: the device keeps whatever it last held there
+   * (it is rewritten at the next first contact), the boundary reports zeros */
+  for( size_t i=0; i<n; i++ ){
+    if( active ) active[i] = act[i];
+    if( act[i] ) continue;
+    if( type ) type[i] = 0;
+    if( ref ) ref[3*i] = ref[3*i+1] = ref[3*i+2] = 0;
+    if( f ) f[3*i] = f[3*i+1] = f[3*i+2] = 0;
+  }
   return 0;
 }
 extern "C" int rkfdBatchSetContact(rkfdBatch *b, const int *active, const int *type, const double *ref)

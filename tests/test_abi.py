@@ -46,3 +46,19 @@ def test_no_cpu_fallback(R):
         assert "no HIP device" in str(e) or "HIP" in str(e)
         return
     raise AssertionError("rkfdBatchCreate must fail without a GPU")
+
+
+def test_lds_budget_and_limits_on_host(R):
+    """rkfdLdsBytesFor works without a GPU: the humanoid workloads fit 8 workgroups per CU
+    (<= 20 480 B of LDS per instance), oversize worlds are rejected with a message"""
+    import os
+    L = R.lib()
+    for cfg, cap in (("config2", 0), ("config3", 0), ("config4", 8)):
+        sc = R.scenarios.CONFIGS[cfg](batch=1)
+        n = L.rkfdLdsBytesFor(sc["world"].model, cap)
+        assert 0 < n <= 20480, (cfg, n)
+    w = R.World()
+    for _ in range(3):
+        w.reg_file(os.path.join(R.scenarios.MODELS, "chain30.ztk"))
+    assert L.rkfdLdsBytesFor(w.model, 0) < 0
+    assert b"exceeds" in L.rkfdHipLastError()

@@ -1,0 +1,133 @@
+"""GPU tier, edge cases of the boundary: fused multi-step launches, state round trips, motor
+inputs, evaluation-only entry point, capacity overflow, small / degenerate worlds."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-9
+
+
+def _rel(x, y):
+    return np.abs(x - y).max() / max(1.0, np.abs(y).max())
+
+
+def test_fused_steps_equal_single_steps(R):
+    """rkfdBatchUpdate(n) == n x rkfdBatchUpdate(1), bit for bit (state round-trips through HBM)"""
+    sc = R.scenarios.config4(batch=64)
+    out = []
+    for chunks in ([7], [1] * 7, [3, 4]):
+        b = R.Batch(sc["world"], 64, max_rigid=sc["max_rigid"])
+        b.set_state(sc["dis"], sc["vel"]); b.update_init()
+        for n in chunks:
+            b.update(n)
+        assert b.status() == 0
+        out.append(b.get_state() + b.get_contact())
+    for other in out[1:]:
+        for x, y in zip(out[0], other):
+            assert np.array_equal(x, y)
+
+
+def test_contact_and_pivot_state_round_trip(R, oracle_cls):
+    """persistent state (stick anchors, stick/slip types, friction pivots) can be read out and
+    put back: continuing from a restored batch equals continuing the original"""
+    sc = R.scenarios.config4(batch=16)
+    a = R.Batch(sc["world"], 16, max_rigid=sc["max_rigid"])
+    a.set_state(sc["dis"], sc["vel"]); a.update_init(); a.update(10)
+    dis, vel, _ = a.get_state(); act, typ, ref, _ = a.get_contact(); pt, pp = a.get_pivot()
+    b = R.Batch(sc["world"], 16, max_rigid=sc["max_rigid"])
+    b.set_state(dis, vel); b.set_contact(act, typ, ref); b.set_pivot(pt, pp)
+    a.update(5); b.update(5)
+    for x, y in zip(a.get_state(), b.get_state()):
+        assert np.array_equal(x, y)
+
+
+def test_motor_inputs_drive_the_joints(R, oracle_cls):
+    """DC-motor voltages per instance (rkJointMotorSetInput): GPU vs oracle with saturating and
+    non-saturating inputs, friction pivots flipping between stick and slip"""
+    B = 8
+    sc = R.scenarios.config3(batch=B)
+    m = sc["world"].model.contents
+    rng = np.random.default_rng(3)
+    inp = np.zeros((B, m.nlink))
+    jt = m.arr("jtype", m.nlink)
+    inp[:, jt == R.JOINT_REVOL] = rng.uniform(-30, 30, (B, int((jt == R.JOINT_REVOL).sum())))   # beyond +-24 V too
+    b = R.Batch(sc["world"], B, max_rigid=0)
+    b.set_state(sc["dis"], sc["vel"]); b.set_motor_input(inp)
+    b.update_init(); b.update(5)
+    assert b.status() == 0
+    dis, vel, acc = b.get_state(); pt, pp = b.get_pivot()
+    for i in range(B):
+        o = oracle_cls(sc["world"].model)
+        o.set_state(sc["dis"][i], sc["vel"][i]); o.set_motor_input(inp[i]); o.update_init()
+        for _ in range(5):
+            o.update()
+        od, ov, oa = o.get_state(); opt, opp = o.get_pivot()
+        assert _rel(dis[i], od) < RTOL and _rel(vel[i], ov) < RTOL and _rel(acc[i], oa) < RTOL
+        assert (pt[i][jt == R.JOINT_REVOL] == opt[jt == R.JOINT_REVOL]).all()
+        assert _rel(pp[i][jt == R.JOINT_REVOL], opp[jt == R.JOINT_REVOL]) < RTOL
+    assert np.abs(vel[:, 6:]).max() > 1e-3      # something actually moved
+
+
+def test_eval_entry_point(R, oracle_cls):
+    """rkfdBatchEval = one _rkFDUpdate / _rkFDUpdateRef at the current state: fills acc and the
+    contact forces, leaves dis / vel untouched; only the committing variant moves friction pivots"""
+    sc = R.scenarios.config4(batch=4)
+    b = R.Batch(sc["world"], 4, max_rigid=sc["max_rigid"])
+    b.set_state(sc["dis"], sc["vel"])
+    b.eval(False)
+    assert b.status() == 0
+    dis, vel, acc = b.get_state()
+    assert np.array_equal(dis, sc["dis"]) and np.array_equal(vel, sc["vel"])
+    for i in range(4):
+        o = oracle_cls(sc["world"].model)
+        o.set_state(sc["dis"][i], sc["vel"][i]); o.eval(False)
+        assert _rel(acc[i], o.get_state()[2]) < RTOL
+        assert _rel(b.get_contact()[3][i], o.get_contact()[3]) < RTOL
+
+
+def test_contact_capacity_overflow_is_reported(R):
+    sc = R.scenarios.config1_rigid(batch=2)
+    dis = sc["dis"].copy(); dis[:, 2] = 0.0499; dis[:, 3:] = 0      # box flat on the floor: 4 contacts
+    b = R.Batch(sc["world"], 2, max_rigid=2)
+    b.set_state(dis, sc["vel"]); b.update_init()
+    assert b.status() == 2
+    b2 = R.Batch(sc["world"], 2, max_rigid=4)
+    b2.set_state(dis, sc["vel"]); b2.update_init()
+    assert b2.status() == 0
+
+
+def test_vert_plugin_reports_rigid_contact(R):
+    """the Vert plugin's rigid QP branch has no device path: a rigid contact under Vert is an error
+    status, never a silent wrong answer"""
+    w = R.World(solver=R.SOLVER_VERT)
+    w.contact_info(os.path.join(R.scenarios.MODELS, "contactinfo.ztk"))
+    w.reg_file(os.path.join(R.scenarios.MODELS, "box.ztk")); w.reg_file(os.path.join(R.scenarios.MODELS, "floor.ztk"))
+    b = R.Batch(w, 1, max_rigid=4)
+    b.set_state(np.array([[0, 0, 0.0499, 0, 0, 0.0]]), np.zeros((1, 6))); b.update_init()
+    assert b.status() == 1
+
+
+def test_batch_of_one_and_world_without_contacts(R, oracle_cls):
+    sc = R.scenarios.config2(batch=1)
+    b = R.Batch(sc["world"], 1, max_rigid=0)
+    b.set_state(sc["dis"], sc["vel"]); b.update_init(); b.update(3)
+    o = oracle_cls(sc["world"].model); o.set_state(sc["dis"][0], sc["vel"][0]); o.update_init()
+    for _ in range(3):
+        o.update()
+    assert _rel(b.get_state()[0][0], o.get_state()[0]) < RTOL
+    act, typ, ref, f = b.get_contact()
+    assert act.shape == (1, 0)
+
+
+def test_limits_are_reported(R):
+    """a world beyond the per-wave limits fails at creation with a message"""
+    w = R.World(solver=R.SOLVER_VERT)
+    for _ in range(3):
+        w.reg_file(os.path.join(R.scenarios.MODELS, "chain30.ztk"))     # 90 joint coordinates > 64
+    with pytest.raises(R.RkfdError, match="exceeds"):
+        R.Batch(w, 1, max_rigid=0)
+    sc = R.scenarios.config4(batch=1)
+    with pytest.raises(R.RkfdError, match="exceeds"):
+        R.Batch(sc["world"], 1, max_rigid=50)
