@@ -69,8 +69,10 @@ int rkfdBatchEval(rkfdBatch *b, int doUpRef, void *stream);
  * 2 rigid-contact capacity exceeded; negative: HIP error */
 int rkfdBatchStatus(rkfdBatch *b, void *stream);
 
-/* diagnostic launch: nsteps x rkFDUpdate with in-kernel phase stamps.  out is [batch][8]
- * shader-clock cycles: kinematics, collision+penalty, sweep 2, sweep 3, MLCP, tail, -, whole launch.
+/* diagnostic launch: nsteps x rkFDUpdate with in-kernel phase stamps.  out is [batch][24]
+  * (RKFD_NPROF = 24 per instance) shader-clock cycles: kinematics, collision+penalty, sweep 2, sweep 3 (both
+ * passes), MLCP, tail, MLCP matrix, whole launch, then finer stamps inside sweep 2 (8-13), MLCP (14, 15, 21-23)
+ * and kinematics (16-20); tools/prof_phases.py names them.
  * Synchronous; not for timing runs (the stamps serialise the phases). */
 int rkfdBatchProfile(rkfdBatch *b, int nsteps, unsigned long long *out);
 

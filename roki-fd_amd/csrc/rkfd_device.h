@@ -327,7 +327,7 @@ typedef struct {
   unsigned char *PL;              /* [NL*nlevel] ancestor at depth d (MLCP only), one byte each */
 } rkfdLds;
 
-RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int M, int nlevel, int npool, int nfloat, int maxact, int nside, int pu_alias)
+RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int M, int nlevel, int npool, int nfloat, int maxact, int nside, int pu_alias, int npurow)
 /* must match the byte count computed in rkfd_devmodel.cpp */
 {
   double *d = (double *)base;
@@ -345,8 +345,8 @@ RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int
   L->CX = d; d += maxact*3; L->AX = d; d += maxact*9; L->RW = d; d += maxact*3; L->PRO = d; d += maxact*3;
   L->REF = d; d += ( NC <= RKFD_WAVE ? maxact : NC )*3; L->CF = d; d += maxact*3;
   L->MB = d; d += M; L->MF = d; d += M;
-  /* probe scratch: lives between the computation of b and the bias-only sweep, when PA|AC are dead */
-  if( pu_alias ) L->PU = L->PA; else { L->PU = d; d += nside*nlevel*M; }
+  /* probe scratch: lives while the contact problem is set up and solved, when V, C, PB, PA are dead */
+  if( pu_alias ) L->PU = L->V; else { L->PU = d; d += nside*npurow*M; }
   int *ip = (int *)d;
   L->act = ip; ip += NC; L->typ = ip; ip += NC; L->asl = ip; ip += NC; L->CIp = ip; ip += NC; L->CFO = ip; ip += NC;
   L->lrg = ip; ip += maxact; L->lel = ip; ip += maxact; L->tgt = ip; ip += 2*maxact; L->cnt = ip; ip += 8;
@@ -360,6 +360,15 @@ typedef struct { double min, pivp; int pivt; } rkfdLaneLink;
 /* the stick anchors REF live per active-contact slot when all candidates fit one sweep of the
  * wave (ncand <= 64), else per candidate */
 #define RIDX(j) ( m.ref_by_slot ? L.asl[j] : (j) )
+
+/* packed description of one moving side of a rigid contact (built per evaluation in L->tgt) */
+#define RKFD_CS_LINK(e)   ( (int)( (e) & 0xFF ) )
+#define RKFD_CS_DEPTH(e)  ( (int)( ( (e) >> 8 ) & 0x3F ) )
+#define RKFD_CS_TOP(e)    ( (int)( ( (e) >> 14 ) & 0xFF ) )
+#define RKFD_CS_D0(e)     ( (int)( ( (e) >> 22 ) & 0x7F ) )
+#define RKFD_CS_FLOAT(e)  ( (int)( ( (e) >> 29 ) & 1 ) )
+#define RKFD_CS_SIDE(e)   ( (int)( ( (e) >> 30 ) & 1 ) )
+#define RKFD_CS_VALID(e)  ( (int)( (e) >> 31 ) )
 
 /* counters in L->cnt */
 #define CNT_NRG 0
@@ -612,21 +621,35 @@ template<bool prof> RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, c
  * stores 1/L_jj so that the factorisation and the solves multiply instead of dividing. */
 RKFD_DEV void d_chol6_inplace(double *A)
 {
+  /* the lower triangle is pulled into registers in one batch of loads, factored there and written back */
+  double a[6][6];
+#pragma unroll
+  for( int i=0; i<6; i++ )
+#pragma unroll
+    for( int k=0; k<6; k++ ) if( k <= i ) a[i][k] = A[6*i+k];
+#pragma unroll
   for( int j=0; j<6; j++ ){
-    double s = A[6*j+j];
-    for( int k=0; k<j; k++ ) s -= A[6*j+k]*A[6*j+k];
+    double s = a[j][j];
+#pragma unroll
+    for( int k=0; k<6; k++ ) if( k < j ) s -= a[j][k]*a[j][k];
     const double inv = RKFD_RCP( sqrt( s ) );
-    A[6*j+j] = inv;
-    for( int i=j+1; i<6; i++ ){
-      double t = A[6*i+j];
-      for( int k=0; k<j; k++ ) t -= A[6*i+k]*A[6*j+k];
-      A[6*i+j] = t*inv;
+    a[j][j] = inv;
+#pragma unroll
+    for( int i=0; i<6; i++ ) if( i > j ){
+      double t = a[i][j];
+#pragma unroll
+      for( int k=0; k<6; k++ ) if( k < j ) t -= a[i][k]*a[j][k];
+      a[i][j] = t*inv;
     }
   }
+#pragma unroll
+  for( int i=0; i<6; i++ )
+#pragma unroll
+    for( int k=0; k<6; k++ ) if( k <= i ) A[6*i+k] = a[i][k];
 }
-RKFD_DEV void d_chol6_solve(const double *Lm, const double *b, double *x)
+/* forward substitution y = L^-1 b and back substitution x = L^-T y with that factor */
+RKFD_DEV void d_chol6_fwd(const double *Lm, const double *b, double *y)
 {
-  double y[6];
 #pragma unroll
   for( int i=0; i<6; i++ ){
     double s = b[i];
@@ -634,6 +657,9 @@ RKFD_DEV void d_chol6_solve(const double *Lm, const double *b, double *x)
     for( int k=0; k<6; k++ ) if( k < i ) s -= Lm[6*i+k]*y[k];
     y[i] = s*Lm[6*i+i];
   }
+}
+RKFD_DEV void d_chol6_back(const double *Lm, const double *y, double *x)
+{
 #pragma unroll
   for( int i=5; i>=0; i-- ){
     double s = y[i];
@@ -661,12 +687,12 @@ RKFD_DEV rkfdRec rkfd_rec_load(const rkfdDevModel &m, int t, int g)
   return r;
 }
 
-/* per-lane operands of one sweep-2 iteration, fetched from LDS one iteration ahead.
+/* per-lane operands of one sweep-2 iteration.
  * row = row rr of the link's own spatial inertia about the world origin,
  *   [ A   m [r]x ;  m [r]x'   m 1 ],   A = Iw + m( |r|^2 1 - r r' ):
  * every entry is one of the 14 staged doubles (A sym, +m r, -m r, m, 0), so a row is six loads at
  * lane-constant offsets ro[] (2.6x less LDS than staging the 6x6, no arithmetic). */
-typedef struct { double row[6], S[6], c[6], S_r, pb, tau, jm, U_r, Dinv, W_r; } rkfdPre2;
+typedef struct { double row[6], S[6], c[6], S_r, pb, tau, jm; } rkfdPre2;
 RKFD_DEV void rkfd_row_offsets(int rr, int *ro)
 {
   /* [r]x = [ 0 -z y ; z 0 -x ; -y x 0 ];  +m r at 6..8, -m r at 9..11, m at 12, 0 at 13 */
@@ -680,31 +706,23 @@ RKFD_DEV void rkfd_row_offsets(int rr, int *ro)
     ro[k] = v;
   }
 }
-RKFD_DEV void rkfd_pre2_load(const rkfdLds &L, int i, int rr, const int *ro, bool full, rkfdPre2 &p)
+RKFD_DEV void rkfd_pre2_load(const rkfdLds &L, int i, int rr, const int *ro, rkfdPre2 &p)
 {
 #pragma unroll
   for( int k=0; k<6; k++ ){ p.S[k] = L.S[6*i+k]; p.c[k] = L.C[6*i+k]; }
   p.S_r = L.S[6*i+rr];
   p.pb = L.PB[6*i+rr];
   p.tau = L.MS[4*i+2]; p.jm = L.MS[4*i+3];
-  if( full ){
 #pragma unroll
-    for( int k=0; k<6; k++ ) p.row[k] = L.IST[14*i+ro[k]];
-    p.U_r = 0.0; p.Dinv = 0.0; p.W_r = 0.0;
-  } else {
-#pragma unroll
-    for( int k=0; k<6; k++ ) p.row[k] = 0.0;
-    p.U_r = L.U[6*i+rr]; p.Dinv = L.MS[4*i+0]; p.W_r = L.W[6*i+rr];
-  }
+  for( int k=0; k<6; k++ ) p.row[k] = L.IST[14*i+ro[k]];
 }
 
-/* ABA sweep 2 (leaf to root), level-synchronous; 8 lanes per link, lane r = row r of the 6x6.
- * full = true : articulated inertia + bias (rkChainUpdateABI, backward part)
- * full = false: bias only, reusing Ia, U, Dinv (rkChainUpdateCachedABI, backward part).
- * Software-pipelined: schedule records are fetched two iterations ahead, the link's own LDS
- * operands one iteration ahead, and along chains the child's (Ia row, pa) stay in registers
- * (schedule flag bit 0), so the dependent path of an iteration is ALU + DPP + one swizzle. */
-template<bool prof> RKFD_DEV void rkfd_phase_sweep2(const rkfdDevModel &m, const rkfdLds &L, bool full, unsigned long long *pc)
+/* ABA sweep 2 (leaf to root), level-synchronous; 8 lanes per link, lane r = row r of the 6x6:
+ * articulated inertia and bias force (backward part of rkChainUpdateABI).
+ * Software-pipelined: schedule records are fetched two iterations ahead, and along chains the
+ * child's (Ia row, pa) stay in registers (schedule flag bit 0), so the dependent path of an
+ * iteration is one LDS round trip + ALU + DPP + one swizzle. */
+template<bool prof> RKFD_DEV void rkfd_phase_sweep2(const rkfdDevModel &m, const rkfdLds &L, unsigned long long *pc)
 {
   const int lane = LANE();
   const int g = lane >> 3, r = lane & 7;
@@ -724,7 +742,7 @@ template<bool prof> RKFD_DEV void rkfd_phase_sweep2(const rkfdDevModel &m, const
     /* operands of this iteration (with two waves per SIMD the other wave covers the LDS latency;
      * a second, prefetched operand set would cost ~60 VGPRs) */
     rkfdPre2 pre;
-    rkfd_pre2_load( L, rec.i >= 0 ? rec.i : 0, rr, ro, full, pre );
+    rkfd_pre2_load( L, rec.i >= 0 ? rec.i : 0, rr, ro, pre );
     QST(8);
     const bool onl = rec.i >= 0;
     const bool on = onl && r < 6;
@@ -738,16 +756,14 @@ template<bool prof> RKFD_DEV void rkfd_phase_sweep2(const rkfdDevModel &m, const
     LDS_FENCE();   /* the children's write-backs of the previous iteration precede the gathers below */
     if( REC_FLAGS( rec ) & 1 ){
       pr += cpa;
-      if( full ){
 #pragma unroll
-        for( int k=0; k<6; k++ ) row[k] += crow[k];
-      }
+      for( int k=0; k<6; k++ ) row[k] += crow[k];
     } else {
       for( int cc=0; cc<REC_NCHILD( rec ); cc++ ){
         const int ch = L.CHI[rec.coff+cc];
         pr += L.PA[6*ch+rr];
         const int ps = L.PSL[ch];
-        if( full && ps >= 0 ){
+        if( ps >= 0 ){
 #pragma unroll
           for( int k=0; k<6; k++ ) row[k] += L.POOL[36*ps+6*rr+k];
         }
@@ -755,22 +771,16 @@ template<bool prof> RKFD_DEV void rkfd_phase_sweep2(const rkfdDevModel &m, const
     }
     QST(9);
     const double S_r = pre.S_r;
-    double U_r, Dinv, u;
-    if( full ){
-      double u0 = row[0]*pre.S[0], u1 = row[1]*pre.S[1];
-      u0 = fma( row[2], pre.S[2], u0 ); u1 = fma( row[3], pre.S[3], u1 );
-      u0 = fma( row[4], pre.S[4], u0 ); u1 = fma( row[5], pre.S[5], u1 );
-      U_r = u0 + u1;
-      double dsum = ( on && is1 ) ? S_r*U_r : 0.0, usum = ( on && is1 ) ? S_r*pr : 0.0;
-      G8SUM2( dsum, usum );
-      Dinv = RKFD_RCP( dsum + pre.jm );
-      u = pre.tau - usum;
-    } else {
-      U_r = pre.U_r; Dinv = pre.Dinv;
-      u = pre.tau - G8SUM( ( on && is1 ) ? S_r*pr : 0.0 );
-    }
+    double u0 = row[0]*pre.S[0], u1 = row[1]*pre.S[1];
+    u0 = fma( row[2], pre.S[2], u0 ); u1 = fma( row[3], pre.S[3], u1 );
+    u0 = fma( row[4], pre.S[4], u0 ); u1 = fma( row[5], pre.S[5], u1 );
+    const double U_r = u0 + u1;
+    double dsum = ( on && is1 ) ? S_r*U_r : 0.0, usum = ( on && is1 ) ? S_r*pr : 0.0;
+    G8SUM2( dsum, usum );
+    const double Dinv = RKFD_RCP( dsum + pre.jm );
+    const double u = pre.tau - usum;
     QST(10);
-    if( full ){
+    {
       /* rank-1 downdate Ia = IA - U U'/D: every row needs every U[k] */
       const double tt = is1 ? U_r*Dinv : 0.0;
       const double b0 = G8BCAST( U_r, 0 ), b1 = G8BCAST( U_r, 1 ), b2 = G8BCAST( U_r, 2 );
@@ -778,44 +788,40 @@ template<bool prof> RKFD_DEV void rkfd_phase_sweep2(const rkfdDevModel &m, const
       row[0] = fma( -tt, b0, row[0] ); row[1] = fma( -tt, b1, row[1] ); row[2] = fma( -tt, b2, row[2] );
       row[3] = fma( -tt, b3, row[3] ); row[4] = fma( -tt, b4, row[4] ); row[5] = fma( -tt, b5, row[5] );
     }
-    double pa = pr, W_r = pre.W_r;
+    double pa = pr;
     if( is1 ){
-      if( full ){
-        double s0 = row[0]*pre.c[0], s1 = row[1]*pre.c[1];
-        s0 = fma( row[2], pre.c[2], s0 ); s1 = fma( row[3], pre.c[3], s1 );
-        s0 = fma( row[4], pre.c[4], s0 ); s1 = fma( row[5], pre.c[5], s1 );
-        W_r = s0 + s1;
-      }
-      pa = pr + W_r + U_r*( u*Dinv );
+      /* pa = pA + Ia c + U u / D */
+      double s0 = row[0]*pre.c[0], s1 = row[1]*pre.c[1];
+      s0 = fma( row[2], pre.c[2], s0 ); s1 = fma( row[3], pre.c[3], s1 );
+      s0 = fma( row[4], pre.c[4], s0 ); s1 = fma( row[5], pre.c[5], s1 );
+      pa = pr + ( s0 + s1 ) + U_r*( u*Dinv );
     } else if( isf ){
       pa = 0;
     }
     QST(11);
     /* write back (needed by later phases and by parents that gather from LDS) */
     if( on ){
-      if( full ){
-        /* Ia goes to LDS only where somebody will read it: a gathering parent (pool slot REC_POOL( rec ))
-         * or the Cholesky of a float joint (slot REC_FSLOT( rec )) */
-        if( REC_POOL( rec ) >= 0 ){
+      /* Ia goes to LDS only where somebody will read it: a gathering parent (pool slot REC_POOL( rec ))
+       * or the Cholesky of a float joint (slot REC_FSLOT( rec )) */
+      if( REC_POOL( rec ) >= 0 ){
 #pragma unroll
-          for( int k=0; k<6; k++ ) L.POOL[36*REC_POOL( rec )+6*rr+k] = row[k];
-        }
-        if( isf ){
-#pragma unroll
-          for( int k=0; k<6; k++ ) L.CHOL[36*REC_FSLOT( rec )+6*rr+k] = row[k];
-        }
-        if( is1 ){ L.U[6*i+rr] = U_r; L.W[6*i+rr] = W_r; }
+        for( int k=0; k<6; k++ ) L.POOL[36*REC_POOL( rec )+6*rr+k] = row[k];
       }
+      if( isf ){
+#pragma unroll
+        for( int k=0; k<6; k++ ) L.CHOL[36*REC_FSLOT( rec )+6*rr+k] = row[k];
+      }
+      if( is1 ) L.U[6*i+rr] = U_r;
       L.PA[6*i+rr] = pa;
       if( isf ) L.U[6*i+rr] = pr;   /* float: the U slot keeps the bias pA */
       if( rr == 0 && is1 ){
-        if( full ) L.MS[4*i+0] = Dinv;
+        L.MS[4*i+0] = Dinv;
         L.MS[4*i+1] = u;
       }
     }
     LDS_FENCE();
     QST(12);
-    if( full && isf && onl && r == 0 ) d_chol6_inplace( &L.CHOL[36*REC_FSLOT( rec )] );
+    if( isf && onl && r == 0 ) d_chol6_inplace( &L.CHOL[36*REC_FSLOT( rec )] );
     QST(13);
 #undef QST
 #pragma unroll
@@ -826,14 +832,20 @@ template<bool prof> RKFD_DEV void rkfd_phase_sweep2(const rkfdDevModel &m, const
 }
 
 /* ABA sweep 3 (root to leaf): accelerations and joint accelerations.  Same pipelining; along
- * chains the parent's acceleration stays in registers (schedule flag bit 1). */
+ * chains the parent's acceleration stays in registers (schedule flag bit 1).
+ * delta = false: the forward part of rkChainUpdateABI, acc = joint accelerations.
+ * delta = true : the response to the contact forces found by the MLCP solve, added onto acc -
+ *   the same recursion without the velocity-product terms, driven by the innovations the
+ *   forces cause (MS slot 1 = du/D of 1-DoF joints, U slot of a float joint = L^-1 of its bias
+ *   change).  By linearity of the dynamics in the external forces this equals re-running both
+ *   sweeps with the contact wrenches applied (rkChainUpdateCachedABI, reference src/rkfd_mlcp.c:292-296). */
 typedef struct { double c_r, U_r, S_r, u, Dinv; } rkfdPre3;
-RKFD_DEV void rkfd_pre3_load(const rkfdLds &L, int i, int rr, rkfdPre3 &p)
+template<bool delta> RKFD_DEV void rkfd_pre3_load(const rkfdLds &L, int i, int rr, rkfdPre3 &p)
 {
-  p.c_r = L.C[6*i+rr]; p.U_r = L.U[6*i+rr]; p.S_r = L.S[6*i+rr];
+  p.c_r = delta ? 0.0 : L.C[6*i+rr]; p.U_r = L.U[6*i+rr]; p.S_r = L.S[6*i+rr];
   p.Dinv = L.MS[4*i+0]; p.u = L.MS[4*i+1];
 }
-RKFD_DEV void rkfd_phase_sweep3(const rkfdDevModel &m, const rkfdLds &L)
+template<bool delta> RKFD_DEV void rkfd_phase_sweep3(const rkfdDevModel &m, const rkfdLds &L)
 {
   const int lane = LANE();
   const int g = lane >> 3, r = lane & 7;
@@ -846,7 +858,7 @@ RKFD_DEV void rkfd_phase_sweep3(const rkfdDevModel &m, const rkfdLds &L)
     rec1 = rec2;
     rec2 = rkfd_rec_load( m, t+2, g );
     rkfdPre3 pre;
-    rkfd_pre3_load( L, rec.i >= 0 ? rec.i : 0, rr, pre );
+    rkfd_pre3_load<delta>( L, rec.i >= 0 ? rec.i : 0, rr, pre );
     const bool onl = rec.i >= 0;
     const bool on = onl && r < 6;
     const int i = onl ? rec.i : 0;
@@ -862,20 +874,30 @@ RKFD_DEV void rkfd_phase_sweep3(const rkfdDevModel &m, const rkfdLds &L)
     const double uy = G8SUM( ( on && is1 ) ? pre.U_r*y : 0.0 );
     double a = y;
     if( is1 ){
-      const double qdd = ( pre.u - uy )*pre.Dinv;
+      const double qdd = delta ? fma( -uy, pre.Dinv, pre.u ) : ( pre.u - uy )*pre.Dinv;
       a = fma( pre.S_r, qdd, y );
-      if( on && rr == 0 ) L.acc[off] = qdd;
+      if( on && rr == 0 ){
+        if( delta ) L.acc[off] += qdd; else L.acc[off] = qdd;
+      }
     } else if( jt == RKFD_JOINT_FLOAT ){
       if( onl && r == 0 ){
         /* a = IA^-1 ( -pA ); joint acceleration from a - a_parent - c */
         double rhs[6], x[6], d[6], Row[9], p[3];
+        if( delta ){
 #pragma unroll
-        for( int k=0; k<6; k++ ) rhs[k] = -L.U[6*i+k];
-        d_chol6_solve( &L.CHOL[36*REC_FSLOT( rec )], rhs, x );
+          for( int k=0; k<6; k++ ) rhs[k] = L.U[6*i+k];
+          d_chol6_back( &L.CHOL[36*REC_FSLOT( rec )], rhs, x );
+        } else {
+          double yv[6];
+#pragma unroll
+          for( int k=0; k<6; k++ ) rhs[k] = -L.U[6*i+k];
+          d_chol6_fwd( &L.CHOL[36*REC_FSLOT( rec )], rhs, yv );
+          d_chol6_back( &L.CHOL[36*REC_FSLOT( rec )], yv, x );
+        }
 #pragma unroll
         for( int k=0; k<6; k++ ){
           L.AC[6*i+k] = x[k];
-          d[k] = x[k] - ( par >= 0 ? L.AC[6*par+k] : 0.0 ) - L.C[6*i+k];
+          d[k] = x[k] - ( par >= 0 ? L.AC[6*par+k] : 0.0 ) - ( delta ? 0.0 : L.C[6*i+k] );
         }
 #pragma unroll
         for( int k=0; k<9; k++ ) Row[k] = L.XF[12*REC_FSLOT( rec )+k];
@@ -885,8 +907,13 @@ RKFD_DEV void rkfd_phase_sweep3(const rkfdDevModel &m, const rkfdLds &L)
         d_cross( p, d, t3 );
         lin[0] = d[3]-t3[0]; lin[1] = d[4]-t3[1]; lin[2] = d[5]-t3[2];
         d_tmulv( Row, lin, o1 ); d_tmulv( Row, d, o2 );
-        L.acc[off] = o1[0]; L.acc[off+1] = o1[1]; L.acc[off+2] = o1[2];
-        L.acc[off+3] = o2[0]; L.acc[off+4] = o2[1]; L.acc[off+5] = o2[2];
+        if( delta ){
+          L.acc[off] += o1[0]; L.acc[off+1] += o1[1]; L.acc[off+2] += o1[2];
+          L.acc[off+3] += o2[0]; L.acc[off+4] += o2[1]; L.acc[off+5] += o2[2];
+        } else {
+          L.acc[off] = o1[0]; L.acc[off+1] = o1[1]; L.acc[off+2] = o1[2];
+          L.acc[off+3] = o2[0]; L.acc[off+4] = o2[1]; L.acc[off+5] = o2[2];
+        }
       }
     }
     LDS_FENCE();
@@ -1133,9 +1160,22 @@ RKFD_DEV void rkfd_phase_bvel(const rkfdDevModel &m, const rkfdLds &L, double *b
 }
 
 /* ------------------------------------------------------------------------ */
-/* MLCP rigid branch (reference src/rkfd_mlcp.c:287-297).  Preconditions: sweep 2 (full) and
- * sweep 3 have been run with the wrenches applied so far (rkFDUpdateAccBias), so AC holds
- * the free accelerations and IA/U/MS hold Ia, U, Dinv.  Adds the contact wrenches to FE. */
+/* MLCP rigid branch (reference src/rkfd_mlcp.c:287-297).  Preconditions: sweep 2 and sweep 3
+ * have been run with the wrenches applied so far (rkFDUpdateAccBias), so AC holds the free
+ * accelerations and U / MS / CHOL hold U, 1/D and the factor of a float joint's Ia.
+ *
+ * The reference builds the contact-space matrix A column by column (unit force at a contact,
+ * rkFDChainUpdateCachedABIPair, read the relative accelerations, src/rkfd_mlcp.c:76-122) and,
+ * once the forces are found, re-runs the cached-ABI sweeps with them applied.  Here both use
+ * the factorisation the sweeps already hold, H^-1 = (1-HpsiK)' D^-1 (1-HpsiK): a probe walks
+ * from its contact link up to the root once, leaving the innovation nu_k(j) = -S_j' dp it
+ * causes at every joint j it passes (scaled by sqrt(1/D_j); for a float joint the six
+ * components of L^-1 dp).  Then
+ *     A(r,k)   = sum over the joints common to both paths of nu_r(j) nu_k(j)      (+ relaxation),
+ *     delta qdd = the sweep-3 recursion driven by sum_k f_k nu_k                  (rkfd_phase_sweep3<true>),
+ * i.e. no per-column response walks and no second backward sweep; A comes out exactly
+ * symmetric.  Output: contact forces CF, committed contact state, and the inputs of the delta
+ * sweep (MS slot 1, U slot of float joints). */
 template<bool prof> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L, const double *bv, unsigned long long *pc)
 {
   unsigned long long q0 = prof ? RKFD_CLOCK() : 0ull, q1;
@@ -1144,23 +1184,14 @@ template<bool prof> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const r
   const int nc = L.cnt[CNT_NRG];
   const int M = 3*nc;
   const int ld = M+1;
-  const int NLV = m.nlevel;
+  const int NLV = m.nlevel, NL = m.nlink, NR = m.npurow;
+  const int NSD = m.nside;
+  const int PUS = NR*M;                               /* stride between the two sides of PU */
+  const unsigned char *TOP = L.PL + NL*NLV;           /* where a force on a link stops propagating (255: static) */
+  const unsigned char *FSL = TOP + NL;                /* float slot of a link */
+  const unsigned char *FLK = FSL + NL;                /* link of a float slot */
   const double dt = m.dt;
 
-  /* distinct non-static links that carry a rigid contact (targets of the response walk) */
-  if( lane == 0 ){
-    int nt = 0;
-    for( int c=0; c<nc; c++ ){
-      const int j = L.lrg[c];
-      for( int s=0; s<2; s++ ){
-        const int l = s == 0 ? RKFD_CI_A( L.CIp[j] ) : RKFD_CI_B( L.CIp[j] );
-        if( RKFD_LI_STATIC( L.LI[l] ) ) continue;
-        int k; for( k=0; k<nt; k++ ) if( L.tgt[k] == l ) break;
-        if( k == nt ) L.tgt[nt++] = l;
-      }
-    }
-    L.cnt[CNT_NTGT] = nt;
-  }
   /* b: free relative acceleration, then *dt + relative velocity + compensation
    * (_rkFDSolverBiasAcc / BiasVel / RelaxationCompensation, reference src/rkfd_mlcp.c:58-74,146-188) */
   if( lane < nc ){
@@ -1185,21 +1216,39 @@ template<bool prof> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const r
       b += ( i == 0 ? K : K*mu )*d_dot( d, ax );
       L.MB[3*lane+i] = b;
     }
+    /* the moving side(s) of this contact, packed (RKFD_CS_*): link, its depth, the link where its
+     * path ends (TOP), the first level of the path that carries a 1-DoF joint, float-top flag,
+     * side.  One entry per contact when no rigid pair has two moving links, else one per side. */
+    if( NSD == 1 ) L.tgt[lane] = 0;      /* (a contact between two immovable links has no moving side) */
+#pragma unroll
+    for( int sd=0; sd<2; sd++ ){
+      const int a = sd == 0 ? la : lb;
+      const int top = TOP[a];
+      if( NSD == 1 && top == 255 ) continue;
+      const int lit = L.LI[top == 255 ? 0 : top], jtt = RKFD_LI_JT( lit );
+      const int d0 = RKFD_LI_DEPTH( lit ) + ( jtt == RKFD_JOINT_REVOL || jtt == RKFD_JOINT_PRISM ? 0 : 1 );
+      const unsigned e = (unsigned)a | ( (unsigned)RKFD_LI_DEPTH( L.LI[a] ) << 8 ) | ( (unsigned)top << 14 ) | ( (unsigned)d0 << 22 )
+                       | ( jtt == RKFD_JOINT_FLOAT ? 1u << 29 : 0u ) | ( (unsigned)sd << 30 ) | ( top != 255 ? 1u << 31 : 0u );
+      L.tgt[NSD == 1 ? lane : 2*lane+sd] = (int)e;
+    }
+  }
+  /* sqrt(1/D) of the 1-DoF joints (MS slot 2: the driving torque kept there is dead after sweep 2) */
+  if( lane < NL ){
+    const int jt = RKFD_LI_JT( L.LI[lane] );
+    if( jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM ) L.MS[4*lane+2] = sqrt( L.MS[4*lane+0] );
   }
   SYNC();
   MST(14);
   /* probes: lane = column k = 3c+i; unit force along axis i at contact c, applied to the
-   * owner link (+) and the other link (-).  Linear response only (delta form of
-   * rkFDChainUpdateCachedABIPair + _rkFDSolverRelativeAcc, reference src/rkfd_mlcp.c:76-122). */
+   * owner link (+) and the other link (-).  Every level between the contact link and the top of
+   * its path carries a 1-DoF joint; the operands of the next level are fetched while this one is
+   * computed. */
   for( int cb=0; cb<M; cb+=RKFD_WAVE ){      /* 64 probe columns at a time */
     const int col = cb + lane;
     const bool on = col < M;
     const int c = on ? col/3 : 0, ia = on ? col%3 : 0;
-    const int j = nc > 0 ? L.lrg[c] : 0;
-    const int cinfk = L.CIp[j];
-    const int lk[2] = { RKFD_CI_A( cinfk ), RKFD_CI_B( cinfk ) };
-    double W[6], droot[2][6];
-    int rootl[2] = { -1, -1 };
+    const int j = L.lrg[c];
+    double W[6];
     {
       const double x[3] = { L.CX[3*L.asl[j]], L.CX[3*L.asl[j]+1], L.CX[3*L.asl[j]+2] };
       const double *ax = &L.AX[9*L.asl[j]+3*ia];
@@ -1207,102 +1256,109 @@ template<bool prof> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const r
       W[3] = ax[0]; W[4] = ax[1]; W[5] = ax[2];
     }
     if( on ){
-      for( int s=0; s<2; s++ ){
-        int i = lk[s];
-#pragma unroll
-        for( int k=0; k<6; k++ ) droot[s][k] = 0;
-        if( RKFD_LI_STATIC( L.LI[i] ) ) continue;
+      for( int s2=0; s2<NSD; s2++ ){
+        const unsigned e = (unsigned)L.tgt[c*NSD+s2];
+        if( !RKFD_CS_VALID( e ) ) continue;
+        const int a = RKFD_CS_LINK( e ), da = RKFD_CS_DEPTH( e ), d0 = RKFD_CS_D0( e );
         /* bias force delta: p = -f_ext */
         double dp[6];
-        const double sg = s == 0 ? -1.0 : 1.0;
+        const double sg = RKFD_CS_SIDE( e ) == 0 ? -1.0 : 1.0;
 #pragma unroll
         for( int k=0; k<6; k++ ) dp[k] = sg*W[k];
-        int lii = L.LI[i];
-        for(;;){
-          const int jt = RKFD_LI_JT( lii ), par = RKFD_LI_PAR( lii );
-          const int lin = L.LI[par >= 0 ? par : 0];     /* the parent's record, fetched under this link's arithmetic */
-          if( jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM ){
-            double du = 0;
+        double *pu = &L.PU[s2*PUS + col];
+        const unsigned char *path = &L.PL[a*NLV];
+        double Sx[6], Ux[6], sdx, dix;
 #pragma unroll
-            for( int k=0; k<6; k++ ) du -= L.S[6*i+k]*dp[k];
-            L.PU[( ( m.nside == 2 ? s : 0 )*NLV + RKFD_LI_DEPTH( lii ) )*M + col] = du;
-            const double t = du*L.MS[4*i+0];
+        for( int k=0; k<6; k++ ){ Sx[k] = L.S[6*a+k]; Ux[k] = L.U[6*a+k]; }
+        sdx = L.MS[4*a+2]; dix = L.MS[4*a+0];
+        int inext = path[da > 0 ? da-1 : 0];
+        for( int d=da; d>=d0; d-- ){
+          const int in_ = inext;
+          double Sn[6], Un[6];
 #pragma unroll
-            for( int k=0; k<6; k++ ) dp[k] += L.U[6*i+k]*t;
-          } else if( jt == RKFD_JOINT_FLOAT ){
-            /* delta a = IA^-1 ( -dp ) */
-            double rhs[6];
+          for( int k=0; k<6; k++ ){ Sn[k] = L.S[6*in_+k]; Un[k] = L.U[6*in_+k]; }
+          const double sdn = L.MS[4*in_+2], din = L.MS[4*in_+0];
+          inext = path[d > 1 ? d-2 : 0];
+          double du0 = Sx[0]*dp[0], du1 = Sx[1]*dp[1];
+          du0 = fma( Sx[2], dp[2], du0 ); du1 = fma( Sx[3], dp[3], du1 );
+          du0 = fma( Sx[4], dp[4], du0 ); du1 = fma( Sx[5], dp[5], du1 );
+          const double du = -( du0 + du1 );
+          pu[d*M] = du*sdx;
+          const double t = du*dix;
 #pragma unroll
-            for( int k=0; k<6; k++ ) rhs[k] = -dp[k];
-            /* float slot = rank of link i among the float joints (same order as the host's) */
-            int fs = 0;
-            for( int q=0; q<i; q++ ) fs += RKFD_LI_JT( L.LI[q] ) == RKFD_JOINT_FLOAT;
-            d_chol6_solve( &L.CHOL[36*fs], rhs, droot[s] );
-            rootl[s] = i;
-            break;
-          }
-          if( par < 0 ){ rootl[s] = i; break; }  /* fixed / 1-DoF root: world does not move */
-          i = par; lii = lin;
+          for( int k=0; k<6; k++ ) dp[k] = fma( Ux[k], t, dp[k] );
+#pragma unroll
+          for( int k=0; k<6; k++ ){ Sx[k] = Sn[k]; Ux[k] = Un[k]; }
+          sdx = sdn; dix = din;
+        }
+        if( RKFD_CS_FLOAT( e ) ){
+          /* delta a = IA^-1 ( -dp ) = L^-T y,  y = L^-1 ( -dp ) */
+          double rhs[6], y[6];
+#pragma unroll
+          for( int k=0; k<6; k++ ) rhs[k] = -dp[k];
+          d_chol6_fwd( &L.CHOL[36*FSL[RKFD_CS_TOP( e )]], rhs, y );
+#pragma unroll
+          for( int k=0; k<6; k++ ) pu[( NLV+k )*M] = y[k];
         }
       }
     }
-    SYNC();
-    MST(15);
-    /* response at every target link, then the column entries */
-    const int nt = L.cnt[CNT_NTGT];
-    if( on ){
-      for( int r=0; r<M; r++ ) L.MA[r*ld+col] = 0.0;
-      for( int t=0; t<nt; t++ ){
-        const int T = L.tgt[t];
-        const int dT = RKFD_LI_DEPTH( L.LI[T] );
-        const int rt = L.PL[T*NLV];
-        double da[6] = {0,0,0,0,0,0};
-        int side = -1;
-        if( rootl[0] >= 0 && L.PL[lk[0]*NLV] == rt ) side = 0;
-        else if( rootl[1] >= 0 && L.PL[lk[1]*NLV] == rt ) side = 1;
-        if( side < 0 ) continue;
-        const int src = lk[side], dsrc = RKFD_LI_DEPTH( L.LI[src] );
-        int i = L.PL[T*NLV], lii = L.LI[i];
-        for( int d=0; d<=dT; d++ ){
-          const int in_ = L.PL[T*NLV + ( d < dT ? d+1 : d )];
-          const int lin = L.LI[in_];                     /* next level, fetched under this level's arithmetic */
-          const int jt = RKFD_LI_JT( lii );
-          if( jt == RKFD_JOINT_FLOAT ){
-#pragma unroll
-            for( int k=0; k<6; k++ ) da[k] = droot[side][k];
-          } else if( jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM ){
-            const bool onpath = d <= dsrc && L.PL[src*NLV+d] == i;
-            double du = onpath ? L.PU[( ( m.nside == 2 ? side : 0 )*NLV + d )*M + col] : 0.0;
-            double ua = 0;
-#pragma unroll
-            for( int k=0; k<6; k++ ) ua += L.U[6*i+k]*da[k];
-            const double qdd = ( du - ua )*L.MS[4*i+0];
-#pragma unroll
-            for( int k=0; k<6; k++ ) da[k] += L.S[6*i+k]*qdd;
-          }
-          i = in_; lii = lin;
-        }
-        /* entries for the contacts that touch T */
-        for( int r=0; r<nc; r++ ){
-          const int jr = L.lrg[r];
-          double sgn = 0;
-          if( RKFD_CI_A( L.CIp[jr] ) == T ) sgn = 1.0;
-          else if( RKFD_CI_B( L.CIp[jr] ) == T ) sgn = -1.0;
-          if( sgn == 0 ) continue;
-          const double x[3] = { L.CX[3*L.asl[jr]], L.CX[3*L.asl[jr]+1], L.CX[3*L.asl[jr]+2] };
-          double t3[3], acc[3];
-          d_cross( da, x, t3 );
-          acc[0] = da[3]+t3[0]; acc[1] = da[4]+t3[1]; acc[2] = da[5]+t3[2];
-#pragma unroll
-          for( int i2=0; i2<3; i2++ )
-            L.MA[(3*r+i2)*ld+col] += sgn*d_dot( &L.AX[9*L.asl[jr]+3*i2], acc );
-        }
-      }
-      /* relaxation on the diagonal */
-      L.MA[col*ld+col] += m.ci_l[RKFD_CI_CI( cinfk )];
-    }
-    SYNC();
   }
+  SYNC();
+  MST(15);
+  /* A, one 3x3 block per lane and pass: block ( cr, ck <= cr ) and its mirror image */
+  for( int e0=0; e0<nc*nc; e0+=RKFD_WAVE ){
+    const int e = e0 + lane;
+    const int cr = e/nc, ck = e - cr*nc;
+    if( e < nc*nc && ck <= cr ){
+      double blk[9] = {0,0,0,0,0,0,0,0,0};
+      for( int sr=0; sr<NSD; sr++ ) for( int sk=0; sk<NSD; sk++ ){
+        const unsigned er = (unsigned)L.tgt[cr*NSD+sr], ek = (unsigned)L.tgt[ck*NSD+sk];
+        if( !RKFD_CS_VALID( er ) || !RKFD_CS_VALID( ek ) || RKFD_CS_TOP( er ) != RKFD_CS_TOP( ek ) ) continue;   /* no joint in common */
+        const double *pr = &L.PU[sr*PUS + 3*cr], *pk = &L.PU[sk*PUS + 3*ck];
+        const int a = RKFD_CS_LINK( er ), b = RKFD_CS_LINK( ek );
+        const int d0 = RKFD_CS_D0( er );
+        int dc = RKFD_CS_DEPTH( er ) < RKFD_CS_DEPTH( ek ) ? RKFD_CS_DEPTH( er ) : RKFD_CS_DEPTH( ek );
+        if( a != b ){
+          /* last level the two paths share */
+          int d = d0;
+          while( d <= dc && L.PL[a*NLV+d] == L.PL[b*NLV+d] ) d++;
+          dc = d-1;
+        }
+#pragma unroll 2
+        for( int d=d0; d<=dc; d++ ){
+          const double r0 = pr[d*M], r1 = pr[d*M+1], r2 = pr[d*M+2];
+          const double k0 = pk[d*M], k1 = pk[d*M+1], k2 = pk[d*M+2];
+          blk[0] = fma( r0, k0, blk[0] ); blk[1] = fma( r0, k1, blk[1] ); blk[2] = fma( r0, k2, blk[2] );
+          blk[3] = fma( r1, k0, blk[3] ); blk[4] = fma( r1, k1, blk[4] ); blk[5] = fma( r1, k2, blk[5] );
+          blk[6] = fma( r2, k0, blk[6] ); blk[7] = fma( r2, k1, blk[7] ); blk[8] = fma( r2, k2, blk[8] );
+        }
+        if( RKFD_CS_FLOAT( er ) ){
+#pragma unroll
+          for( int q=0; q<6; q++ ){
+            const int d = NLV + q;
+            const double r0 = pr[d*M], r1 = pr[d*M+1], r2 = pr[d*M+2];
+            const double k0 = pk[d*M], k1 = pk[d*M+1], k2 = pk[d*M+2];
+            blk[0] = fma( r0, k0, blk[0] ); blk[1] = fma( r0, k1, blk[1] ); blk[2] = fma( r0, k2, blk[2] );
+            blk[3] = fma( r1, k0, blk[3] ); blk[4] = fma( r1, k1, blk[4] ); blk[5] = fma( r1, k2, blk[5] );
+            blk[6] = fma( r2, k0, blk[6] ); blk[7] = fma( r2, k1, blk[7] ); blk[8] = fma( r2, k2, blk[8] );
+          }
+        }
+      }
+      if( cr == ck ){
+        /* relaxation on the diagonal */
+        const double rl = m.ci_l[RKFD_CI_CI( L.CIp[L.lrg[cr]] )];
+        blk[0] += rl; blk[4] += rl; blk[8] += rl;
+      }
+#pragma unroll
+      for( int i=0; i<3; i++ )
+#pragma unroll
+        for( int q=0; q<3; q++ ){
+          L.MA[( 3*cr+i )*ld + 3*ck+q] = blk[3*i+q];
+          if( cr != ck ) L.MA[( 3*ck+q )*ld + 3*cr+i] = blk[3*i+q];
+        }
+    }
+  }
+  SYNC();
   MST(6);
   /* projected Gauss-Seidel, fixed max_iter sweeps, no warm start (_rkFDSolverMLCP, reference
    * src/rkfd_mlcp.c:190-249), same update order.  lane = contact: each lane keeps the three
@@ -1356,7 +1412,7 @@ template<bool prof> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const r
     if( on ){ L.MF[r0] = fn/dt; L.MF[r0+1] = f1/dt; L.MF[r0+2] = f2/dt; }
   }
   SYNC();
-  MST(7);
+  MST(21);
   /* _rkFDSolverSetForce (reference src/rkfd_mlcp.c:252-284) incl. quirks Q1 / Q2 */
   if( lane < nc ){
     const int j = L.lrg[lane], ci = RKFD_CI_CI( L.CIp[j] );
@@ -1377,7 +1433,40 @@ template<bool prof> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const r
     }
   }
   SYNC();
-  rkfd_push_wrenches( m, L, L.lrg, nc );
+  MST(22);
+  /* inputs of the delta sweep, lane = link: what the solved forces F = MF do to the joint's
+   * innovation.  1-DoF joint: sum_k F_k nu_k / D  (= scaled sum times sqrt(1/D));  float joint:
+   * sum_k F_k y_k.  Links no contact path passes get 0. */
+  {
+    const int ntask = NL + 6*m.nfloat;    /* one per link (used by those with a 1-DoF joint), then six per float joint */
+    for( int t0=0; t0<ntask; t0+=RKFD_WAVE ){
+      const int t = t0 + lane;
+      const bool isl = t < NL, isf = !isl && t < ntask;
+      const int fq = isf ? ( t-NL )%6 : 0;
+      const int link = isl ? t : ( isf ? FLK[( t-NL )/6] : 0 );
+      const int lii = L.LI[link], jt = RKFD_LI_JT( lii );
+      const bool is1 = isl && ( jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM );
+      const int dpt = isl ? RKFD_LI_DEPTH( lii ) : 0;
+      const int row = isf ? NLV+fq : dpt;
+      double sum = 0;
+#pragma unroll 2
+      for( int cs=0; cs<nc*NSD; cs++ ){
+        const unsigned e = (unsigned)L.tgt[cs];
+        const int c = NSD == 1 ? cs : cs >> 1;
+        const double *pu = &L.PU[( NSD == 1 ? 0 : ( cs & 1 ) )*PUS + row*M + 3*c];
+        const double v = L.MF[3*c]*pu[0] + L.MF[3*c+1]*pu[1] + L.MF[3*c+2]*pu[2];
+        /* 1-DoF joint: it lies on the moving path of the contact side; float joint: the path ends there */
+        const bool onp = RKFD_CS_VALID( e ) && ( isf ? RKFD_CS_TOP( e ) == link
+                       : ( RKFD_CS_DEPTH( e ) >= dpt && RKFD_CS_D0( e ) <= dpt && L.PL[RKFD_CS_LINK( e )*NLV+dpt] == link ) );
+        sum += onp ? v : 0.0;
+      }
+      if( is1 ) L.MS[4*link+1] = sum*L.MS[4*link+2];
+      if( isf ) L.U[6*link+fq] = sum;
+    }
+  }
+  SYNC();
+  MST(23);
+#undef MST
 }
 
 /* ------------------------------------------------------------------------ */
@@ -1414,23 +1503,20 @@ template<bool prof> RKFD_DEV int rkfd_evaluate(const rkfdDevModel &m, const rkfd
   double bv[6];
   rkfd_phase_bvel( m, L, bv );
   STAMP(1);
-  /* pass 0: rkChainUpdateABI (full sweeps; with rigid contacts this is rkFDUpdateAccBias);
-   * pass 1 (only after the MLCP solve): rkChainUpdateCachedABI with the contact wrenches.
-   * Written as a loop so that the sweep code exists once in the instruction stream. */
-  int npass = 1;
-  for( int pass=0; pass<npass; pass++ ){
-    rkfd_phase_sweep2<prof>( m, L, pass == 0, pc );
-    STAMP(2);
-    rkfd_phase_sweep3( m, L );
-    STAMP(3);
-    if( pass == 0 && L.cnt[CNT_NRG] > 0 ){
-      if( m.solver == RKFD_SOLVER_MLCP ){
-        rkfd_phase_mlcp<prof>( m, L, bv, pc );
-        STAMP(4);
-        npass = 2;
-      } else {
-        err = 1;
-      }
+  /* rkChainUpdateABI (with rigid contacts this is rkFDUpdateAccBias) */
+  rkfd_phase_sweep2<prof>( m, L, pc );
+  STAMP(2);
+  rkfd_phase_sweep3<false>( m, L );
+  STAMP(3);
+  if( L.cnt[CNT_NRG] > 0 ){
+    if( m.solver == RKFD_SOLVER_MLCP ){
+      /* contact forces, then their effect on the accelerations (rkChainUpdateCachedABI in the reference) */
+      rkfd_phase_mlcp<prof>( m, L, bv, pc );
+      STAMP(4);
+      rkfd_phase_sweep3<true>( m, L );
+      STAMP(3);
+    } else {
+      err = 1;
     }
   }
   /* rkFDUpdateJointPrevDrivingTrq (reference src/rkfd_util.c:289-311), committing evaluation only */
@@ -1480,7 +1566,7 @@ template<bool prof> RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkf
   const int lane = LANE();
   const int ND = m.ndof, NL = m.nlink, NC = m.ncand;
   rkfdLds L;
-  rkfd_lds_carve( &L, ldsbase, NL, ND, NC, 3*m.maxrg, m.nlevel, m.npool, m.nfloat, m.maxact, m.nside, m.pu_alias );
+  rkfd_lds_carve( &L, ldsbase, NL, ND, NC, 3*m.maxrg, m.nlevel, m.npool, m.nfloat, m.maxact, m.nside, m.pu_alias, m.npurow );
   if( lane == 0 ) L.cnt[CNT_OVF] = 0;
 
   /* load persistent state */
@@ -1498,7 +1584,7 @@ template<bool prof> RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkf
     ll.pivp = st.piv_prev[(size_t)b*m.nlink_model+lm];
   }
   if( m.maxrg > 0 ){
-    for( int k=lane; k<NL*m.nlevel; k+=RKFD_WAVE ) L.PL[k] = (unsigned char)m.pathlink[k];
+    for( int k=lane; k<NL*( m.nlevel+3 ); k+=RKFD_WAVE ) L.PL[k] = (unsigned char)m.pathlink[k];
   }
   for( int c0=0; c0<NC; c0+=RKFD_WAVE ){
     const int j = c0 + lane;

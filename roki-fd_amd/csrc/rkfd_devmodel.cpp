@@ -160,10 +160,17 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
     for( int i=0; i<NL; i++ ) if( R_parent[i] >= 0 ) child_idx[cur[R_parent[i]]++] = i;
   }
   /* ancestor at depth d */
-  std::vector<int> pathlink( (size_t)NL*nlevel, -1 );
+  std::vector<int> pathlink( (size_t)NL*( nlevel+3 ), -1 );
   for( int i=0; i<NL; i++ ){
     int a = i;
     while( a >= 0 ){ pathlink[(size_t)i*nlevel+depth[a]] = a; a = R_parent[a]; }
+  }
+  /* row nlevel: the link where a force applied to link i stops propagating upwards - the nearest
+   * float joint at or above i, else the root (-1 for a link that cannot move) */
+  for( int i=0; i<NL; i++ ){
+    int a = i;
+    while( R_jtype[a] != RKFD_JOINT_FLOAT && R_parent[a] >= 0 ) a = R_parent[a];
+    pathlink[(size_t)NL*nlevel+i] = is_static[i] ? -1 : a;
   }
   /* candidates: owner / other link after merging, vertex in the owner device link's frame;
    * planes of every shape re-expressed in its device link's frame */
@@ -279,6 +286,12 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
       }
   }
 
+  /* rows nlevel+1, nlevel+2 of the path table: float slot of a link (its CHOL / XF slot), link of a float slot */
+  for( int i=0; i<NL; i++ ){
+    pathlink[(size_t)NL*( nlevel+1 )+i] = fslot[i];
+    if( fslot[i] >= 0 ) pathlink[(size_t)NL*( nlevel+2 )+fslot[i]] = i;
+  }
+
   Blob b;
   rkfdDevModel dm;
   memset( &dm, 0, sizeof(dm) );
@@ -294,7 +307,11 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
     if( m->ci_type[cci[j]] == RKFD_CONTACT_RIGID && !is_static[cA[j]] && !is_static[cB[j]] ) nside = 2;
   dm.maxact = maxact; dm.nside = nside; dm.ref_by_slot = NC <= RKFD_WAVE ? 1 : 0;
   const size_t Mrows = 3*(size_t)max_rigid;
-  dm.pu_alias = ( (size_t)nside*nlevel*Mrows <= (size_t)12*NL ) ? 1 : 0;
+  /* probe scratch: one row per tree level plus six for a float root, per side; it overlays the
+   * V|C|PB|PA block of the link arrays (dead while the contact problem is solved) when it fits */
+  const int npurow = nlevel + ( nfloat > 0 ? 6 : 0 );
+  dm.npurow = npurow;
+  dm.pu_alias = ( (size_t)nside*npurow*Mrows <= (size_t)24*NL ) ? 1 : 0;
   std::vector<int> dofkind( ND ? ND : 1, 0 );
   for( int i=0; i<NL; i++ )
     if( R_jtype[i] == RKFD_JOINT_FLOAT ){ dofkind[R_dofoff[i]+3] = 1; dofkind[R_dofoff[i]+4] = 2; dofkind[R_dofoff[i]+5] = 2; }
@@ -343,9 +360,9 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
     size_t stage = (size_t)14*NL + (size_t)36*npool;            /* inertia staging + Ia pool ...   */
     if( M*(M+1) > stage ) stage = M*(M+1);                       /* ... shared with the MLCP matrix */
     const size_t dbl = (size_t)3*ND + (size_t)NL*( 7*6 + 4 ) + stage + (size_t)48*nfloat
-                     + (size_t)maxact*21 + (size_t)( NC <= RKFD_WAVE ? maxact : NC )*3 + 2*M + ( dm.pu_alias ? 0 : (size_t)nside*nlevel*M );
+                     + (size_t)maxact*21 + (size_t)( NC <= RKFD_WAVE ? maxact : NC )*3 + 2*M + ( dm.pu_alias ? 0 : (size_t)nside*npurow*M );
     const size_t ints = (size_t)5*NC + (size_t)4*maxact + 8 + 3*(size_t)NL     /* act typ asl CIp CFO, lrg lel tgt, cnt, LI CHI PSL */
-                      + ( max_rigid > 0 ? ( (size_t)NL*nlevel + 3 )/4 : 0 );   /* PL (bytes) */
+                      + ( max_rigid > 0 ? ( (size_t)NL*( nlevel+3 ) + 3 )/4 : 0 );   /* PL (bytes) */
     out->lds_bytes = dbl*sizeof(double) + ints*sizeof(int);
     out->lds_bytes = ( out->lds_bytes + 15 ) & ~(size_t)15;
   }

@@ -22,7 +22,8 @@ typedef struct {
   int solver, max_iter;
   int maxact;            /* capacity: active contact vertices (rigid + elastic) per instance        */
   int ref_by_slot;       /* 1: stick anchors are stored per active-contact slot (ncand <= 64)          */
-  int pu_alias;          /* 1: the probe scratch PU fits in (and aliases) the PA|AC region              */
+  int pu_alias;          /* 1: the probe scratch PU fits in (and aliases) the V|C|PB|PA block           */
+  int npurow;            /* rows of PU per side: nlevel (+6 with a float joint)                         */
   int nside;             /* 1 when every rigid-capable pair has a static cell (probe walks one-sided) else 2 */
   int maxrg;             /* capacity: rigid contact vertices solved per instance (3*maxrg <= 128) */
   double dt, fric_w;
@@ -38,7 +39,7 @@ typedef struct {
   const int *level_link; /* [nlink] links sorted by depth                                */
   const int *child_off;  /* [nlink+1]                                                    */
   const int *child_idx;  /* [nlink-#roots]                                               */
-  const int *pathlink;   /* [nlink][nlevel]: ancestor of link at depth d (d<=depth)      */
+  const int *pathlink;   /* [nlink][nlevel]: ancestor of link at depth d (d<=depth); then [nlink]: top link (see host) */
   /* packed per-link ints (copied to LDS): see RKFD_LI_* */
   const int *linfo;      /* [nlink]                                                      */
   /* sweep schedule: (nsched+4) iterations x 8 lane groups x 4 ints
