@@ -13,7 +13,10 @@ static thread_local char g_err[512] = "";
 #define HIPCHK(call, ret) do{ hipError_t e_ = (call); if( e_ != hipSuccess ){ \
   SETERR( "%s failed: %s", #call, hipGetErrorString( e_ ) ); return ret; } }while(0)
 
-/* one workgroup = one wavefront = one world instance; state lives in LDS for the whole launch */
+/* one workgroup = one wavefront = one world instance; state lives in LDS for the whole launch.
+ * Register budget: 256 VGPRs = two waves per SIMD = eight instances per CU.  A third wave per
+ * SIMD (168 VGPRs, LDS permitting) was measured slower: at two waves the VALU is already ~55 %
+ * busy and the tighter budget spills (~230 B of scratch per lane). */
 extern "C" __global__ void __launch_bounds__(RKFD_WAVE, 2)
 rkfd_step_kernel(rkfdDevModel m, rkfdDevState st, int mode, int nsteps, int *errflag)
 {

@@ -298,16 +298,14 @@ typedef struct {
   double *q, *qd, *acc;           /* [ndof] each                                         */
   double *tmp;                    /* [ndof] scratch of rkfd_cat_dis: ALIASES V (dead between evaluations) */
   double *S;                      /* [NL*6]  joint axis (ang, lin)                        */
-  double *V;                      /* [NL*6]  spatial velocity                             */
-  double *C;                      /* [NL*6]  velocity-product acceleration                */
-  double *PB;                     /* [NL*6]  own bias force minus the external wrenches   */
-  double *PA;                     /* [NL*6]  bias force handed to the parent              */
-  double *AC;                     /* [NL*6]  spatial acceleration (adjacent to PA)        */
-  double *X;                      /* [NL*12] world frames R(9) p(3): ALIASES PA|AC, valid from the
-                                     kinematics phase to the end of the collision phase   */
-  double *U;                      /* [NL*6]                                               */
-  double *W;                      /* [NL*6]  Ia c, kept for the bias-only sweep: ALIASES V (the link velocities are
-                                     dead once the contact phases and rkfd_phase_bvel are done) */
+  double *V;                      /* [NL*6]  spatial velocity (kinematics .. rkfd_phase_bvel)               */
+  double *U;                      /* [NL*6]  Ia S, written by sweep 2: ALIASES V                            */
+  double *PB;                     /* [NL*6]  own bias force minus the external wrenches (kinematics .. sweep 2) */
+  double *AC;                     /* [NL*6]  spatial acceleration, written by sweep 3: ALIASES PB           */
+  double *C;                      /* [NL*6]  velocity-product acceleration (kinematics .. sweep 3)          */
+  double *PA;                     /* [NL*6]  bias force handed to the parent (sweep 2)                      */
+  double *XA, *XB;                /* [NL*6] each: world frames, R rows 0-1 | R row 2, p.  Valid from the kinematics
+                                     phase to the end of the collision phase: XA ALIASES PA, XB the Ia pool */
   double *MS;                     /* [NL*4]  Dinv, u, tau, jm                             */
   double *IST;                    /* [NL*14] inertia staging: A = Iw + m(|r|^2 1 - r r') (xx,xy,xz,yy,yz,zz),
                                      +m r (3), -m r (3), m, 0: every entry of the 6x6 is one of these */
@@ -315,9 +313,10 @@ typedef struct {
   double *CHOL;                   /* [nfloat*36] articulated inertia / Cholesky factor of float joints */
   double *XF;                     /* [nfloat*12] float joints: world orientation of the joint-origin frame (9), link position (3) */
   double *CX, *AX, *RW, *PRO;     /* per ACTIVE contact slot (capacity maxact): 3, 9, 3, 3 */
-  double *REF;                    /* stick anchors (state): per active slot when ncand <= 64, else per candidate */
+  double *REF;                    /* stick anchors (state): per active slot              */
+  double *RTMP;                   /* [maxact*3] copy of REF while the slots are re-assigned; only when ncand > 64 */
   double *CF;                     /* contact forces (output): per active slot              */
-  double *MA, *MB, *MF, *PU;      /* MLCP: [M*(M+1)] (ALIASES IST|POOL), [M], [M], [2*nlevel*M] */
+  double *MA, *MB, *MF, *PU;      /* MLCP: [M*(M+1)] (ALIASES IST|POOL), [M], [M], [nside*npurow*M] (ALIASES C|PA when it fits) */
   int *act, *typ, *lrg, *lel, *tgt, *cnt;
   int *asl;                       /* [NC] active-contact slot of a candidate              */
   int *LI;                        /* [NL] packed link info (RKFD_LI_*)                    */
@@ -332,21 +331,26 @@ RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int
 {
   double *d = (double *)base;
   L->q = d; d += ND; L->qd = d; d += ND; L->acc = d; d += ND;
-  L->S = d; d += NL*6; L->V = d; L->tmp = d; d += NL*6; L->C = d; d += NL*6; L->PB = d; d += NL*6;
-  L->PA = d; L->X = d; d += NL*6; L->AC = d; d += NL*6;
-  L->U = d; d += NL*6; L->W = L->V; L->MS = d; d += NL*4;
+  L->S = d; d += NL*6;
+  L->V = d; L->U = d; L->tmp = d; d += NL*6;
+  L->PB = d; L->AC = d; d += NL*6;
+  L->C = d; d += NL*6;
+  L->PA = d; L->XA = d; d += NL*6;
+  L->MS = d; d += NL*4;
   {
-    int stage = 14*NL + 36*npool;
-    L->IST = d; L->POOL = d + 14*NL; L->MA = d;
+    const int pool = 36*npool > 6*NL ? 36*npool : 6*NL;
+    int stage = 14*NL + pool;
+    L->IST = d; L->POOL = d + 14*NL; L->XB = d + 14*NL; L->MA = d;
     if( M*(M+1) > stage ) stage = M*(M+1);
     d += stage;
   }
   L->CHOL = d; d += 36*nfloat; L->XF = d; d += 12*nfloat;
   L->CX = d; d += maxact*3; L->AX = d; d += maxact*9; L->RW = d; d += maxact*3; L->PRO = d; d += maxact*3;
-  L->REF = d; d += ( NC <= RKFD_WAVE ? maxact : NC )*3; L->CF = d; d += maxact*3;
+  L->REF = d; d += maxact*3; L->RTMP = d; if( NC > RKFD_WAVE ) d += maxact*3;
+  L->CF = d; d += maxact*3;
   L->MB = d; d += M; L->MF = d; d += M;
-  /* probe scratch: lives while the contact problem is set up and solved, when V, C, PB, PA are dead */
-  if( pu_alias ) L->PU = L->V; else { L->PU = d; d += nside*npurow*M; }
+  /* probe scratch: lives while the contact problem is set up and solved, when C and PA are dead */
+  if( pu_alias ) L->PU = L->C; else { L->PU = d; d += nside*npurow*M; }
   int *ip = (int *)d;
   L->act = ip; ip += NC; L->typ = ip; ip += NC; L->asl = ip; ip += NC; L->CIp = ip; ip += NC; L->CFO = ip; ip += NC;
   L->lrg = ip; ip += maxact; L->lel = ip; ip += maxact; L->tgt = ip; ip += 2*maxact; L->cnt = ip; ip += 8;
@@ -357,9 +361,8 @@ RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int
 /* per-lane state that only lane = link ever touches: kept in registers for the whole launch */
 typedef struct { double min, pivp; int pivt; } rkfdLaneLink;
 
-/* the stick anchors REF live per active-contact slot when all candidates fit one sweep of the
- * wave (ncand <= 64), else per candidate */
-#define RIDX(j) ( m.ref_by_slot ? L.asl[j] : (j) )
+/* the stick anchors REF live per active-contact slot */
+#define RIDX(j) ( L.asl[j] )
 
 /* packed description of one moving side of a rigid contact (built per evaluation in L->tgt) */
 #define RKFD_CS_LINK(e)   ( (int)( (e) & 0xFF ) )
@@ -431,8 +434,7 @@ template<bool prof> RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, c
   }
   if( on ){
 #pragma unroll
-    for( int k=0; k<9; k++ ) L.X[12*i+k] = R[k];
-    L.X[12*i+9] = p[0]; L.X[12*i+10] = p[1]; L.X[12*i+11] = p[2];
+    for( int k=0; k<6; k++ ){ L.XA[6*i+k] = R[k]; L.XB[6*i+k] = k < 3 ? R[6+k] : p[k-3]; }
   }
   SYNC();
   KST(16);
@@ -444,8 +446,9 @@ template<bool prof> RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, c
     if( a >= 0 ){
       double Ra[9], pa[3], t[3];
 #pragma unroll
-      for( int k=0; k<9; k++ ) Ra[k] = L.X[12*a+k];
-      pa[0] = L.X[12*a+9]; pa[1] = L.X[12*a+10]; pa[2] = L.X[12*a+11];
+      for( int k=0; k<6; k++ ) Ra[k] = L.XA[6*a+k];
+#pragma unroll
+      for( int k=0; k<3; k++ ){ Ra[6+k] = L.XB[6*a+k]; pa[k] = L.XB[6*a+3+k]; }
       d_mulv( Ra, p, t );
       p[0] = pa[0]+t[0]; p[1] = pa[1]+t[1]; p[2] = pa[2]+t[2];
       d_mul33( Ra, R, R );
@@ -453,8 +456,7 @@ template<bool prof> RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, c
     SYNC();
     if( a >= 0 ){
 #pragma unroll
-      for( int k=0; k<9; k++ ) L.X[12*i+k] = R[k];
-      L.X[12*i+9] = p[0]; L.X[12*i+10] = p[1]; L.X[12*i+11] = p[2];
+      for( int k=0; k<6; k++ ){ L.XA[6*i+k] = R[k]; L.XB[6*i+k] = k < 3 ? R[6+k] : p[k-3]; }
     }
     SYNC();
   }
@@ -948,6 +950,13 @@ RKFD_DEV void rkfd_phase_collision(const rkfdDevModel &m, const rkfdLds &L)
   const int lane = LANE();
   const unsigned long long below = lane == 0 ? 0ull : ( ~0ull >> ( 64-lane ) );
   int base_act = 0, base_rg = 0, base_el = 0, ovf = 0;
+  /* slots are re-assigned chunk by chunk: with more than one chunk the old anchors are read from a copy */
+  const double *oldref = L.REF;
+  if( m.ncand > RKFD_WAVE ){
+    for( int k=lane; k<3*m.maxact; k+=RKFD_WAVE ) L.RTMP[k] = L.REF[k];
+    oldref = L.RTMP;
+    SYNC();
+  }
   /* candidates are swept 64 at a time; slots and list positions keep candidate order */
   for( int c0=0; c0<m.ncand; c0+=RKFD_WAVE ){
     const bool on = c0+lane < m.ncand;
@@ -962,9 +971,11 @@ RKFD_DEV void rkfd_phase_collision(const rkfdDevModel &m, const rkfdLds &L)
       const int la = RKFD_CI_A( cinf ), lb = RKFD_CI_B( cinf );
       double RA[9], pA[3], vl[3], rr[3];
 #pragma unroll
-      for( int k=0; k<9; k++ ){ RA[k] = L.X[12*la+k]; RB[k] = L.X[12*lb+k]; }
+      for( int k=0; k<6; k++ ){ RA[k] = L.XA[6*la+k]; RB[k] = L.XA[6*lb+k]; }
 #pragma unroll
-      for( int k=0; k<3; k++ ){ pA[k] = L.X[12*la+9+k]; pB[k] = L.X[12*lb+9+k]; vl[k] = RELOAD( m.cand_vert )[3*j+k]; }
+      for( int k=0; k<3; k++ ){ RA[6+k] = L.XB[6*la+k]; RB[6+k] = L.XB[6*lb+k]; }
+#pragma unroll
+      for( int k=0; k<3; k++ ){ pA[k] = L.XB[6*la+3+k]; pB[k] = L.XB[6*lb+3+k]; vl[k] = RELOAD( m.cand_vert )[3*j+k]; }
       d_mulv( RA, vl, x );
       x[0] += pA[0]; x[1] += pA[1]; x[2] += pA[2];
       rr[0] = x[0]-pB[0]; rr[1] = x[1]-pB[1]; rr[2] = x[2]-pB[2];
@@ -979,7 +990,7 @@ RKFD_DEV void rkfd_phase_collision(const rkfdDevModel &m, const rkfdLds &L)
     /* anchors of the contacts that persist, read at their OLD slots before anything is rewritten */
     double oref[3] = {0,0,0};
     const int was = on ? L.act[j] : 0;
-    if( was ){ const int ri = RIDX( j ); oref[0] = L.REF[3*ri]; oref[1] = L.REF[3*ri+1]; oref[2] = L.REF[3*ri+2]; }
+    if( was ){ const int ri = RIDX( j ); oref[0] = oldref[3*ri]; oref[1] = oldref[3*ri+1]; oref[2] = oldref[3*ri+2]; }
     LDS_FENCE();
     /* active contacts get a slot in the per-contact arrays (capacity m.maxact) in candidate order */
     const unsigned long long mact = BALLOT( is_act );
@@ -998,10 +1009,7 @@ RKFD_DEV void rkfd_phase_collision(const rkfdDevModel &m, const rkfdLds &L)
           L.act[j] = 1; L.typ[j] = RKFD_SF;
           ref[0] = pro[0]; ref[1] = pro[1]; ref[2] = pro[2];
         } else { ref[0] = oref[0]; ref[1] = oref[1]; ref[2] = oref[2]; }
-        {
-          const int ri = m.ref_by_slot ? slot : j;
-          L.REF[3*ri] = ref[0]; L.REF[3*ri+1] = ref[1]; L.REF[3*ri+2] = ref[2];
-        }
+        L.REF[3*slot] = ref[0]; L.REF[3*slot+1] = ref[1]; L.REF[3*slot+2] = ref[2];
         L.CF[3*slot] = 0; L.CF[3*slot+1] = 0; L.CF[3*slot+2] = 0;
         d_mulv( RB, ref, rw );
         L.RW[3*slot] = rw[0]+pB[0]; L.RW[3*slot+1] = rw[1]+pB[1]; L.RW[3*slot+2] = rw[2]+pB[2];
@@ -1586,7 +1594,7 @@ template<bool prof> RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkf
   if( m.maxrg > 0 ){
     for( int k=lane; k<NL*( m.nlevel+3 ); k+=RKFD_WAVE ) L.PL[k] = (unsigned char)m.pathlink[k];
   }
-  for( int c0=0; c0<NC; c0+=RKFD_WAVE ){
+  for( int c0=0, base=0; c0<NC; c0+=RKFD_WAVE ){
     const int j = c0 + lane;
     const bool onj = j < NC;
     int a = 0;
@@ -1598,15 +1606,15 @@ template<bool prof> RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkf
     }
     /* slots of the contacts alive at launch (candidate order; re-assigned by every collision pass) */
     const unsigned long long ma = BALLOT( a != 0 );
-    int sl = __builtin_popcountll( ma & ( lane == 0 ? 0ull : ( ~0ull >> ( 64-lane ) ) ) );
-    if( m.ref_by_slot && a && sl >= m.maxact ) a = 0;
+    const int sl = base + __builtin_popcountll( ma & ( lane == 0 ? 0ull : ( ~0ull >> ( 64-lane ) ) ) );
+    base += __builtin_popcountll( ma );
+    if( a && sl >= m.maxact ) a = 0;
     if( onj ){
       L.act[j] = a;
-      L.asl[j] = m.ref_by_slot ? sl : 0;
+      L.asl[j] = a ? sl : 0;
       if( a ){
-        const int ri = m.ref_by_slot ? sl : j;
 #pragma unroll
-        for( int k=0; k<3; k++ ) L.REF[3*ri+k] = st.cv_ref[((size_t)b*NC+j)*3+k];
+        for( int k=0; k<3; k++ ) L.REF[3*sl+k] = st.cv_ref[((size_t)b*NC+j)*3+k];
       }
     }
   }

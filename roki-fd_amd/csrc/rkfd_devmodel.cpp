@@ -300,18 +300,25 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   dm.dt = m->dt; dm.fric_w = m->friction_weight;
   dm.nsched = nsched; dm.npool = npool; dm.nfloat = nfloat;
   /* contact capacities */
-  int maxact = NC < 16 ? NC : 16;
-  if( max_rigid > maxact ) maxact = max_rigid < NC ? max_rigid : NC;
+  /* active-contact slots: up to 16 when elastic (penalty) contacts can occur, and at least the
+   * rigid capacity when rigid ones can */
+  bool has_elastic = false, has_rigid = false;
+  for( int j=0; j<NC; j++ ){
+    if( m->ci_type[cci[j]] == RKFD_CONTACT_RIGID ) has_rigid = true; else has_elastic = true;
+  }
+  int maxact = has_elastic ? ( NC < 16 ? NC : 16 ) : 0;
+  if( has_rigid && max_rigid > maxact ) maxact = max_rigid < NC ? max_rigid : NC;
+  if( NC > 0 && maxact < 1 ) maxact = 1;
   int nside = 1;
   for( int j=0; j<NC; j++ )
     if( m->ci_type[cci[j]] == RKFD_CONTACT_RIGID && !is_static[cA[j]] && !is_static[cB[j]] ) nside = 2;
-  dm.maxact = maxact; dm.nside = nside; dm.ref_by_slot = NC <= RKFD_WAVE ? 1 : 0;
+  dm.maxact = maxact; dm.nside = nside;
   const size_t Mrows = 3*(size_t)max_rigid;
   /* probe scratch: one row per tree level plus six for a float root, per side; it overlays the
-   * V|C|PB|PA block of the link arrays (dead while the contact problem is solved) when it fits */
+   * C|PA block of the link arrays (dead while the contact problem is solved) when it fits */
   const int npurow = nlevel + ( nfloat > 0 ? 6 : 0 );
   dm.npurow = npurow;
-  dm.pu_alias = ( (size_t)nside*npurow*Mrows <= (size_t)24*NL ) ? 1 : 0;
+  dm.pu_alias = ( (size_t)nside*npurow*Mrows <= (size_t)12*NL ) ? 1 : 0;
   std::vector<int> dofkind( ND ? ND : 1, 0 );
   for( int i=0; i<NL; i++ )
     if( R_jtype[i] == RKFD_JOINT_FLOAT ){ dofkind[R_dofoff[i]+3] = 1; dofkind[R_dofoff[i]+4] = 2; dofkind[R_dofoff[i]+5] = 2; }
@@ -357,10 +364,11 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   /* LDS bytes one instance needs (must match rkfd_lds_carve in rkfd_device.h) */
   {
     const size_t M = 3*(size_t)max_rigid;
-    size_t stage = (size_t)14*NL + (size_t)36*npool;            /* inertia staging + Ia pool ...   */
+    const size_t pool = (size_t)36*npool > (size_t)6*NL ? (size_t)36*npool : (size_t)6*NL;   /* Ia pool | second half of the world frames */
+    size_t stage = (size_t)14*NL + pool;                         /* inertia staging + Ia pool ...   */
     if( M*(M+1) > stage ) stage = M*(M+1);                       /* ... shared with the MLCP matrix */
-    const size_t dbl = (size_t)3*ND + (size_t)NL*( 7*6 + 4 ) + stage + (size_t)48*nfloat
-                     + (size_t)maxact*21 + (size_t)( NC <= RKFD_WAVE ? maxact : NC )*3 + 2*M + ( dm.pu_alias ? 0 : (size_t)nside*npurow*M );
+    const size_t dbl = (size_t)3*ND + (size_t)NL*( 5*6 + 4 ) + stage + (size_t)48*nfloat
+                     + (size_t)maxact*( 24 + ( NC > RKFD_WAVE ? 3 : 0 ) ) + 2*M + ( dm.pu_alias ? 0 : (size_t)nside*npurow*M );
     const size_t ints = (size_t)5*NC + (size_t)4*maxact + 8 + 3*(size_t)NL     /* act typ asl CIp CFO, lrg lel tgt, cnt, LI CHI PSL */
                       + ( max_rigid > 0 ? ( (size_t)NL*( nlevel+3 ) + 3 )/4 : 0 );   /* PL (bytes) */
     out->lds_bytes = dbl*sizeof(double) + ints*sizeof(int);

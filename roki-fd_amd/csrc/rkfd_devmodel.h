@@ -21,8 +21,7 @@ typedef struct {
   int nci;
   int solver, max_iter;
   int maxact;            /* capacity: active contact vertices (rigid + elastic) per instance        */
-  int ref_by_slot;       /* 1: stick anchors are stored per active-contact slot (ncand <= 64)          */
-  int pu_alias;          /* 1: the probe scratch PU fits in (and aliases) the V|C|PB|PA block           */
+  int pu_alias;          /* 1: the probe scratch PU fits in (and aliases) the C|PA block                */
   int npurow;            /* rows of PU per side: nlevel (+6 with a float joint)                         */
   int nside;             /* 1 when every rigid-capable pair has a static cell (probe walks one-sided) else 2 */
   int maxrg;             /* capacity: rigid contact vertices solved per instance (3*maxrg <= 128) */

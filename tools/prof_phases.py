@@ -3,8 +3,8 @@ import rkfd_pkg; R = rkfd_pkg.load()
 import numpy as np
 warm = int(os.environ.get('WARM','20'))
 for cfg in sys.argv[1:]:
-    sc = R.scenarios.CONFIGS[cfg](batch=4096)
-    b = R.Batch(sc['world'], 4096, max_rigid=sc['max_rigid'])
+    sc = R.scenarios.CONFIGS[cfg](batch=int(os.environ.get('BATCH','4096')))
+    b = R.Batch(sc['world'], int(os.environ.get('BATCH','4096')), max_rigid=sc['max_rigid'])
     b.set_state(sc['dis'], sc['vel']); b.update_init(); b.update(warm)
     p = b.profile(5).astype(np.float64)/5
     names=['kin','cd+pen','sweep2','sweep3','mlcp','tail','m:entries','launch total','s2:pre','s2:gather','s2:UD','s2:rank1','s2:store','s2:chol','m:tgt+b','m:probe-up','k:local','k:fkscan','k:axis','k:velscan','k:bias+friction','m:pgs','m:setforce','m:delta-in']
