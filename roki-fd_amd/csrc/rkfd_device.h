@@ -1167,6 +1167,51 @@ RKFD_DEV void rkfd_phase_bvel(const rkfdDevModel &m, const rkfdLds &L, double *b
   SYNC();
 }
 
+/* projected Gauss-Seidel for up to RKFD_PGS_NC contacts with the lane's three matrix rows held in
+ * registers (3 x 3*RKFD_PGS_NC doubles): the contact loop is unrolled, so the rows are indexed
+ * statically, the broadcasts read fixed lanes and the dependent path of an update is ALU only.
+ * Same arithmetic and update order as the general loop in rkfd_phase_mlcp. */
+#define RKFD_PGS_NC 4
+RKFD_DEV void rkfd_pgs_registers(const double *Arow, int ld, int nc, int max_iter, bool on, int lane, double mu,
+                                 double in_, double i1, double i2, double &rn, double &r1, double &r2, double &fn, double &f1, double &f2)
+{
+  double A0[3*RKFD_PGS_NC], A1[3*RKFD_PGS_NC], A2[3*RKFD_PGS_NC];
+#pragma unroll
+  for( int k=0; k<3*RKFD_PGS_NC; k++ ){
+    const bool in = on && k < 3*nc;
+    A0[k] = in ? Arow[k] : 0.0; A1[k] = in ? Arow[ld+k] : 0.0; A2[k] = in ? Arow[2*ld+k] : 0.0;
+  }
+  for( int it=0; it<max_iter; it++ ){
+#pragma unroll
+    for( int c=0; c<RKFD_PGS_NC; c++ ){
+      if( c < nc ){
+        double ff = fn - rn*in_;
+        if( ff < RKFD_DEV_TOL ) ff = 0.0;
+        const double dl = BCAST( ff - fn, c );
+        if( lane == c ) fn = ff;
+        rn = fma( A0[3*c], dl, rn ); r1 = fma( A1[3*c], dl, r1 ); r2 = fma( A2[3*c], dl, r2 );
+      }
+    }
+#pragma unroll
+    for( int c=0; c<RKFD_PGS_NC; c++ ){
+      if( c < nc ){
+        const double ff0 = f1 - r1*i1, ff1 = f2 - r2*i2;
+        const double fnorm = ff0*ff0 + ff1*ff1;
+        double fs = mu*fn; fs = fs*fs;
+        double n1, n2;
+        if( fnorm < RKFD_DEV_TOL || fs < RKFD_DEV_TOL ){ n1 = 0; n2 = 0; }
+        else if( fnorm > fs ){ const double sc = fs*RKFD_RCP( fnorm ); n1 = ff0*sc; n2 = ff1*sc; }
+        else { n1 = ff0; n2 = ff1; }
+        const double d1 = BCAST( n1 - f1, c ), d2 = BCAST( n2 - f2, c );
+        if( lane == c ){ f1 = n1; f2 = n2; }
+        rn = fma( A0[3*c+1], d1, fma( A0[3*c+2], d2, rn ) );
+        r1 = fma( A1[3*c+1], d1, fma( A1[3*c+2], d2, r1 ) );
+        r2 = fma( A2[3*c+1], d1, fma( A2[3*c+2], d2, r2 ) );
+      }
+    }
+  }
+}
+
 /* ------------------------------------------------------------------------ */
 /* MLCP rigid branch (reference src/rkfd_mlcp.c:287-297).  Preconditions: sweep 2 and sweep 3
  * have been run with the wrenches applied so far (rkFDUpdateAccBias), so AC holds the free
@@ -1388,7 +1433,8 @@ template<bool prof> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const r
       mu = L.typ[jr_] == RKFD_SF ? m.ci_sf[cir_] : m.ci_kf[cir_];
     }
     const double *Arow = &L.MA[r0*ld];
-    for( int it=0; it<m.max_iter; it++ ){
+    if( nc <= RKFD_PGS_NC ) rkfd_pgs_registers( Arow, ld, nc, m.max_iter, on, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
+    else for( int it=0; it<m.max_iter; it++ ){
       for( int c=0; c<nc; c++ ){
         /* normal force of contact c: f_n <- max( 0, -( b + a.f - a_nn f_n ) / a_nn ) */
         const double a0 = Arow[3*c], a1 = Arow[ld+3*c], a2 = Arow[2*ld+3*c];
