@@ -7,7 +7,9 @@ W=${1:-config4}; TAG=${2:-r01}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_${TAG}_${W}
 ARGS="bench.py --workload $W --steps 20 --warmup 5 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT.trace.log 2>&1
+# kernel trace + stats of the SAME command whose JSON line is reported (default steps / warmup), so that
+# the average kernel duration can be compared with bench.py's own HIP-event figure
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --workload $W > $OUT.bench.json 2> $OUT.trace.log
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ARGS > $OUT.fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ARGS > $OUT.write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $OUT/sq1 -- python3 $ARGS > $OUT.sq1.log 2>&1
