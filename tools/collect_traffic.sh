@@ -6,6 +6,7 @@ set -e
 W=${1:-config4}; TAG=${2:-r01}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_${TAG}_${W}
+rm -rf $OUT && mkdir -p $OUT
 ARGS="bench.py --workload $W --steps 20 --warmup 5 --no-cpu-baseline"
 # kernel trace + stats of the SAME command whose JSON line is reported (default steps / warmup), so that
 # the average kernel duration can be compared with bench.py's own HIP-event figure
