@@ -54,13 +54,43 @@ def cpu_baseline(R, name, seconds=10.0):
         o = Oracle(sc["world"].model)
         o.set_state(sc["dis"][inst % 4], sc["vel"][inst % 4])
         o.update_init()
-        for _ in range(200):
-            o.update()
+        o.update_n(200)
         nsteps += 200
         inst += 1
     dt = time.perf_counter() - t0
     return dict(value=nsteps / dt, unit="sim-steps/sec", cores=1, kind="port",
                 sample=f"{inst} instances x 200 steps of {name}, sequential on 1 core (oracle/rkfd_oracle.c, gcc -O3 -funroll-loops)")
+
+
+def cpu_baseline_all_cores(R, name, seconds=8.0):
+    """the same oracle on every host core this process may use: one OS thread per core over disjoint
+    instances (the reference itself is single-threaded; this is the generous baseline).
+    ctypes releases the GIL inside the C calls and the oracle keeps no global state."""
+    import threading
+    from oracle.pyoracle import Oracle
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    sc = R.scenarios.CONFIGS[name](batch=4)
+    done = [0] * cores
+    t0 = time.perf_counter()
+
+    def work(k):
+        inst = k
+        while time.perf_counter() - t0 < seconds:
+            o = Oracle(sc["world"].model)
+            o.set_state(sc["dis"][inst % 4], sc["vel"][inst % 4])
+            o.update_init()
+            o.update_n(200)
+            done[k] += 200
+            inst += cores
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(cores)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    return dict(value=sum(done) / dt, unit="sim-steps/sec", cores=cores, kind="port",
+                sample=f"{sum(done) // 200} instances x 200 steps of {name}, one thread per core on {cores} cores")
 
 
 def main():
@@ -149,6 +179,7 @@ def main():
         }
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(R, args.workload)
+            res["cpu_baseline_all_cores"] = cpu_baseline_all_cores(R, args.workload)
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

@@ -35,6 +35,7 @@ def lib():
         L.rkfdOracleSetPivot.argtypes = [vp, vp, vp]
         L.rkfdOracleUpdateInit.argtypes = [vp]
         L.rkfdOracleUpdate.argtypes = [vp]
+        L.rkfdOracleUpdateN.argtypes = [vp, C.c_int]
         L.rkfdOracleEval.argtypes = [vp, C.c_int]
         L.rkfdOracleGetLinkFrames.argtypes = [vp, vp, vp]
         L.rkfdOracleGetLinkVelAcc.argtypes = [vp, vp, vp]
@@ -105,6 +106,9 @@ class Oracle:
 
     def update_init(self):
         self._L.rkfdOracleUpdateInit(self._o)
+
+    def update_n(self, nsteps):
+        return self._L.rkfdOracleUpdateN(self._o, int(nsteps))
 
     def update(self):
         return self._L.rkfdOracleUpdate(self._o)

@@ -1054,3 +1054,11 @@ int rkfdOracleUpdate(rkfdOracle *o)
   r |= eval_ref( o );
   return r;
 }
+
+/* nsteps x rkFDUpdate (the driver loop of reference example/chain/boxdrop_test.c:49-54) */
+int rkfdOracleUpdateN(rkfdOracle *o, int nsteps)
+{
+  int r = 0, k;
+  for( k=0; k<nsteps; k++ ) r |= rkfdOracleUpdate( o );
+  return r;
+}

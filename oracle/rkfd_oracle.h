@@ -44,6 +44,8 @@ void rkfdOracleSetPivot(rkfdOracle *o, const int *type, const double *prev_trq);
 void rkfdOracleUpdateInit(rkfdOracle *o);
 /* rkFDUpdate (reference src/rkfd_sim.c:560-566): RKG stages + committing evaluation */
 int  rkfdOracleUpdate(rkfdOracle *o);
+/* nsteps x rkFDUpdate */
+int  rkfdOracleUpdateN(rkfdOracle *o, int nsteps);
 /* one dynamics evaluation at the current state: _rkFDUpdate / _rkFDUpdateRef
  * (reference src/rkfd_sim.c:533-549); result in acc */
 int  rkfdOracleEval(rkfdOracle *o, int doUpRef);
