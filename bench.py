@@ -42,6 +42,16 @@ def measured_traffic(workload, batch):
     return None
 
 
+def counted_flops(workload):
+    """algorithmic flops per instance-step from the flop-counting build of the oracle
+    (tools/count_flops.py -> profiles/r01_flops.json); None when not on file"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_flops.json")) as fp:
+            return json.load(fp)[workload]["flops_per_instance_step"]
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def cpu_baseline(R, name, seconds=10.0):
     """the oracle (CPU restatement, 'port') timed on one host core on a bounded sample"""
     import numpy as np
@@ -177,6 +187,12 @@ def main():
                          "kernel": "rkfd_step_kernel", "kernel_ms": kernel_ms, "alg_bytes_per_instance_step": alg},
             "device_status": st,
         }
+        fl = counted_flops(args.workload)
+        if fl is not None:
+            # second axis SURVEY 8d asks for: fp64 vector throughput (dense peak 78.6 TFLOP/s, MI355X_MICROARCH.md)
+            tf = fl * Bn / (kernel_ms * 1e-3) / 1e12
+            res["roofline_valu"] = {"bound": "valu_fp64", "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6,
+                                    "alg_flops_per_instance_step": fl}
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(R, args.workload)
             res["cpu_baseline_all_cores"] = cpu_baseline_all_cores(R, args.workload)

@@ -207,3 +207,33 @@ def test_dc_motor_friction_truth_table(R, oracle_cls):
     o.set_motor_input(inp); o.eval(True)
     typ2, _ = o.get_pivot()
     assert typ2[1] == 1 and abs(o.get_state()[2][6]) > 1.0
+
+
+def test_flop_counting_build_matches_the_plain_oracle(R):
+    """oracle/flopcount.cpp compiles the oracle source with a counting number type: same results bit for
+    bit, and a flop count per step of the order SURVEY 8d estimates (~0.1 Mflop for one ABA-only step)"""
+    import ctypes as C
+    import os
+    import subprocess
+    import oracle.pyoracle as po
+    root = os.path.join(os.path.dirname(__file__), "..")
+    subprocess.run(["make", "-C", os.path.join(root, "oracle"), "count"], check=True, stdout=subprocess.DEVNULL)
+    sc = R.scenarios.config4(batch=1)
+    plain = po.Oracle(sc["world"].model)
+    plain.set_state(sc["dis"][0], sc["vel"][0]); plain.update_init(); plain.update_n(5)
+    Lc = C.CDLL(os.path.join(root, "oracle", "_build", "librkfd_oracle_count.so"))
+    vp = C.c_void_p
+    Lc.rkfdOracleCreate.argtypes = [vp]; Lc.rkfdOracleCreate.restype = vp
+    Lc.rkfdOracleSetState.argtypes = [vp, vp, vp]; Lc.rkfdOracleGetState.argtypes = [vp, vp, vp, vp]
+    Lc.rkfdOracleUpdateInit.argtypes = [vp]; Lc.rkfdOracleUpdateN.argtypes = [vp, C.c_int]; Lc.rkfdOracleDestroy.argtypes = [vp]
+    Lc.rkfdOracleFlops.restype = C.c_ulonglong
+    o = Lc.rkfdOracleCreate(C.cast(sc["world"].model, vp))
+    d = np.ascontiguousarray(sc["dis"][0]); v = np.ascontiguousarray(sc["vel"][0])
+    Lc.rkfdOracleSetState(o, d.ctypes.data, v.ctypes.data); Lc.rkfdOracleUpdateInit(o)
+    Lc.rkfdOracleFlopsReset(); Lc.rkfdOracleUpdateN(o, 5)
+    flops = Lc.rkfdOracleFlops() / 5
+    acc = np.empty_like(d); dis = np.empty_like(d); vel = np.empty_like(d)
+    Lc.rkfdOracleGetState(o, dis.ctypes.data, vel.ctypes.data, acc.ctypes.data); Lc.rkfdOracleDestroy(o)
+    pd, pv, pa = plain.get_state()
+    assert np.array_equal(dis, pd) and np.array_equal(acc, pa)
+    assert 1e5 < flops < 2e6
