@@ -27,6 +27,7 @@ typedef struct { int size; double *buf; } zVecStruct;
 typedef zVecStruct *zVec;
 zVec zVecAlloc(int size);
 void zVecFree(zVec v);
+double zRandF(double min, double max);
 void zVecFPrint(FILE *fp, zVec v);
 #define zVecSize(v)      ( (v)->size )
 #define zVecSizeNC(v)    ( (v)->size )
@@ -133,7 +134,12 @@ typedef struct _rkFD {
 
 rkFD *rkFDCreate(rkFD *fd);
 void rkFDDestroy(rkFD *fd);
+/* reference include/roki_fd/rkfd_sim.h:61-63.  rkFDChainReg registers a CLONE of `chain`; chains exist
+ * here only as the views of registered cells (rkFDCellChain), of this or another rkFD.  Packed-state
+ * pointers are invalidated by (un)registration, as in the reference (src/rkfd_sim.c:72-110). */
+rkFDCell *rkFDChainReg(rkFD *fd, rkChain *chain);
 rkFDCell *rkFDChainRegFile(rkFD *fd, char filename[]);
+bool rkFDChainUnreg(rkFD *fd, rkFDCell *cell);
 void rkFDChainSetDis(rkFDCell *lc, zVec dis);
 void rkFDChainSetVel(rkFDCell *lc, zVec vel);
 bool rkFDContactInfoScanFile(rkFD *fd, char filename[]);

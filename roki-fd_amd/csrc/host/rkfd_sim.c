@@ -31,6 +31,8 @@ zVec zVecAlloc(int size)
   return v;
 }
 void zVecFree(zVec v){ if( v ){ free( v->buf ); free( v ); } }
+/* uniform random number in [min,max] (ZM's zRandF, used by reference example/chain/boxdrop_test.c:30-32) */
+double zRandF(double min, double max){ return min + ( max - min )*( (double)rand()/(double)RAND_MAX ); }
 void zVecFPrint(FILE *fp, zVec v)
 {
   int i;
@@ -177,15 +179,14 @@ void rkFDDestroy(rkFD *fd)
   memset( fd, 0, sizeof(rkFD) );
 }
 
-rkFDCell *rkFDChainRegFile(rkFD *fd, char filename[])
+/* _rkFDCellPush (reference src/rkfd_sim.c:188-209): takes ownership of cd */
+static rkFDCell *cell_push(rkFD *fd, rkfdChainDesc *cd)
 {
   rkFDImpl *im = IMPL( fd );
-  rkfdChainDesc *cd;
   rkFDCell *lc, **tail;
   zVec nd, nv, na;
   int id, i;
 
-  if( !( cd = rkfdChainReadZTK( filename ) ) ) return NULL;
   if( !( lc = (rkFDCell *)calloc( 1, sizeof(rkFDCell) ) ) ){ rkfdChainDescFree( cd ); return NULL; }
   lc->chain.link_off = rkfdWorldChainLinkOffset( &im->world, im->world.nchain );
   lc->chain.dof_off  = rkfdWorldChainDofOffset( &im->world, im->world.nchain );
@@ -209,6 +210,61 @@ rkFDCell *rkFDChainRegFile(rkFD *fd, char filename[])
   for( i=0; i<cd->nlink; i++ ) im->motor_in[lc->chain.link_off+i] = 0.0;
   im->dirty = 1; im->ncell++;
   return lc;
+}
+
+rkFDCell *rkFDChainRegFile(rkFD *fd, char filename[])
+{
+  rkfdChainDesc *cd;
+  if( !( cd = rkfdChainReadZTK( filename ) ) ) return NULL;
+  return cell_push( fd, cd );
+}
+
+/* registers a CLONE of a chain (reference src/rkfd_sim.c:211-222).  Chains exist here only as the
+ * views of registered cells, so the argument is the chain of a cell of this or another rkFD. */
+rkFDCell *rkFDChainReg(rkFD *fd, rkChain *chain)
+{
+  rkfdChainDesc *cd;
+  if( !chain || !chain->fd ) return NULL;
+  if( !( cd = rkfdChainDescClone( IMPL( chain->fd )->world.chain[chain->id] ) ) ) return NULL;
+  return cell_push( fd, cd );
+}
+
+/* reference src/rkfd_sim.c:237-255: the cell leaves the list, the packed state shrinks
+ * (_rkFDAllocJointStatePop :112-140) and its shapes leave the collision registry.  As in the
+ * reference, not between rkFDUpdateInit and rkFDUpdateDestroy. */
+bool rkFDChainUnreg(rkFD *fd, rkFDCell *cell)
+{
+  rkFDImpl *im = IMPL( fd );
+  rkFDCell **pp, *lc, *c;
+  int nd, nl, k;
+
+  for( pp=&fd->list; *pp && *pp != cell; pp=&(*pp)->next );
+  if( !( lc = *pp ) ) return false;
+  nd = lc->chain.ndof; nl = lc->chain.nlink;
+  if( fd->size - nd > 0 ){
+    zVec d2 = zVecAlloc( fd->size - nd ), v2 = zVecAlloc( fd->size - nd ), a2 = zVecAlloc( fd->size - nd );
+    if( !d2 || !v2 || !a2 ){ zVecFree( d2 ); zVecFree( v2 ); zVecFree( a2 ); rkFDDestroy( fd ); return false; }
+    memcpy( d2->buf, fd->dis->buf, sizeof(double)*lc->chain.dof_off );
+    memcpy( v2->buf, fd->vel->buf, sizeof(double)*lc->chain.dof_off );
+    k = fd->size - lc->chain.dof_off - nd;
+    memcpy( d2->buf + lc->chain.dof_off, fd->dis->buf + lc->chain.dof_off + nd, sizeof(double)*k );
+    memcpy( v2->buf + lc->chain.dof_off, fd->vel->buf + lc->chain.dof_off + nd, sizeof(double)*k );
+    zVecFree( fd->dis ); zVecFree( fd->vel ); zVecFree( fd->acc );
+    fd->dis = d2; fd->vel = v2; fd->acc = a2;
+  } else {
+    zVecFree( fd->dis ); zVecFree( fd->vel ); zVecFree( fd->acc );
+    fd->dis = fd->vel = fd->acc = NULL;
+  }
+  fd->size -= nd;
+  k = rkfdWorldChainLinkOffset( &im->world, im->world.nchain ) - lc->chain.link_off - nl;
+  memmove( im->motor_in + lc->chain.link_off, im->motor_in + lc->chain.link_off + nl, sizeof(double)*k );
+  for( c=lc->next; c; c=c->next ){ c->chain.id--; c->chain.link_off -= nl; c->chain.dof_off -= nd; }
+  *pp = lc->next;
+  rkfdWorldRemoveChain( &im->world, lc->chain.id );
+  free( lc->chain.joint ); free( lc );
+  if( im->batch ){ rkfdBatchDestroy( im->batch ); im->batch = NULL; }
+  im->dirty = 1; im->ncell--;
+  return true;
 }
 
 void rkFDChainSetDis(rkFDCell *lc, zVec dis)

@@ -46,6 +46,28 @@ int rkfdWorldAddChain(rkfdWorld *w, rkfdChainDesc *c)
   return n;
 }
 
+void rkfdWorldRemoveChain(rkfdWorld *w, int chain)
+{
+  int n = w->nchain, i, j, ii, jj;
+  unsigned char *np;
+  if( chain < 0 || chain >= n ) return;
+  rkfdChainDescFree( w->chain[chain] );
+  for( i=chain; i<n-1; i++ ) w->chain[i] = w->chain[i+1];
+  /* the no-pair matrix loses row and column `chain` (in place: entries only move towards the front) */
+  np = w->nopair;
+  for( i=0, ii=0; i<n; i++ ){
+    if( i == chain ) continue;
+    for( j=0, jj=0; j<n; j++ ){
+      if( j == chain ) continue;
+      np[ii*(n-1)+jj] = np[i*n+j];
+      jj++;
+    }
+    ii++;
+  }
+  w->nchain = n-1;
+  w->built = 0;
+}
+
 void rkfdWorldPairChainUnreg(rkfdWorld *w, int chain)
 {
   int j, n = w->nchain;

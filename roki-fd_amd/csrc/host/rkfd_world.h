@@ -26,6 +26,8 @@ void rkfdWorldInit(rkfdWorld *w);
 void rkfdWorldDestroy(rkfdWorld *w);
 /* takes ownership of c; returns chain id or -1 */
 int  rkfdWorldAddChain(rkfdWorld *w, rkfdChainDesc *c);
+/* remove chain id (rkCDChainUnreg + cell removal, reference src/rkfd_sim.c:237-255); later chains move down by one */
+void rkfdWorldRemoveChain(rkfdWorld *w, int chain);
 /* drop every collision pair that involves chain id and a chain registered so far
  * (rkCDPairChainUnreg as used in reference example/chain/boxdrop_test.c:37) */
 void rkfdWorldPairChainUnreg(rkfdWorld *w, int chain);

@@ -486,3 +486,32 @@ int rkfdContactInfoReadZTK(const char *filename, rkfdContactInfo **out)
   *out = ci;
   return n;
 }
+
+static void *dup_mem(const void *p, size_t n)
+{
+  void *q;
+  if( !p || n == 0 ) return NULL;
+  if( ( q = malloc( n ) ) ) memcpy( q, p, n );
+  return q;
+}
+
+rkfdChainDesc *rkfdChainDescClone(const rkfdChainDesc *c)
+{
+  rkfdChainDesc *d;
+  int i;
+  if( !c || !( d = (rkfdChainDesc *)calloc( 1, sizeof(rkfdChainDesc) ) ) ) return NULL;
+  *d = *c;
+  d->link = (rkfdLinkDesc *)dup_mem( c->link, sizeof(rkfdLinkDesc)*c->nlink );
+  d->motor = (rkfdMotor *)dup_mem( c->motor, sizeof(rkfdMotor)*c->nmotor );
+  d->init_dis = (double *)dup_mem( c->init_dis, sizeof(double)*c->ndof );
+  d->shape = (rkfdShape *)dup_mem( c->shape, sizeof(rkfdShape)*c->nshape );
+  for( i=0; d->shape && i<c->nshape; i++ ){
+    d->shape[i].vert = (double *)dup_mem( c->shape[i].vert, sizeof(double)*3*c->shape[i].nvert );
+    d->shape[i].plane = (double *)dup_mem( c->shape[i].plane, sizeof(double)*4*c->shape[i].nplane );
+  }
+  if( ( c->nlink && !d->link ) || ( c->nmotor && !d->motor ) || ( c->nshape && !d->shape ) || ( c->ndof && !d->init_dis ) ){
+    rkfdChainDescFree( d );
+    return NULL;
+  }
+  return d;
+}

@@ -70,6 +70,8 @@ typedef struct {
 /* returns NULL on failure (message on stderr), like rkChainReadZTK */
 rkfdChainDesc *rkfdChainReadZTK(const char *filename);
 void rkfdChainDescFree(rkfdChainDesc *c);
+/* deep copy (the role of rkChainClone in reference src/rkfd_sim.c:217); NULL on allocation failure */
+rkfdChainDesc *rkfdChainDescClone(const rkfdChainDesc *c);
 
 /* returns number of entries read (>=0) or -1 on failure; *out is malloc'ed */
 int rkfdContactInfoReadZTK(const char *filename, rkfdContactInfo **out);

@@ -54,3 +54,18 @@ def test_unknown_file_fails_loudly(R):
     except R.RkfdError:
         return
     raise AssertionError("expected RkfdError")
+
+
+def test_chain_reg_clone_unreg_in_c(R, tmp_path):
+    """rkFDChainReg (clone) and rkFDChainUnreg keep the packed state and the cell offsets consistent
+    (reference src/rkfd_sim.c:72-140,211-255); C program against include/roki_fd_amd.h, no GPU calls"""
+    import subprocess
+    root = os.path.join(os.path.dirname(__file__), "..")
+    exe = str(tmp_path / "reg_unreg")
+    subprocess.run(["gcc", "-O1", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "c", "reg_unreg.c"),
+                    "-L" + os.path.join(root, "roki-fd_amd"), "-lrkfd_amd", "-Wl,-rpath," + os.path.join(root, "roki-fd_amd"), "-o", exe], check=True)
+    out = subprocess.run([exe, os.path.join(root, "models")], check=True, capture_output=True, text=True).stdout.splitlines()
+    assert out[0] == "size 36"                                            # box 6 + chain 30 + floor 0
+    assert out[1] == "after clone size 42 chain ids 0 1 2 3"
+    assert out[2] == "after unreg size 36 ids 0 1 2 dofoff 0 30 30  q[3]=0.25"   # the chain's joint value moved with it
+    assert out[3] == "model nlink 33 ndof 36 ncand 16"                    # chain 31 + floor 1 + cloned box 1; box x floor candidates
