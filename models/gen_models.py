@@ -181,6 +181,37 @@ def chain30():
     return s
 
 
+def arm(name, root_joint):
+    """SYNTHETIC test model: a 4-joint arm (yaw, shoulder pitch, telescopic forearm, wrist roll) with a
+    box-shaped hand.  root_joint = 'fixed': a static pedestal carries the yaw joint; 'revolute': the yaw
+    link is the root itself.  Exercises prismatic joints, both motor types, joint friction and contact
+    paths that end at a fixed / 1-DoF root."""
+    inertia = "inertia : {\n 1e-2, 0, 0\n 0, 1e-2, 0\n 0, 0, 1e-2\n}\n"
+    s = f"[roki::chain]\nname : {name}\n\n"
+    s += "[zeo::shape]\ntype : box\nname : hand\ncenter : 0, 0, 0.1\ndepth : 0.08\nwidth : 0.08\nheight : 0.08\n\n"
+    s += ("[roki::motor]\nname : dcm\ntype: dc\nmotorconstant : 2.53e-2\nadmittance : 0.045872\nmaxvoltage : 24.0\nminvoltage : -24.0\n"
+          "gearratio : 100.0\nrotorinertia : 2.97e-7\ngearinertia : 3.0e-7\n\n")
+    s += "[roki::motor]\nname : trqm\ntype: trq\nmax : 20.0\nmin : -20.0\n\n"
+    base = " 1, 0, 0, 0\n 0, 1, 0, 0\n 0, 0, 1, 0.4\n"
+    if root_joint == "fixed":
+        s += "[roki::link]\nname : pedestal\njointtype : fixed\nmass : 5.0\nstuff : body\n" + inertia + "frame : {\n" + base + "}\n\n"
+        s += "[roki::link]\nname : yaw\njointtype : revolute\nmass : 1.0\nstuff : body\nCOM : { 0, 0, 0.02 }\n" + inertia
+        s += "motor : dcm\nstiffness: 0.0\nviscosity: 0.0\ncoulomb: 1.0\nstaticfriction: 1.2\nparent : pedestal\n\n"
+    else:
+        s += "[roki::link]\nname : yaw\njointtype : revolute\nmass : 1.0\nstuff : body\nCOM : { 0, 0, 0.02 }\n" + inertia
+        s += "motor : dcm\nstiffness: 0.0\nviscosity: 0.0\ncoulomb: 1.0\nstaticfriction: 1.2\nframe : {\n" + base + "}\n\n"
+    # shoulder pitch: local z = parent's y
+    s += "[roki::link]\nname : shoulder\njointtype : revolute\nmass : 1.5\nstuff : body\nCOM : { 0.15, 0, 0 }\n" + inertia
+    s += "motor : trqm\nframe : {\n 1, 0, 0, 0\n 0, 0, 1, 0\n 0, -1, 0, 0\n}\nparent : yaw\n\n"
+    # telescopic forearm: local z = parent's x
+    s += "[roki::link]\nname : forearm\njointtype : prismatic\nmass : 0.8\nstuff : body\nCOM : { 0, 0, 0.1 }\n" + inertia
+    s += "frame : {\n 0, 0, 1, 0.3\n 0, 1, 0, 0\n -1, 0, 0, 0\n}\nparent : shoulder\n\n"
+    s += "[roki::link]\nname : wrist\njointtype : revolute\nmass : 0.4\nstuff : body\nCOM : { 0, 0, 0.1 }\n"
+    s += "inertia : {\n 1e-3, 0, 0\n 0, 1e-3, 0\n 0, 0, 1e-3\n}\n"
+    s += "frame : {\n 1, 0, 0, 0\n 0, 1, 0, 0\n 0, 0, 1, 0.2\n}\nparent : forearm\nshape : hand\n\n"
+    return s
+
+
 def humanoid(ref_root):
     src = os.path.join(ref_root, "example", "model", "mighty.ztk")
     text = open(src).read()
@@ -251,6 +282,8 @@ def main():
     w("contact_elastic.ztk", contact([dict(bind="ground body", sf=0.5, kf=0.3, e=1000.0, v=10.0)]))
     w("contact_rigid.ztk", contact([dict(bind="ground body", sf=0.5, kf=0.3, k=1000.0, l=0.0001)]))
     w("chain30.ztk", chain30())
+    w("arm_fixedroot.ztk", arm("arm_fixedroot", "fixed"))
+    w("arm_revroot.ztk", arm("arm_revroot", "revolute"))
     ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
     if os.path.isdir(ref):
         humanoid(ref)

@@ -83,7 +83,12 @@ def _rot_aa(aa):
 
 
 def lowest_vertex_z(m, q, chain):
-    """height of the lowest collision vertex of `chain` at joint displacement q (plain forward
+    """height of the lowest collision vertex of `chain` at joint displacement q"""
+    return chain_vertices(m, q, chain)[:, 2].min()
+
+
+def chain_vertices(m, q, chain):
+    """world positions of the collision vertices of `chain` at joint displacement q (plain forward
     kinematics on the flattened model; scenario set-up only)"""
     nl = m.nlink
     parent, jt, off = m.arr("parent", nl), m.arr("jtype", nl), m.arr("dofoff", nl)
@@ -104,13 +109,13 @@ def lowest_vertex_z(m, q, chain):
             R[i] = Rp @ Ro; p[i] = pp + Rp @ po
     voff = m.arr("shape_voff", m.nshape + 1); slink = m.arr("shape_link", m.nshape)
     verts = m.arr("verts", 3 * voff[-1]).reshape(-1, 3)
-    z = np.inf
+    out = [np.zeros((0, 3))]
     for sh in range(m.nshape):
         l = slink[sh]
         if ch[l] != chain:
             continue
-        z = min(z, (p[l] + verts[voff[sh]:voff[sh + 1]] @ R[l].T)[:, 2].min())
-    return z
+        out.append(p[l] + verts[voff[sh]:voff[sh + 1]] @ R[l].T)
+    return np.concatenate(out)
 
 
 SEAT_DEPTH = 0.0005
@@ -182,6 +187,47 @@ def config5(batch=4096, max_rigid=24):
         dis[b, ho + 2] -= lowest_vertex_z(m, dis[b], h) + SEAT_DEPTH
     vel = np.zeros_like(dis)
     return dict(name="config5_humanoid_clutter_mlcp", world=w, dis=dis, vel=vel, max_rigid=max_rigid, steps=1000)
+
+
+def arm_press(batch=8, root="fixed", with_box=True, seed=0x5EED00A1):
+    """TEST scenario (not one of BASELINE's configs): a 4-joint arm (yaw with DC motor and joint friction,
+    shoulder pitch with torque motor, telescopic forearm, wrist roll) presses its box-shaped hand onto a
+    free box lying on the rigid floor (or onto the floor itself), MLCP plugin.  Contact paths end at a
+    fixed root / at a 1-DoF root, one rigid pair has two moving sides, joints are prismatic as well as
+    revolute, motor inputs are non-zero - the branches the humanoid workloads do not take."""
+    w = B.World(solver=B.SOLVER_MLCP)
+    w.contact_info(_m("contactinfo.ztk"))
+    a = w.reg_file(_m("arm_fixedroot.ztk" if root == "fixed" else "arm_revroot.ztk"))
+    bx = w.reg_file(_m("box.ztk")) if with_box else None
+    w.reg_file(_m("floor.ztk"))
+    m = w.model.contents
+    u = splitmix64_uniform(seed, batch * 8).reshape(batch, 8)
+    dis = np.zeros((batch, m.ndof)); vel = np.zeros((batch, m.ndof))
+    inp = np.zeros((batch, m.nlink))
+    ao = w.dof_offset(a)
+    top = 0.1 if with_box else 0.0                       # what the hand rests on
+    for b in range(batch):
+        q = np.zeros(m.ndof)
+        q[ao + 0] = (u[b, 0] - 0.5) * 0.6                # yaw
+        q[ao + 2] = u[b, 1] * 0.05                       # forearm extension
+        q[ao + 3] = (u[b, 2] - 0.5) * 0.4                # wrist roll
+        lo, hi = 0.0, 1.2                                # shoulder pitch by bisection: lowest hand vertex SEAT_DEPTH inside
+        for _ in range(60):
+            q[ao + 1] = 0.5 * (lo + hi)
+            if lowest_vertex_z(m, q, a) > top - SEAT_DEPTH:
+                lo = q[ao + 1]
+            else:
+                hi = q[ao + 1]
+        if with_box:
+            v = chain_vertices(m, q, a)
+            c = v[np.argsort(v[:, 2])[:4]].mean(axis=0)  # under the lowest face of the hand
+            o = w.dof_offset(bx)
+            q[o:o + 3] = (c[0], c[1], 0.05 - SEAT_DEPTH)
+        dis[b] = q
+        vel[b, ao:ao + 4] = (u[b, 3:7] - 0.5) * 0.2
+        inp[b, w.link_offset(a) + (1 if root == "fixed" else 0)] = (u[b, 7] - 0.5) * 20.0     # yaw motor voltage
+        inp[b, w.link_offset(a) + (2 if root == "fixed" else 1)] = 2.0                         # shoulder torque, pressing down
+    return dict(name=f"arm_press_{root}{'_box' if with_box else ''}", world=w, dis=dis, vel=vel, motor_in=inp, max_rigid=12, steps=200)
 
 
 CONFIGS = {"config1": config1, "config1b": config1_rigid, "config2": config2, "config3": config3, "config4": config4, "config5": config5}

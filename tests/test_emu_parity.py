@@ -39,3 +39,27 @@ def test_contact_capacity_overflow_is_reported(R):
     eb.set_state(dis, sc["vel"])
     eb.update_init()
     assert eb.status() == 2
+
+
+@pytest.mark.parametrize("root,with_box", [("fixed", True), ("revolute", True), ("fixed", False)])
+def test_emulated_arm_press_matches_oracle(R, oracle_cls, root, with_box):
+    """contact paths that end at a fixed root / a 1-DoF root, a rigid pair with two moving sides, prismatic
+    joint, DC and torque motors with non-zero inputs (scenarios.arm_press)"""
+    B, nsteps = 2, 4
+    sc = R.scenarios.arm_press(batch=B, root=root, with_box=with_box)
+    eb = EmuBatch(sc["world"], B, max_rigid=sc["max_rigid"])
+    eb.set_state(sc["dis"], sc["vel"]); eb.set_motor_input(sc["motor_in"])
+    eb.update_init(); eb.update(nsteps)
+    assert eb.status() == 0
+    dis, vel, acc = eb.get_state()
+    act, typ, ref, f = eb.get_contact()
+    for i in range(B):
+        o = oracle_cls(sc["world"].model)
+        o.set_state(sc["dis"][i], sc["vel"][i]); o.set_motor_input(sc["motor_in"][i]); o.update_init()
+        o.update_n(nsteps)
+        od, ov, oa = o.get_state()
+        for x, y in ((dis[i], od), (vel[i], ov), (acc[i], oa)):
+            assert np.abs(x - y).max() / max(1.0, np.abs(y).max()) < 1e-9
+        oact, otyp, oref, of = o.get_contact()
+        assert (act[i] == oact).all()
+        assert np.abs(f[i] - of).max() / max(1.0, np.abs(of).max()) < 1e-9

@@ -131,3 +131,30 @@ def test_limits_are_reported(R):
     sc = R.scenarios.config4(batch=1)
     with pytest.raises(R.RkfdError, match="exceeds"):
         R.Batch(sc["world"], 1, max_rigid=50)
+
+
+@pytest.mark.parametrize("root,with_box", [("fixed", True), ("revolute", True), ("fixed", False)])
+def test_arm_press_paths(R, oracle_cls, root, with_box):
+    """MLCP branches the humanoid workloads do not take: contact paths ending at a fixed / 1-DoF root, a
+    rigid pair with two moving sides (hand on a free box), prismatic joint, both motor types driven"""
+    B, nsteps = 8, 30
+    sc = R.scenarios.arm_press(batch=B, root=root, with_box=with_box)
+    b = R.Batch(sc["world"], B, max_rigid=sc["max_rigid"])
+    b.set_state(sc["dis"], sc["vel"]); b.set_motor_input(sc["motor_in"])
+    b.update_init(); b.update(nsteps)
+    assert b.status() == 0
+    dis, vel, acc = b.get_state()
+    act, typ, ref, f = b.get_contact()
+    seen = 0
+    for i in range(B):
+        o = oracle_cls(sc["world"].model)
+        o.set_state(sc["dis"][i], sc["vel"][i]); o.set_motor_input(sc["motor_in"][i]); o.update_init()
+        o.update_n(nsteps)
+        od, ov, oa = o.get_state()
+        assert _rel(dis[i], od) < RTOL and _rel(vel[i], ov) < RTOL and _rel(acc[i], oa) < 1e-8
+        oact, otyp, oref, of = o.get_contact()
+        assert (act[i] == oact).all()
+        assert _rel(f[i], of * (oact[:, None] != 0)) < 1e-8
+        seen += int(oact.sum())
+    if with_box:
+        assert seen > 0
