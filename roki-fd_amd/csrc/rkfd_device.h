@@ -1648,7 +1648,7 @@ template<bool prof> RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkf
       L.CIp[j] = m.cinfo[j];
       L.CFO[j] = m.cand_foff[j];
       a = st.cv_active[(size_t)b*NC+j];
-      L.typ[j] = st.cv_type[(size_t)b*NC+j];
+      L.typ[j] = a ? st.cv_type[(size_t)b*NC+j] : 0;
     }
     /* slots of the contacts alive at launch (candidate order; re-assigned by every collision pass) */
     const unsigned long long ma = BALLOT( a != 0 );
@@ -1728,13 +1728,19 @@ template<bool prof> RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkf
     st.piv_type[(size_t)b*m.nlink_model+lm] = ll.pivt;
     st.piv_prev[(size_t)b*m.nlink_model+lm] = ll.pivp;
   }
+  /* contact state: the flag of every candidate, the rest only for those in contact (a candidate out of
+   * contact has no state: type and anchor are re-initialised at its next first contact, and the
+   * boundary reports zeros for it) */
   for( int j=lane; j<NC; j+=RKFD_WAVE ){
-    st.cv_active[(size_t)b*NC+j] = L.act[j];
-    st.cv_type[(size_t)b*NC+j] = L.typ[j];
+    const int a = L.act[j];
+    st.cv_active[(size_t)b*NC+j] = a;
+    if( a ){
+      st.cv_type[(size_t)b*NC+j] = L.typ[j];
 #pragma unroll
-    for( int k=0; k<3; k++ ){
-      if( L.act[j] ) st.cv_ref[((size_t)b*NC+j)*3+k] = L.REF[3*RIDX( j )+k];
-      st.cv_f[((size_t)b*NC+j)*3+k] = L.act[j] ? L.CF[3*L.asl[j]+k] : 0.0;
+      for( int k=0; k<3; k++ ){
+        st.cv_ref[((size_t)b*NC+j)*3+k] = L.REF[3*RIDX( j )+k];
+        st.cv_f[((size_t)b*NC+j)*3+k] = L.CF[3*L.asl[j]+k];
+      }
     }
   }
   if( st.dbg ){

@@ -67,7 +67,9 @@ class EmuBatch:
 
     def get_contact(self):
         n = self.ncand
-        return self.cv_active[:, :n].copy(), self.cv_type[:, :n].copy(), self.cv_ref[:, :n].copy(), self.cv_f[:, :n].copy()
+        # like rkfdBatchGetContact: a candidate out of contact has no state, report zeros
+        act = self.cv_active[:, :n].copy(); on = act != 0
+        return act, self.cv_type[:, :n] * on, self.cv_ref[:, :n] * on[:, :, None], self.cv_f[:, :n] * on[:, :, None]
 
     def get_pivot(self):
         return self.piv_type.copy(), self.piv_prev.copy()
