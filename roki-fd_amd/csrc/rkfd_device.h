@@ -1198,10 +1198,14 @@ RKFD_DEV void rkfd_pgs_registers(const double *Arow, int ld, int nc, int max_ite
         const double ff0 = f1 - r1*i1, ff1 = f2 - r2*i2;
         const double fnorm = ff0*ff0 + ff1*ff1;
         double fs = mu*fn; fs = fs*fs;
-        double n1, n2;
-        if( fnorm < RKFD_DEV_TOL || fs < RKFD_DEV_TOL ){ n1 = 0; n2 = 0; }
-        else if( fnorm > fs ){ const double sc = fs*RKFD_RCP( fnorm ); n1 = ff0*sc; n2 = ff1*sc; }
-        else { n1 = ff0; n2 = ff1; }
+        /* only the decision of lane c matters: branch on it wave-uniformly, so that the reciprocal
+         * is evaluated only when contact c really slides */
+        const bool zero = fnorm < RKFD_DEV_TOL || fs < RKFD_DEV_TOL;
+        double n1 = zero ? 0.0 : ff0, n2 = zero ? 0.0 : ff1;
+        if( ( BALLOT( !zero && fnorm > fs ) >> c ) & 1ull ){
+          const double sc = fs*RKFD_RCP( fnorm );
+          n1 = ff0*sc; n2 = ff1*sc;
+        }
         const double d1 = BCAST( n1 - f1, c ), d2 = BCAST( n2 - f2, c );
         if( lane == c ){ f1 = n1; f2 = n2; }
         rn = fma( A0[3*c+1], d1, fma( A0[3*c+2], d2, rn ) );
