@@ -22,10 +22,10 @@ $(BUILD):
 $(BUILD)/%.o: $(CSRC)/host/%.c include/*.h $(CSRC)/host/*.h | $(BUILD)
 	$(CC) $(CFLAGS) -c $< -o $@
 
-$(BUILD)/rkfd_devmodel.o: $(CSRC)/rkfd_devmodel.cpp $(CSRC)/*.h include/*.h | $(BUILD)
+$(BUILD)/rkfd_devmodel.o: $(CSRC)/rkfd_devmodel.cpp $(CSRC)/*.h $(CSRC)/device/*.h include/*.h | $(BUILD)
 	$(CXX) -std=c++17 $(CFLAGS) -c $< -o $@
 
-$(BUILD)/rkfd_capi.o: $(CSRC)/rkfd_capi.hip $(CSRC)/*.h include/*.h | $(BUILD)
+$(BUILD)/rkfd_capi.o: $(CSRC)/rkfd_capi.hip $(CSRC)/*.h $(CSRC)/device/*.h include/*.h | $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIB): $(HOST_OBJS) $(BUILD)/rkfd_capi.o
@@ -36,7 +36,7 @@ oracle:
 
 emu: tests/emu/librkfd_emu.so
 
-tests/emu/librkfd_emu.so: tests/emu/rkfd_emu.cpp $(CSRC)/rkfd_device.h $(CSRC)/rkfd_devmodel.cpp $(CSRC)/*.h include/*.h
+tests/emu/librkfd_emu.so: tests/emu/rkfd_emu.cpp $(CSRC)/rkfd_device.h $(CSRC)/rkfd_devmodel.cpp $(CSRC)/*.h $(CSRC)/device/*.h include/*.h
 	$(CXX) -std=c++20 -O2 -Wall -Wno-unknown-pragmas -fPIC -shared -pthread $(INC) -o $@ tests/emu/rkfd_emu.cpp $(CSRC)/rkfd_devmodel.cpp
 
 clean:

@@ -1,0 +1,360 @@
+/* rkfd_dev_base.h - part of the device code of the batched rkFDUpdate step (see rkfd_device.h):
+ * platform macros (HIP / lane emulator), cross-lane helpers, small vector algebra, the LDS carve-up.
+ * Included by rkfd_device.h only, in this order; compiles for gfx950 and under the lane emulator. */
+#ifndef RKFD_DEV_BASE_H
+#define RKFD_DEV_BASE_H
+
+#ifdef RKFD_EMU
+#  define RKFD_DEV static inline
+   int    rkfd_emu_lane(void);
+   void   rkfd_emu_sync(void);
+   double rkfd_emu_g8sum(double x);
+   double rkfd_emu_bcast(double x, int src);
+   unsigned long long rkfd_emu_ballot(int pred);
+#  define LANE()        rkfd_emu_lane()
+#  define SYNC()        rkfd_emu_sync()
+   double rkfd_emu_g8bcast(double x, int k);
+#  define G8SUM(x)      rkfd_emu_g8sum(x)
+#  define G8SUM2(x,y)   do{ (x) = rkfd_emu_g8sum(x); (y) = rkfd_emu_g8sum(y); }while(0)
+#  define G8BCAST(x,k)  rkfd_emu_g8bcast(x,k)
+#  define RKFD_RCP(x)   ( 1.0/(x) )
+#  define LDS_FENCE()   rkfd_emu_sync()
+#  define BCAST(x,l)    rkfd_emu_bcast(x,l)
+#  define BALLOT(p)     rkfd_emu_ballot(p)
+#else
+#  define RKFD_DEV __device__ __forceinline__
+#  define LANE()        ((int)threadIdx.x)
+/* One workgroup is one wavefront: lanes exchange data through LDS in program order, so a
+ * "barrier" only has to (a) stop the compiler from moving LDS accesses across it and (b) wait
+ * for the wave's own outstanding LDS operations.  __syncthreads() would also drain vmcnt (the
+ * schedule-record prefetches), which is exactly the latency the prefetch is meant to hide. */
+#  define SYNC()        asm volatile( "s_waitcnt lgkmcnt(0)" ::: "memory" )
+RKFD_DEV double rkfd_dpp_xor1(double x)
+{
+  int lo = __double2loint( x ), hi = __double2hiint( x );
+  lo = __builtin_amdgcn_update_dpp( lo, lo, 0xB1, 0xF, 0xF, false ); /* quad_perm [1,0,3,2] */
+  hi = __builtin_amdgcn_update_dpp( hi, hi, 0xB1, 0xF, 0xF, false );
+  return __hiloint2double( hi, lo );
+}
+RKFD_DEV double rkfd_dpp_xor2(double x)
+{
+  int lo = __double2loint( x ), hi = __double2hiint( x );
+  lo = __builtin_amdgcn_update_dpp( lo, lo, 0x4E, 0xF, 0xF, false ); /* quad_perm [2,3,0,1] */
+  hi = __builtin_amdgcn_update_dpp( hi, hi, 0x4E, 0xF, 0xF, false );
+  return __hiloint2double( hi, lo );
+}
+RKFD_DEV double rkfd_dpp_hmirror(double x)
+{
+  int lo = __double2loint( x ), hi = __double2hiint( x );
+  lo = __builtin_amdgcn_update_dpp( lo, lo, 0x141, 0xF, 0xF, false ); /* row_half_mirror */
+  hi = __builtin_amdgcn_update_dpp( hi, hi, 0x141, 0xF, 0xF, false );
+  return __hiloint2double( hi, lo );
+}
+/* sum over the aligned group of 8 lanes, result in every lane of the group */
+RKFD_DEV double rkfd_g8sum(double x)
+{
+  x += rkfd_dpp_xor1( x );
+  x += rkfd_dpp_xor2( x );
+  x += rkfd_dpp_hmirror( x );
+  return x;
+}
+/* two independent 8-lane sums, interleaved so that their DPP chains overlap */
+RKFD_DEV void rkfd_g8sum2(double &x, double &y)
+{
+  double a = rkfd_dpp_xor1( x ), b = rkfd_dpp_xor1( y );
+  x += a; y += b;
+  a = rkfd_dpp_xor2( x ); b = rkfd_dpp_xor2( y );
+  x += a; y += b;
+  a = rkfd_dpp_hmirror( x ); b = rkfd_dpp_hmirror( y );
+  x += a; y += b;
+}
+/* broadcast lane src (wave-uniform) to every lane */
+RKFD_DEV double rkfd_bcast(double x, int src)
+{
+  int lo = __builtin_amdgcn_readlane( __double2loint( x ), src );
+  int hi = __builtin_amdgcn_readlane( __double2hiint( x ), src );
+  return __hiloint2double( hi, lo );
+}
+/* broadcast lane k (compile-time 0..7) of every aligned 8-lane group to the whole group:
+ * ds_swizzle in bit mode, lane' = ( lane & 0x18 ) | k within each half-wave; no LDS storage */
+template<int K> RKFD_DEV double rkfd_g8bcast(double x)
+{
+  int lo = __builtin_amdgcn_ds_swizzle( __double2loint( x ), ( K << 5 ) | 0x18 );
+  int hi = __builtin_amdgcn_ds_swizzle( __double2hiint( x ), ( K << 5 ) | 0x18 );
+  return __hiloint2double( hi, lo );
+}
+/* reciprocal: v_rcp_f64 + two Newton steps (relative error ~1e-16) instead of the IEEE division sequence */
+RKFD_DEV double rkfd_rcp(double x)
+{
+  double r = __builtin_amdgcn_rcp( x );
+  r = fma( r, fma( -x, r, 1.0 ), r );
+  r = fma( r, fma( -x, r, 1.0 ), r );
+  return r;
+}
+#  define G8SUM(x)      rkfd_g8sum(x)
+#  define G8SUM2(x,y)   rkfd_g8sum2(x,y)
+#  define G8BCAST(x,k)  rkfd_g8bcast<k>(x)
+#  define RKFD_RCP(x)   rkfd_rcp(x)
+/* compiler-only fence: LDS operations of one wavefront execute in program order */
+#  define LDS_FENCE()   asm volatile( "" ::: "memory" )
+#  define BCAST(x,l)    rkfd_bcast(x,l)
+#  define BALLOT(p)     __ballot(p)
+#endif
+
+#define RKFD_DEV_TOL RKFD_TOL
+
+/* RELOAD(p): makes the compiler forget what it knows about pointer p.  The per-lane model constants
+ * (link frames, inertias, motor data ...) are the same in every evaluation, so LLVM hoists their
+ * loads out of the step loop and then has to SPILL ~35 doubles per lane to scratch - HBM write
+ * traffic an order of magnitude above the algorithmic bytes.  Re-reading them from L2 is cheaper. */
+#ifdef RKFD_EMU
+#  define RELOAD(p) (p)
+#else
+template<class T> RKFD_DEV const T *rkfd_reload(const T *p){ asm volatile( "" : "+s"(p) ); return p; }
+#  define RELOAD(p) rkfd_reload(p)
+#endif
+
+/* optional in-kernel phase timing (diagnostic launches only: rkfdBatchProfile) */
+#define RKFD_NPROF 24
+#ifdef RKFD_EMU
+#  define RKFD_CLOCK() 0ull
+#else
+#  define RKFD_CLOCK() ( (unsigned long long)__builtin_amdgcn_s_memtime() )
+#endif
+
+/* ------------------------------------------------------------------------ */
+/* 3-vector helpers on plain arrays */
+RKFD_DEV void d_cross(const double *a, const double *b, double *c)
+{
+  double x = a[1]*b[2]-a[2]*b[1], y = a[2]*b[0]-a[0]*b[2], z = a[0]*b[1]-a[1]*b[0];
+  c[0]=x; c[1]=y; c[2]=z;
+}
+RKFD_DEV double d_dot(const double *a, const double *b){ return a[0]*b[0]+a[1]*b[1]+a[2]*b[2]; }
+RKFD_DEV void d_mulv(const double *m, const double *v, double *r)
+{
+  double x = m[0]*v[0]+m[1]*v[1]+m[2]*v[2], y = m[3]*v[0]+m[4]*v[1]+m[5]*v[2], z = m[6]*v[0]+m[7]*v[1]+m[8]*v[2];
+  r[0]=x; r[1]=y; r[2]=z;
+}
+RKFD_DEV void d_tmulv(const double *m, const double *v, double *r)
+{
+  double x = m[0]*v[0]+m[3]*v[1]+m[6]*v[2], y = m[1]*v[0]+m[4]*v[1]+m[7]*v[2], z = m[2]*v[0]+m[5]*v[1]+m[8]*v[2];
+  r[0]=x; r[1]=y; r[2]=z;
+}
+RKFD_DEV void d_mul33(const double *a, const double *b, double *c)
+{
+  double t[9];
+#pragma unroll
+  for( int i=0; i<3; i++ )
+#pragma unroll
+    for( int j=0; j<3; j++ )
+      t[3*i+j] = a[3*i]*b[j] + a[3*i+1]*b[3+j] + a[3*i+2]*b[6+j];
+#pragma unroll
+  for( int i=0; i<9; i++ ) c[i] = t[i];
+}
+/* ------------------------------------------------------------------------ */
+/* compact sin/cos and atan2 for joint-angle sized arguments.  The library versions inline a
+ * Payne-Hanek slow path (v_trig_preop) that costs registers and code for arguments a robot never
+ * has; these use a two-term Cody-Waite reduction by pi/2 and the classic fdlibm kernel
+ * polynomials (|error| < 1 ulp for |x| < 1e5), and an fdlibm-style atan. */
+/* the polynomial coefficients live in constant memory and are fetched with scalar loads when a
+ * function runs: as 64-bit literals the compiler materialises them in VGPR pairs, hoists them out
+ * of the step loop and then spills them to scratch */
+#ifdef RKFD_EMU
+static const double rkfd_kc[] = {
+#else
+__constant__ double rkfd_kc[] = {
+#endif
+  /*  0 */ 6.36619772367581382433e-01, 1.57079632673412561417e+00, 6.07710050650619224932e-11,
+  /*  3 sin */ -1.66666666666666324348e-01, 8.33333333332248946124e-03, -1.98412698298579493134e-04,
+               2.75573137070700676789e-06, -2.50507602534068634195e-08, 1.58969099521155010221e-10,
+  /*  9 cos */ 4.16666666666666019037e-02, -1.38888888888741095749e-03, 2.48015872894767294178e-05,
+               -2.75573143513906633035e-07, 2.08757232129817482790e-09, -1.13596475577881948265e-11,
+  /* 15 atan hi/lo */ 4.63647609000806093515e-01, 2.26987774529616870924e-17, 7.85398163397448278999e-01, 3.06161699786838301793e-17,
+               9.82793723247329054082e-01, 1.39033110312309984516e-17, 1.57079632679489655800e+00, 6.12323399573676603587e-17,
+  /* 23 atan odd */ 3.33333333333329318027e-01, 1.42857142725034663711e-01, 9.09088713343650656196e-02,
+               6.66107313738753120669e-02, 4.97687799461593236017e-02, 1.62858201153657823623e-02,
+  /* 29 atan even */ -1.99999999998764832476e-01, -1.11111104054623557880e-01, -7.69187620504482999495e-02,
+               -5.83357013379057348645e-02, -3.65315727442169155270e-02,
+  /* 34 */ 3.14159265358979311600e+00
+};
+RKFD_DEV void d_sincos(double x, double *sn, double *cs)
+{
+  const double *K = RELOAD( (const double *)rkfd_kc );
+  const double k = rint( x*K[0] );
+  double r = fma( -k, K[1], x );
+  r = fma( -k, K[2], r );
+  const double z = r*r;
+  const double ps = K[3] + z*( K[4] + z*( K[5] + z*( K[6] + z*( K[7] + z*K[8] ) ) ) );
+  const double pc = K[9] + z*( K[10] + z*( K[11] + z*( K[12] + z*( K[13] + z*K[14] ) ) ) );
+  const double s0 = fma( r*z, ps, r );
+  const double c0 = fma( z*z, pc, fma( -0.5, z, 1.0 ) );
+  const int q = (int)k & 3;
+  const double s1 = ( q & 1 ) ? c0 : s0, c1 = ( q & 1 ) ? s0 : c0;
+  *sn = ( q & 2 ) ? -s1 : s1;
+  *cs = ( ( q + 1 ) & 2 ) ? -c1 : c1;
+}
+RKFD_DEV double d_atan_pos(double x)   /* x >= 0 */
+{
+  /* fdlibm atan: reduce to |t| <= 7/16 around 0, 0.5, 1, 1.5, inf */
+  const double *K = RELOAD( (const double *)rkfd_kc );
+  double hi, lo, t;
+  if( x < 0.4375 ){ hi = 0; lo = 0; t = x; }
+  else if( x < 0.6875 ){ hi = K[15]; lo = K[16]; t = ( 2.0*x - 1.0 )/( 2.0 + x ); }
+  else if( x < 1.1875 ){ hi = K[17]; lo = K[18]; t = ( x - 1.0 )/( x + 1.0 ); }
+  else if( x < 2.4375 ){ hi = K[19]; lo = K[20]; t = ( x - 1.5 )/( 1.0 + 1.5*x ); }
+  else { hi = K[21]; lo = K[22]; t = -1.0/x; }
+  const double z = t*t, w = z*z;
+  const double s1 = z*( K[23] + w*( K[24] + w*( K[25] + w*( K[26] + w*( K[27] + w*K[28] ) ) ) ) );
+  const double s2 = w*( K[29] + w*( K[30] + w*( K[31] + w*( K[32] + w*K[33] ) ) ) );
+  return hi - ( ( t*( s1 + s2 ) - lo ) - t );
+}
+RKFD_DEV double d_atan2_ypos(double y, double x)   /* y >= 0 */
+{
+  const double *K = RELOAD( (const double *)rkfd_kc );
+  if( x > 0 ) return d_atan_pos( y/x );
+  if( x < 0 ) return K[34] - d_atan_pos( y/( -x ) );
+  return y > 0 ? K[21] : 0.0;
+}
+
+RKFD_DEV void d_from_aa(const double *aa, double *m)
+{
+  double th = sqrt( d_dot( aa, aa ) );
+  if( th < RKFD_DEV_TOL ){
+    m[0]=1; m[1]=0; m[2]=0; m[3]=0; m[4]=1; m[5]=0; m[6]=0; m[7]=0; m[8]=1;
+    return;
+  }
+  double s, c;
+  d_sincos( th, &s, &c );
+  const double k = 1-c, ith = 1.0/th;
+  double x = aa[0]*ith, y = aa[1]*ith, z = aa[2]*ith;
+  m[0] = c+k*x*x;   m[1] = k*x*y-s*z; m[2] = k*x*z+s*y;
+  m[3] = k*x*y+s*z; m[4] = c+k*y*y;   m[5] = k*y*z-s*x;
+  m[6] = k*x*z-s*y; m[7] = k*y*z+s*x; m[8] = c+k*z*z;
+}
+RKFD_DEV void d_to_aa(const double *m, double *aa)
+{
+  double l[3] = { m[7]-m[5], m[2]-m[6], m[3]-m[1] };
+  double a = sqrt( d_dot( l, l ) );
+  double th = d_atan2_ypos( a, m[0]+m[4]+m[8]-1.0 );
+  if( a < RKFD_DEV_TOL ){ aa[0]=aa[1]=aa[2]=0; return; }
+  double k = th/a;
+  aa[0] = l[0]*k; aa[1] = l[1]*k; aa[2] = l[2]*k;
+}
+RKFD_DEV void d_ortho_space(const double *n, double *t1, double *t2)
+{
+  int k = 0;
+  if( fabs(n[1]) < fabs(n[k]) ) k = 1;
+  if( fabs(n[2]) < fabs(n[k]) ) k = 2;
+  double e[3] = { k==0 ? 1.0 : 0.0, k==1 ? 1.0 : 0.0, k==2 ? 1.0 : 0.0 };
+  double d = d_dot( e, n );
+  t1[0] = e[0]-d*n[0]; t1[1] = e[1]-d*n[1]; t1[2] = e[2]-d*n[2];
+  double l = sqrt( d_dot( t1, t1 ) );
+  t1[0] /= l; t1[1] /= l; t1[2] /= l;
+  d_cross( n, t1, t2 );
+}
+/* spatial motion cross product v x m and force cross product v x* f, (ang, lin) ordering */
+RKFD_DEV void d_crm(const double *v, const double *m, double *r)
+{
+  double a[3], b[3], c[3];
+  d_cross( v, m, a ); d_cross( v, m+3, b ); d_cross( v+3, m, c );
+  r[0]=a[0]; r[1]=a[1]; r[2]=a[2]; r[3]=b[0]+c[0]; r[4]=b[1]+c[1]; r[5]=b[2]+c[2];
+}
+RKFD_DEV void d_crf(const double *v, const double *f, double *r)
+{
+  double a[3], b[3], c[3];
+  d_cross( v, f, a ); d_cross( v+3, f+3, b ); d_cross( v, f+3, c );
+  r[0]=a[0]+b[0]; r[1]=a[1]+b[1]; r[2]=a[2]+b[2]; r[3]=c[0]; r[4]=c[1]; r[5]=c[2];
+}
+
+/* ------------------------------------------------------------------------ */
+/* motor model (see oracle/rkfd_oracle.c for the RoKi call sites it restates) */
+RKFD_DEV double d_clamp(double x, double lo, double hi){ return x < lo ? lo : ( x > hi ? hi : x ); }
+
+/* ------------------------------------------------------------------------ */
+/* LDS carve-up for one instance */
+typedef struct {
+  double *q, *qd, *acc;           /* [ndof] each                                         */
+  double *tmp;                    /* [ndof] scratch of rkfd_cat_dis: ALIASES V (dead between evaluations) */
+  double *S;                      /* [NL*6]  joint axis (ang, lin)                        */
+  double *V;                      /* [NL*6]  spatial velocity (kinematics .. rkfd_phase_bvel)               */
+  double *U;                      /* [NL*6]  Ia S, written by sweep 2: ALIASES V                            */
+  double *PB;                     /* [NL*6]  own bias force minus the external wrenches (kinematics .. sweep 2) */
+  double *AC;                     /* [NL*6]  spatial acceleration, written by sweep 3: ALIASES PB           */
+  double *C;                      /* [NL*6]  velocity-product acceleration (kinematics .. sweep 3)          */
+  double *PA;                     /* [NL*6]  bias force handed to the parent (sweep 2)                      */
+  double *XA, *XB;                /* [NL*6] each: world frames, R rows 0-1 | R row 2, p.  Valid from the kinematics
+                                     phase to the end of the collision phase: XA ALIASES PA, XB the Ia pool */
+  double *MS;                     /* [NL*4]  Dinv, u, tau, jm                             */
+  double *IST;                    /* [NL*14] inertia staging: A = Iw + m(|r|^2 1 - r r') (xx,xy,xz,yy,yz,zz),
+                                     +m r (3), -m r (3), m, 0: every entry of the 6x6 is one of these */
+  double *POOL;                   /* [npool*36] Ia of links whose parent gathers through LDS */
+  double *CHOL;                   /* [nfloat*36] articulated inertia / Cholesky factor of float joints */
+  double *XF;                     /* [nfloat*12] float joints: world orientation of the joint-origin frame (9), link position (3) */
+  double *CX, *AX, *RW, *PRO;     /* per ACTIVE contact slot (capacity maxact): 3, 9, 3, 3 */
+  double *REF;                    /* stick anchors (state): per active slot              */
+  double *RTMP;                   /* [maxact*3] copy of REF while the slots are re-assigned; only when ncand > 64 */
+  double *CF;                     /* contact forces (output): per active slot              */
+  double *MA, *MB, *MF, *PU;      /* MLCP: [M*(M+1)] (ALIASES IST|POOL), [M], [M], [nside*npurow*M] (ALIASES C|PA when it fits) */
+  int *act, *typ, *lrg, *lel, *tgt, *cnt;
+  int *asl;                       /* [NC] active-contact slot of a candidate              */
+  int *LI;                        /* [NL] packed link info (RKFD_LI_*)                    */
+  int *CIp, *CFO;                 /* [NC] packed candidate info, first plane              */
+  int *CHI;                       /* [NL] children lists (CSR values; offsets in the schedule)     */
+  int *PSL;                       /* [NL] pool slot of a link (-1 none)                   */
+  unsigned char *PL;              /* [NL*nlevel] ancestor at depth d (MLCP only), one byte each */
+} rkfdLds;
+
+RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int M, int nlevel, int npool, int nfloat, int maxact, int nside, int pu_alias, int npurow)
+/* must match the byte count computed in rkfd_devmodel.cpp */
+{
+  double *d = (double *)base;
+  L->q = d; d += ND; L->qd = d; d += ND; L->acc = d; d += ND;
+  L->S = d; d += NL*6;
+  L->V = d; L->U = d; L->tmp = d; d += NL*6;
+  L->PB = d; L->AC = d; d += NL*6;
+  L->C = d; d += NL*6;
+  L->PA = d; L->XA = d; d += NL*6;
+  L->MS = d; d += NL*4;
+  {
+    const int pool = 36*npool > 6*NL ? 36*npool : 6*NL;
+    int stage = 14*NL + pool;
+    L->IST = d; L->POOL = d + 14*NL; L->XB = d + 14*NL; L->MA = d;
+    if( M*(M+1) > stage ) stage = M*(M+1);
+    d += stage;
+  }
+  L->CHOL = d; d += 36*nfloat; L->XF = d; d += 12*nfloat;
+  L->CX = d; d += maxact*3; L->AX = d; d += maxact*9; L->RW = d; d += maxact*3; L->PRO = d; d += maxact*3;
+  L->REF = d; d += maxact*3; L->RTMP = d; if( NC > RKFD_WAVE ) d += maxact*3;
+  L->CF = d; d += maxact*3;
+  L->MB = d; d += M; L->MF = d; d += M;
+  /* probe scratch: lives while the contact problem is set up and solved, when C and PA are dead */
+  if( pu_alias ) L->PU = L->C; else { L->PU = d; d += nside*npurow*M; }
+  int *ip = (int *)d;
+  L->act = ip; ip += NC; L->typ = ip; ip += NC; L->asl = ip; ip += NC; L->CIp = ip; ip += NC; L->CFO = ip; ip += NC;
+  L->lrg = ip; ip += maxact; L->lel = ip; ip += maxact; L->tgt = ip; ip += 2*maxact; L->cnt = ip; ip += 8;
+  L->LI = ip; ip += NL; L->CHI = ip; ip += NL; L->PSL = ip; ip += NL;
+  L->PL = (unsigned char *)ip;
+}
+
+/* per-lane state that only lane = link ever touches: kept in registers for the whole launch */
+typedef struct { double min, pivp; int pivt; } rkfdLaneLink;
+
+/* the stick anchors REF live per active-contact slot */
+#define RIDX(j) ( L.asl[j] )
+
+/* packed description of one moving side of a rigid contact (built per evaluation in L->tgt) */
+#define RKFD_CS_LINK(e)   ( (int)( (e) & 0xFF ) )
+#define RKFD_CS_DEPTH(e)  ( (int)( ( (e) >> 8 ) & 0x3F ) )
+#define RKFD_CS_TOP(e)    ( (int)( ( (e) >> 14 ) & 0xFF ) )
+#define RKFD_CS_D0(e)     ( (int)( ( (e) >> 22 ) & 0x7F ) )
+#define RKFD_CS_FLOAT(e)  ( (int)( ( (e) >> 29 ) & 1 ) )
+#define RKFD_CS_SIDE(e)   ( (int)( ( (e) >> 30 ) & 1 ) )
+#define RKFD_CS_VALID(e)  ( (int)( (e) >> 31 ) )
+
+/* counters in L->cnt */
+#define CNT_NRG 0
+#define CNT_NEL 1
+#define CNT_NTGT 2
+#define CNT_OVF 3
+
+#endif /* RKFD_DEV_BASE_H */

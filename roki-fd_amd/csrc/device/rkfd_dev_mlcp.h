@@ -1,0 +1,367 @@
+/* rkfd_dev_mlcp.h - part of the device code of the batched rkFDUpdate step (see rkfd_device.h):
+ * phase: MLCP rigid contacts in innovations form + projected Gauss-Seidel.
+ * Included by rkfd_device.h only, in this order; compiles for gfx950 and under the lane emulator. */
+#ifndef RKFD_DEV_MLCP_H
+#define RKFD_DEV_MLCP_H
+
+/* projected Gauss-Seidel for up to RKFD_PGS_NC contacts with the lane's three matrix rows held in
+ * registers (3 x 3*RKFD_PGS_NC doubles): the contact loop is unrolled, so the rows are indexed
+ * statically, the broadcasts read fixed lanes and the dependent path of an update is ALU only.
+ * Same arithmetic and update order as the general loop in rkfd_phase_mlcp. */
+#define RKFD_PGS_NC 4
+RKFD_DEV void rkfd_pgs_registers(const double *Arow, int ld, int nc, int max_iter, bool on, int lane, double mu,
+                                 double in_, double i1, double i2, double &rn, double &r1, double &r2, double &fn, double &f1, double &f2)
+{
+  double A0[3*RKFD_PGS_NC], A1[3*RKFD_PGS_NC], A2[3*RKFD_PGS_NC];
+#pragma unroll
+  for( int k=0; k<3*RKFD_PGS_NC; k++ ){
+    const bool in = on && k < 3*nc;
+    A0[k] = in ? Arow[k] : 0.0; A1[k] = in ? Arow[ld+k] : 0.0; A2[k] = in ? Arow[2*ld+k] : 0.0;
+  }
+  for( int it=0; it<max_iter; it++ ){
+#pragma unroll
+    for( int c=0; c<RKFD_PGS_NC; c++ ){
+      if( c < nc ){
+        double ff = fn - rn*in_;
+        if( ff < RKFD_DEV_TOL ) ff = 0.0;
+        const double dl = BCAST( ff - fn, c );
+        if( lane == c ) fn = ff;
+        rn = fma( A0[3*c], dl, rn ); r1 = fma( A1[3*c], dl, r1 ); r2 = fma( A2[3*c], dl, r2 );
+      }
+    }
+#pragma unroll
+    for( int c=0; c<RKFD_PGS_NC; c++ ){
+      if( c < nc ){
+        const double ff0 = f1 - r1*i1, ff1 = f2 - r2*i2;
+        const double fnorm = ff0*ff0 + ff1*ff1;
+        double fs = mu*fn; fs = fs*fs;
+        /* only the decision of lane c matters: branch on it wave-uniformly, so that the reciprocal
+         * is evaluated only when contact c really slides */
+        const bool zero = fnorm < RKFD_DEV_TOL || fs < RKFD_DEV_TOL;
+        double n1 = zero ? 0.0 : ff0, n2 = zero ? 0.0 : ff1;
+        if( ( BALLOT( !zero && fnorm > fs ) >> c ) & 1ull ){
+          const double sc = fs*RKFD_RCP( fnorm );
+          n1 = ff0*sc; n2 = ff1*sc;
+        }
+        const double d1 = BCAST( n1 - f1, c ), d2 = BCAST( n2 - f2, c );
+        if( lane == c ){ f1 = n1; f2 = n2; }
+        rn = fma( A0[3*c+1], d1, fma( A0[3*c+2], d2, rn ) );
+        r1 = fma( A1[3*c+1], d1, fma( A1[3*c+2], d2, r1 ) );
+        r2 = fma( A2[3*c+1], d1, fma( A2[3*c+2], d2, r2 ) );
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* MLCP rigid branch (reference src/rkfd_mlcp.c:287-297).  Preconditions: sweep 2 and sweep 3
+ * have been run with the wrenches applied so far (rkFDUpdateAccBias), so AC holds the free
+ * accelerations and U / MS / CHOL hold U, 1/D and the factor of a float joint's Ia.
+ *
+ * The reference builds the contact-space matrix A column by column (unit force at a contact,
+ * rkFDChainUpdateCachedABIPair, read the relative accelerations, src/rkfd_mlcp.c:76-122) and,
+ * once the forces are found, re-runs the cached-ABI sweeps with them applied.  Here both use
+ * the factorisation the sweeps already hold, H^-1 = (1-HpsiK)' D^-1 (1-HpsiK): a probe walks
+ * from its contact link up to the root once, leaving the innovation nu_k(j) = -S_j' dp it
+ * causes at every joint j it passes (scaled by sqrt(1/D_j); for a float joint the six
+ * components of L^-1 dp).  Then
+ *     A(r,k)   = sum over the joints common to both paths of nu_r(j) nu_k(j)      (+ relaxation),
+ *     delta qdd = the sweep-3 recursion driven by sum_k f_k nu_k                  (rkfd_phase_sweep3<true>),
+ * i.e. no per-column response walks and no second backward sweep; A comes out exactly
+ * symmetric.  Output: contact forces CF, committed contact state, and the inputs of the delta
+ * sweep (MS slot 1, U slot of float joints). */
+template<bool prof> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L, const double *bv, unsigned long long *pc)
+{
+  unsigned long long q0 = prof ? RKFD_CLOCK() : 0ull, q1;
+#define MST(k) do{ if( prof ){ q1 = RKFD_CLOCK(); pc[k] += q1 - q0; q0 = q1; } }while(0)
+  const int lane = LANE();
+  const int nc = L.cnt[CNT_NRG];
+  const int M = 3*nc;
+  const int ld = M+1;
+  const int NLV = m.nlevel, NL = m.nlink, NR = m.npurow;
+  const int NSD = m.nside;
+  const int PUS = NR*M;                               /* stride between the two sides of PU */
+  const unsigned char *TOP = L.PL + NL*NLV;           /* where a force on a link stops propagating (255: static) */
+  const unsigned char *FSL = TOP + NL;                /* float slot of a link */
+  const unsigned char *FLK = FSL + NL;                /* link of a float slot */
+  const double dt = m.dt;
+
+  /* b: free relative acceleration, then *dt + relative velocity + compensation
+   * (_rkFDSolverBiasAcc / BiasVel / RelaxationCompensation, reference src/rkfd_mlcp.c:58-74,146-188) */
+  if( lane < nc ){
+    const int j = L.lrg[lane], cinf = L.CIp[j], ci = RKFD_CI_CI( cinf );
+    const int la = RKFD_CI_A( cinf ), lb = RKFD_CI_B( cinf );
+    const double x[3] = { L.CX[3*L.asl[j]], L.CX[3*L.asl[j]+1], L.CX[3*L.asl[j]+2] };
+    double ta[3], tb[3], ra[3], d[3];
+    /* spatial-acceleration part of the point accelerations: a_O + alpha x p (the velocity-product
+     * part and the relative velocity come from rkfd_phase_bvel) */
+    d_cross( &L.AC[6*la], x, ta ); d_cross( &L.AC[6*lb], x, tb );
+#pragma unroll
+    for( int k=0; k<3; k++ ){
+      ra[k] = ( L.AC[6*la+3+k] + ta[k] ) - ( L.AC[6*lb+3+k] + tb[k] );
+      d[k] = x[k]-L.RW[3*L.asl[j]+k];
+    }
+    const double mu = L.typ[j] == RKFD_SF ? m.ci_sf[ci] : m.ci_kf[ci];
+    const double K = m.ci_k[ci];
+#pragma unroll
+    for( int i=0; i<3; i++ ){
+      const double *ax = &L.AX[9*L.asl[j]+3*i];
+      double b = ( d_dot( ax, ra ) + bv[3+i] )*dt + bv[i];
+      b += ( i == 0 ? K : K*mu )*d_dot( d, ax );
+      L.MB[3*lane+i] = b;
+    }
+    /* the moving side(s) of this contact, packed (RKFD_CS_*): link, its depth, the link where its
+     * path ends (TOP), the first level of the path that carries a 1-DoF joint, float-top flag,
+     * side.  One entry per contact when no rigid pair has two moving links, else one per side. */
+    if( NSD == 1 ) L.tgt[lane] = 0;      /* (a contact between two immovable links has no moving side) */
+#pragma unroll
+    for( int sd=0; sd<2; sd++ ){
+      const int a = sd == 0 ? la : lb;
+      const int top = TOP[a];
+      if( NSD == 1 && top == 255 ) continue;
+      const int lit = L.LI[top == 255 ? 0 : top], jtt = RKFD_LI_JT( lit );
+      const int d0 = RKFD_LI_DEPTH( lit ) + ( jtt == RKFD_JOINT_REVOL || jtt == RKFD_JOINT_PRISM ? 0 : 1 );
+      const unsigned e = (unsigned)a | ( (unsigned)RKFD_LI_DEPTH( L.LI[a] ) << 8 ) | ( (unsigned)top << 14 ) | ( (unsigned)d0 << 22 )
+                       | ( jtt == RKFD_JOINT_FLOAT ? 1u << 29 : 0u ) | ( (unsigned)sd << 30 ) | ( top != 255 ? 1u << 31 : 0u );
+      L.tgt[NSD == 1 ? lane : 2*lane+sd] = (int)e;
+    }
+  }
+  /* sqrt(1/D) of the 1-DoF joints (MS slot 2: the driving torque kept there is dead after sweep 2) */
+  if( lane < NL ){
+    const int jt = RKFD_LI_JT( L.LI[lane] );
+    if( jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM ) L.MS[4*lane+2] = sqrt( L.MS[4*lane+0] );
+  }
+  SYNC();
+  MST(14);
+  /* probes: lane = column k = 3c+i; unit force along axis i at contact c, applied to the
+   * owner link (+) and the other link (-).  Every level between the contact link and the top of
+   * its path carries a 1-DoF joint; the operands of the next level are fetched while this one is
+   * computed. */
+  for( int cb=0; cb<M; cb+=RKFD_WAVE ){      /* 64 probe columns at a time */
+    const int col = cb + lane;
+    const bool on = col < M;
+    const int c = on ? col/3 : 0, ia = on ? col%3 : 0;
+    const int j = L.lrg[c];
+    double W[6];
+    {
+      const double x[3] = { L.CX[3*L.asl[j]], L.CX[3*L.asl[j]+1], L.CX[3*L.asl[j]+2] };
+      const double *ax = &L.AX[9*L.asl[j]+3*ia];
+      d_cross( x, ax, W );
+      W[3] = ax[0]; W[4] = ax[1]; W[5] = ax[2];
+    }
+    if( on ){
+      for( int s2=0; s2<NSD; s2++ ){
+        const unsigned e = (unsigned)L.tgt[c*NSD+s2];
+        if( !RKFD_CS_VALID( e ) ) continue;
+        const int a = RKFD_CS_LINK( e ), da = RKFD_CS_DEPTH( e ), d0 = RKFD_CS_D0( e );
+        /* bias force delta: p = -f_ext */
+        double dp[6];
+        const double sg = RKFD_CS_SIDE( e ) == 0 ? -1.0 : 1.0;
+#pragma unroll
+        for( int k=0; k<6; k++ ) dp[k] = sg*W[k];
+        double *pu = &L.PU[s2*PUS + col];
+        const unsigned char *path = &L.PL[a*NLV];
+        double Sx[6], Ux[6], sdx, dix;
+#pragma unroll
+        for( int k=0; k<6; k++ ){ Sx[k] = L.S[6*a+k]; Ux[k] = L.U[6*a+k]; }
+        sdx = L.MS[4*a+2]; dix = L.MS[4*a+0];
+        int inext = path[da > 0 ? da-1 : 0];
+        for( int d=da; d>=d0; d-- ){
+          const int in_ = inext;
+          double Sn[6], Un[6];
+#pragma unroll
+          for( int k=0; k<6; k++ ){ Sn[k] = L.S[6*in_+k]; Un[k] = L.U[6*in_+k]; }
+          const double sdn = L.MS[4*in_+2], din = L.MS[4*in_+0];
+          inext = path[d > 1 ? d-2 : 0];
+          double du0 = Sx[0]*dp[0], du1 = Sx[1]*dp[1];
+          du0 = fma( Sx[2], dp[2], du0 ); du1 = fma( Sx[3], dp[3], du1 );
+          du0 = fma( Sx[4], dp[4], du0 ); du1 = fma( Sx[5], dp[5], du1 );
+          const double du = -( du0 + du1 );
+          pu[d*M] = du*sdx;
+          const double t = du*dix;
+#pragma unroll
+          for( int k=0; k<6; k++ ) dp[k] = fma( Ux[k], t, dp[k] );
+#pragma unroll
+          for( int k=0; k<6; k++ ){ Sx[k] = Sn[k]; Ux[k] = Un[k]; }
+          sdx = sdn; dix = din;
+        }
+        if( RKFD_CS_FLOAT( e ) ){
+          /* delta a = IA^-1 ( -dp ) = L^-T y,  y = L^-1 ( -dp ) */
+          double rhs[6], y[6];
+#pragma unroll
+          for( int k=0; k<6; k++ ) rhs[k] = -dp[k];
+          d_chol6_fwd( &L.CHOL[36*FSL[RKFD_CS_TOP( e )]], rhs, y );
+#pragma unroll
+          for( int k=0; k<6; k++ ) pu[( NLV+k )*M] = y[k];
+        }
+      }
+    }
+  }
+  SYNC();
+  MST(15);
+  /* A, one 3x3 block per lane and pass: block ( cr, ck <= cr ) and its mirror image */
+  for( int e0=0; e0<nc*nc; e0+=RKFD_WAVE ){
+    const int e = e0 + lane;
+    const int cr = e/nc, ck = e - cr*nc;
+    if( e < nc*nc && ck <= cr ){
+      double blk[9] = {0,0,0,0,0,0,0,0,0};
+      for( int sr=0; sr<NSD; sr++ ) for( int sk=0; sk<NSD; sk++ ){
+        const unsigned er = (unsigned)L.tgt[cr*NSD+sr], ek = (unsigned)L.tgt[ck*NSD+sk];
+        if( !RKFD_CS_VALID( er ) || !RKFD_CS_VALID( ek ) || RKFD_CS_TOP( er ) != RKFD_CS_TOP( ek ) ) continue;   /* no joint in common */
+        const double *pr = &L.PU[sr*PUS + 3*cr], *pk = &L.PU[sk*PUS + 3*ck];
+        const int a = RKFD_CS_LINK( er ), b = RKFD_CS_LINK( ek );
+        const int d0 = RKFD_CS_D0( er );
+        int dc = RKFD_CS_DEPTH( er ) < RKFD_CS_DEPTH( ek ) ? RKFD_CS_DEPTH( er ) : RKFD_CS_DEPTH( ek );
+        if( a != b ){
+          /* last level the two paths share */
+          int d = d0;
+          while( d <= dc && L.PL[a*NLV+d] == L.PL[b*NLV+d] ) d++;
+          dc = d-1;
+        }
+#pragma unroll 2
+        for( int d=d0; d<=dc; d++ ){
+          const double r0 = pr[d*M], r1 = pr[d*M+1], r2 = pr[d*M+2];
+          const double k0 = pk[d*M], k1 = pk[d*M+1], k2 = pk[d*M+2];
+          blk[0] = fma( r0, k0, blk[0] ); blk[1] = fma( r0, k1, blk[1] ); blk[2] = fma( r0, k2, blk[2] );
+          blk[3] = fma( r1, k0, blk[3] ); blk[4] = fma( r1, k1, blk[4] ); blk[5] = fma( r1, k2, blk[5] );
+          blk[6] = fma( r2, k0, blk[6] ); blk[7] = fma( r2, k1, blk[7] ); blk[8] = fma( r2, k2, blk[8] );
+        }
+        if( RKFD_CS_FLOAT( er ) ){
+#pragma unroll
+          for( int q=0; q<6; q++ ){
+            const int d = NLV + q;
+            const double r0 = pr[d*M], r1 = pr[d*M+1], r2 = pr[d*M+2];
+            const double k0 = pk[d*M], k1 = pk[d*M+1], k2 = pk[d*M+2];
+            blk[0] = fma( r0, k0, blk[0] ); blk[1] = fma( r0, k1, blk[1] ); blk[2] = fma( r0, k2, blk[2] );
+            blk[3] = fma( r1, k0, blk[3] ); blk[4] = fma( r1, k1, blk[4] ); blk[5] = fma( r1, k2, blk[5] );
+            blk[6] = fma( r2, k0, blk[6] ); blk[7] = fma( r2, k1, blk[7] ); blk[8] = fma( r2, k2, blk[8] );
+          }
+        }
+      }
+      if( cr == ck ){
+        /* relaxation on the diagonal */
+        const double rl = m.ci_l[RKFD_CI_CI( L.CIp[L.lrg[cr]] )];
+        blk[0] += rl; blk[4] += rl; blk[8] += rl;
+      }
+#pragma unroll
+      for( int i=0; i<3; i++ )
+#pragma unroll
+        for( int q=0; q<3; q++ ){
+          L.MA[( 3*cr+i )*ld + 3*ck+q] = blk[3*i+q];
+          if( cr != ck ) L.MA[( 3*ck+q )*ld + 3*cr+i] = blk[3*i+q];
+        }
+    }
+  }
+  SYNC();
+  MST(6);
+  /* projected Gauss-Seidel, fixed max_iter sweeps, no warm start (_rkFDSolverMLCP, reference
+   * src/rkfd_mlcp.c:190-249), same update order.  lane = contact: each lane keeps the three
+   * residuals res = b + A f, forces and inverse diagonals of ITS contact in registers, every lane
+   * evaluates its own Gauss-Seidel candidate, and only the increment of the contact whose turn it
+   * is gets broadcast (v_readlane) and applied to everybody's residuals. */
+  {
+    const bool on = lane < nc;
+    const int r0 = on ? 3*lane : 0;
+    double rn = 0, r1 = 0, r2 = 0, fn = 0, f1 = 0, f2 = 0, in_ = 0, i1 = 0, i2 = 0, mu = 0;
+    if( on ){
+      rn = L.MB[r0]; r1 = L.MB[r0+1]; r2 = L.MB[r0+2];
+      const double dn = L.MA[r0*ld+r0], d1 = L.MA[(r0+1)*ld+r0+1], d2 = L.MA[(r0+2)*ld+r0+2];
+      in_ = 1.0/dn;
+      /* tangential rows with |a_kk| < zTOL are frozen at 0 (reference :220-221) */
+      i1 = fabs( d1 ) < RKFD_DEV_TOL ? 0.0 : 1.0/d1;
+      i2 = fabs( d2 ) < RKFD_DEV_TOL ? 0.0 : 1.0/d2;
+      const int jr_ = L.lrg[lane], cir_ = RKFD_CI_CI( L.CIp[jr_] );
+      mu = L.typ[jr_] == RKFD_SF ? m.ci_sf[cir_] : m.ci_kf[cir_];
+    }
+    const double *Arow = &L.MA[r0*ld];
+    if( nc <= RKFD_PGS_NC ) rkfd_pgs_registers( Arow, ld, nc, m.max_iter, on, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
+    else for( int it=0; it<m.max_iter; it++ ){
+      for( int c=0; c<nc; c++ ){
+        /* normal force of contact c: f_n <- max( 0, -( b + a.f - a_nn f_n ) / a_nn ) */
+        const double a0 = Arow[3*c], a1 = Arow[ld+3*c], a2 = Arow[2*ld+3*c];
+        double ff = fn - rn*in_;
+        if( ff < RKFD_DEV_TOL ) ff = 0.0;
+        const double dl = BCAST( ff - fn, c );
+        if( lane == c ) fn = ff;
+        rn = fma( a0, dl, rn ); r1 = fma( a1, dl, r1 ); r2 = fma( a2, dl, r2 );
+      }
+      for( int c=0; c<nc; c++ ){
+        /* tangential forces of contact c: Gauss-Seidel value for both, then scaled onto the
+         * friction disc of radius mu f_n */
+        const double a0 = Arow[3*c+1], a1 = Arow[ld+3*c+1], a2 = Arow[2*ld+3*c+1];
+        const double b0 = Arow[3*c+2], b1 = Arow[ld+3*c+2], b2 = Arow[2*ld+3*c+2];
+        const double ff0 = f1 - r1*i1, ff1 = f2 - r2*i2;
+        const double fnorm = ff0*ff0 + ff1*ff1;
+        double fs = mu*fn; fs = fs*fs;
+        double n1, n2;
+        if( fnorm < RKFD_DEV_TOL || fs < RKFD_DEV_TOL ){ n1 = 0; n2 = 0; }
+        else if( fnorm > fs ){ const double sc = fs*RKFD_RCP( fnorm ); n1 = ff0*sc; n2 = ff1*sc; }
+        else { n1 = ff0; n2 = ff1; }
+        const double d1 = BCAST( n1 - f1, c ), d2 = BCAST( n2 - f2, c );
+        if( lane == c ){ f1 = n1; f2 = n2; }
+        rn = fma( a0, d1, fma( b0, d2, rn ) );
+        r1 = fma( a1, d1, fma( b1, d2, r1 ) );
+        r2 = fma( a2, d1, fma( b2, d2, r2 ) );
+      }
+    }
+    if( on ){ L.MF[r0] = fn/dt; L.MF[r0+1] = f1/dt; L.MF[r0+2] = f2/dt; }
+  }
+  SYNC();
+  MST(21);
+  /* _rkFDSolverSetForce (reference src/rkfd_mlcp.c:252-284) incl. quirks Q1 / Q2 */
+  if( lane < nc ){
+    const int j = L.lrg[lane], ci = RKFD_CI_CI( L.CIp[j] );
+    double fw[3] = {0,0,0};
+#pragma unroll
+    for( int i=0; i<3; i++ ){
+      const double fi = L.MF[3*lane+i];
+      fw[0] += fi*L.AX[9*L.asl[j]+3*i]; fw[1] += fi*L.AX[9*L.asl[j]+3*i+1]; fw[2] += fi*L.AX[9*L.asl[j]+3*i+2];
+    }
+    { const int sl_ = L.asl[j]; L.CF[3*sl_] = fw[0]; L.CF[3*sl_+1] = fw[1]; L.CF[3*sl_+2] = fw[2]; }
+    const double fn = fw[0], fs = sqrt( fw[1]*fw[1] + fw[2]*fw[2] );
+    const double mu = L.typ[j] == RKFD_SF ? m.ci_sf[ci] : m.ci_kf[ci];
+    if( fs > mu*fn - RKFD_DEV_TOL ){
+      L.typ[j] = RKFD_KF;
+      { const int ri = RIDX( j ), sl_ = L.asl[j]; L.REF[3*ri] = L.PRO[3*sl_]; L.REF[3*ri+1] = L.PRO[3*sl_+1]; L.REF[3*ri+2] = L.PRO[3*sl_+2]; }
+    } else {
+      L.typ[j] = RKFD_SF;
+    }
+  }
+  SYNC();
+  MST(22);
+  /* inputs of the delta sweep, lane = link: what the solved forces F = MF do to the joint's
+   * innovation.  1-DoF joint: sum_k F_k nu_k / D  (= scaled sum times sqrt(1/D));  float joint:
+   * sum_k F_k y_k.  Links no contact path passes get 0. */
+  {
+    const int ntask = NL + 6*m.nfloat;    /* one per link (used by those with a 1-DoF joint), then six per float joint */
+    for( int t0=0; t0<ntask; t0+=RKFD_WAVE ){
+      const int t = t0 + lane;
+      const bool isl = t < NL, isf = !isl && t < ntask;
+      const int fq = isf ? ( t-NL )%6 : 0;
+      const int link = isl ? t : ( isf ? FLK[( t-NL )/6] : 0 );
+      const int lii = L.LI[link], jt = RKFD_LI_JT( lii );
+      const bool is1 = isl && ( jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM );
+      const int dpt = isl ? RKFD_LI_DEPTH( lii ) : 0;
+      const int row = isf ? NLV+fq : dpt;
+      double sum = 0;
+#pragma unroll 2
+      for( int cs=0; cs<nc*NSD; cs++ ){
+        const unsigned e = (unsigned)L.tgt[cs];
+        const int c = NSD == 1 ? cs : cs >> 1;
+        const double *pu = &L.PU[( NSD == 1 ? 0 : ( cs & 1 ) )*PUS + row*M + 3*c];
+        const double v = L.MF[3*c]*pu[0] + L.MF[3*c+1]*pu[1] + L.MF[3*c+2]*pu[2];
+        /* 1-DoF joint: it lies on the moving path of the contact side; float joint: the path ends there */
+        const bool onp = RKFD_CS_VALID( e ) && ( isf ? RKFD_CS_TOP( e ) == link
+                       : ( RKFD_CS_DEPTH( e ) >= dpt && RKFD_CS_D0( e ) <= dpt && L.PL[RKFD_CS_LINK( e )*NLV+dpt] == link ) );
+        sum += onp ? v : 0.0;
+      }
+      if( is1 ) L.MS[4*link+1] = sum*L.MS[4*link+2];
+      if( isf ) L.U[6*link+fq] = sum;
+    }
+  }
+  SYNC();
+  MST(23);
+#undef MST
+}
+
+#endif /* RKFD_DEV_MLCP_H */
