@@ -2,6 +2,7 @@
 import os
 
 import numpy as np
+import pytest
 
 
 def test_humanoid30_topology(R):
@@ -69,3 +70,23 @@ def test_chain_reg_clone_unreg_in_c(R, tmp_path):
     assert out[1] == "after clone size 42 chain ids 0 1 2 3"
     assert out[2] == "after unreg size 36 ids 0 1 2 dofoff 0 30 30  q[3]=0.25"   # the chain's joint value moved with it
     assert out[3] == "model nlink 33 ndof 36 ncand 16"                    # chain 31 + floor 1 + cloned box 1; box x floor candidates
+
+
+REF_MODELS = "/root/reference/example/model"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_MODELS), reason="reference checkout not present (it never is on the GPU box)")
+def test_reader_loads_the_reference_shipped_models(R):
+    """the independent ZTK reader against the reference's own example models (read as data): every
+    model whose joints are fixed / revolute / prismatic / float loads; spherical and breakable-float
+    joints are reported as unsupported, not mis-read"""
+    expect = {"arm_2DoF.ztk": (3, 2), "arm_2DoF_trq.ztk": (3, 2), "box.ztk": (1, 6), "box_small.ztk": (1, 6), "crawler.ztk": (3, 6),
+              "floor.ztk": (1, 0), "floor_hardsoft.ztk": (2, 0), "mighty.ztk": (25, 26), "puma.ztk": (7, 6)}
+    for f, (nl, nd) in expect.items():
+        w = R.World()
+        w.reg_file(os.path.join(REF_MODELS, f))
+        m = w.model.contents
+        assert (m.nlink, m.ndof) == (nl, nd), f
+    for f in ("arm.ztk", "dualarm.ztk", "wall.ztk"):
+        with pytest.raises(R.RkfdError):
+            R.World().reg_file(os.path.join(REF_MODELS, f))
