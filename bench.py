@@ -193,7 +193,7 @@ def main():
             tf = fl * Bn / (kernel_ms * 1e-3) / 1e12
             res["roofline_valu"] = {"bound": "valu_fp64", "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6,
                                     "alg_flops_per_instance_step": fl}
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:      # the CPU baseline is a single-GPU-run figure (rank 0, N = 1)
             res["cpu_baseline"] = cpu_baseline(R, args.workload)
             res["cpu_baseline_all_cores"] = cpu_baseline_all_cores(R, args.workload)
         print(json.dumps(res))
