@@ -85,6 +85,18 @@ template<bool prof> RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, c
     }
     SYNC();
   }
+  /* Origin of the spatial coordinates.  All spatial quantities of an evaluation are Pluecker vectors about
+   * ONE common point, which may be any point: inertias and bias forces about a far-away point lose
+   * digits to the parallel-axis terms (error ~ distance^2), so the point is the anchor link's current
+   * position - every link position, hence every contact point and lever arm derived from it below, is
+   * taken relative to it.  Nothing spatial is carried from one evaluation to the next. */
+  if( m.anchor >= 0 ){
+    const double o0 = L.XB[6*m.anchor+3], o1 = L.XB[6*m.anchor+4], o2 = L.XB[6*m.anchor+5];
+    SYNC();
+    p[0] -= o0; p[1] -= o1; p[2] -= o2;
+    if( on ){ L.XB[6*i+3] = p[0]; L.XB[6*i+4] = p[1]; L.XB[6*i+5] = p[2]; }
+    SYNC();
+  }
   KST(17);
   /* joint motion axis and joint velocity in world coordinates */
   double Row[9] = {1,0,0, 0,1,0, 0,0,1};   /* float joints: world orientation of the joint-origin frame */

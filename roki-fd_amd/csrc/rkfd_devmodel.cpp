@@ -299,6 +299,8 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   dm.solver = m->solver; dm.max_iter = m->max_iter; dm.maxrg = max_rigid;
   dm.dt = m->dt; dm.fric_w = m->friction_weight;
   dm.nsched = nsched; dm.npool = npool; dm.nfloat = nfloat;
+  dm.anchor = -1;
+  for( int i=0; i<NL; i++ ) if( !is_static[i] ){ dm.anchor = i; break; }
   /* contact capacities */
   /* active-contact slots: up to 16 when elastic (penalty) contacts can occur, and at least the
    * rigid capacity when rigid ones can */

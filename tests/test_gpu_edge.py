@@ -158,3 +158,21 @@ def test_arm_press_paths(R, oracle_cls, root, with_box):
         seen += int(oact.sum())
     if with_box:
         assert seen > 0
+
+
+def test_far_from_the_world_origin(R, oracle_cls):
+    """spatial quantities are taken about the anchor link, not the world origin: a humanoid in free
+    flight 1 km away from the origin still matches the oracle (parallel-axis terms about the world
+    origin would cost ~(distance / link size)^2 in relative accuracy)"""
+    sc = R.scenarios.config4(batch=4)
+    dis = sc["dis"].copy(); dis[:, 0] += 1000.0; dis[:, 1] -= 500.0; dis[:, 2] += 0.5
+    vel = np.random.default_rng(0).uniform(-1, 1, sc["vel"].shape)
+    b = R.Batch(sc["world"], 4, max_rigid=sc["max_rigid"])
+    b.set_state(dis, vel); b.update_init(); b.update(5)
+    assert b.status() == 0
+    d, v, a = b.get_state()
+    for i in range(4):
+        o = oracle_cls(sc["world"].model); o.set_state(dis[i], vel[i]); o.update_init(); o.update_n(5)
+        od, ov, oa = o.get_state()
+        assert _rel(a[i], oa) < 1e-11 and _rel(v[i], ov) < 1e-12
+        assert np.abs(d[i] - od).max() < 1e-9          # absolute: |dis| ~ 1e3
