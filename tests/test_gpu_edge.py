@@ -176,3 +176,45 @@ def test_far_from_the_world_origin(R, oracle_cls):
         od, ov, oa = o.get_state()
         assert _rel(a[i], oa) < 1e-11 and _rel(v[i], ov) < 1e-12
         assert np.abs(d[i] - od).max() < 1e-9          # absolute: |dis| ~ 1e3
+
+
+def _stack_world(R):
+    M = R.scenarios.MODELS
+    w = R.World(solver=R.SOLVER_MLCP); w.contact_info(os.path.join(M, "contactinfo.ztk"))
+    for f in ("box.ztk", "box_small.ztk", "box_small.ztk", "floor.ztk"):
+        w.reg_file(os.path.join(M, f))
+    m = w.model.contents
+    dis = np.zeros((1, m.ndof)); vel = np.zeros((1, m.ndof))
+    dis[0, 0:3] = (0, 0, 0.05 - 0.0005)                                  # box on the floor
+    dis[0, 6:9] = (0.01, 0.0, 0.1 + 0.025 - 0.001); dis[0, 9:12] = (0, 0, 0.3)       # small box on the box, yawed
+    dis[0, 12:15] = (-0.02, 0.01, 0.15 + 0.025 - 0.0015); dis[0, 15:18] = (0.1, 0, 0)   # small box on the small box
+    vel[0, 6] = 0.2
+    return w, dis, vel
+
+
+def test_stacked_boxes(R, oracle_cls):
+    """three free boxes stacked on the floor: rigid pairs with two moving sides whose paths end at
+    different float joints, 96 candidate vertices (two collision chunks: anchors re-slotted through
+    the copy), 30 steps of settling vs the oracle"""
+    w, dis, vel = _stack_world(R)
+    B = 6
+    dis = np.repeat(dis, B, 0); vel = np.repeat(vel, B, 0)
+    vel[:, 6] = np.linspace(0.0, 0.5, B)
+    b = R.Batch(w, B, max_rigid=24)
+    b.set_state(dis, vel); b.update_init()
+    orc = []
+    for i in range(B):
+        o = oracle_cls(w.model); o.set_state(dis[i], vel[i]); o.update_init(); orc.append(o)
+    seen = 0
+    for chunk in range(3):
+        b.update(10)
+        assert b.status() == 0
+        d, v, a = b.get_state(); act, typ, ref, f = b.get_contact()
+        for i, o in enumerate(orc):
+            o.update_n(10)
+            od, ov, oa = o.get_state(); oact, _, _, of = o.get_contact()
+            assert (act[i] == oact).all()
+            assert _rel(d[i], od) < 1e-9 and _rel(v[i], ov) < 1e-9 and _rel(a[i], oa) < 1e-8
+            assert _rel(f[i], of * (oact[:, None] != 0)) < 1e-8
+            seen += int(oact.sum())
+    assert seen > 10
