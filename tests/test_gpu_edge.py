@@ -218,3 +218,28 @@ def test_stacked_boxes(R, oracle_cls):
             assert _rel(f[i], of * (oact[:, None] != 0)) < 1e-8
             seen += int(oact.sum())
     assert seen > 10
+
+
+def test_elastic_and_rigid_contacts_in_one_evaluation(R, oracle_cls):
+    """a box lying across the hard / soft seam of floor_hardsoft under the MLCP plugin: penalty wrenches
+    (elastic vertices) enter the free accelerations, the rigid vertices are solved on top of them"""
+    M = R.scenarios.MODELS
+    w = R.World(solver=R.SOLVER_MLCP); w.contact_info(os.path.join(M, "contactinfo.ztk"))
+    w.reg_file(os.path.join(M, "box.ztk")); w.reg_file(os.path.join(M, "floor_hardsoft.ztk"))
+    m = w.model.contents
+    B = 4
+    dis = np.zeros((B, m.ndof)); vel = np.zeros((B, m.ndof))
+    dis[:, 2] = 0.05 - 0.0005; dis[:, 5] = np.linspace(0.0, 0.6, B)
+    vel[:, 0] = 0.3; vel[:, 5] = 1.0
+    b = R.Batch(w, B, max_rigid=8)
+    b.set_state(dis, vel); b.update_init(); b.update(40)
+    assert b.status() == 0
+    d, v, a = b.get_state(); act, typ, ref, f = b.get_contact()
+    cit = m.arr("ci_type", m.nci); cci = m.arr("pair_ci", m.npair)
+    for i in range(B):
+        o = oracle_cls(w.model); o.set_state(dis[i], vel[i]); o.update_init(); o.update_n(40)
+        od, ov, oa = o.get_state(); oact, _, _, of = o.get_contact()
+        assert (act[i] == oact).all()
+        assert _rel(d[i], od) < RTOL and _rel(v[i], ov) < RTOL and _rel(a[i], oa) < RTOL
+        assert _rel(f[i], of * (oact[:, None] != 0)) < RTOL
+    assert {int(t) for t in cit[cci]} == {R.CONTACT_RIGID, R.CONTACT_ELASTIC}       # both kinds of pairs are registered
