@@ -86,6 +86,7 @@ typedef struct {
   double friction_weight;
   int max_iter;
   int solver;              /* RKFD_SOLVER_*                                 */
+  int pyramid;             /* faces of the friction pyramid of the Vert plugin (rkFDPrp pyramid, default 8) */
 } rkfdModel;
 
 #ifdef __cplusplus

@@ -36,6 +36,7 @@ def lib():
         L.rkfdOracleUpdateInit.argtypes = [vp]
         L.rkfdOracleUpdate.argtypes = [vp]
         L.rkfdOracleUpdateN.argtypes = [vp, C.c_int]
+        L.rkfdOracleLastQPIter.argtypes = [vp]
         L.rkfdOracleEval.argtypes = [vp, C.c_int]
         L.rkfdOracleGetLinkFrames.argtypes = [vp, vp, vp]
         L.rkfdOracleGetLinkVelAcc.argtypes = [vp, vp, vp]
@@ -109,6 +110,9 @@ class Oracle:
 
     def update_n(self, nsteps):
         return self._L.rkfdOracleUpdateN(self._o, int(nsteps))
+
+    def last_qp_iter(self):
+        return self._L.rkfdOracleLastQPIter(self._o)
 
     def update(self):
         return self._L.rkfdOracleUpdate(self._o)

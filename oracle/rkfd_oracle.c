@@ -20,6 +20,9 @@
 #include "rkfd_oracle.h"
 
 #define TOL RKFD_TOL
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
 #define is_tiny(x) ( fabs(x) < TOL )
 
 /* ------------------------------------------------------------------------ */
@@ -128,6 +131,7 @@ struct rkfdOracle {
   /* MLCP workspace */
   int mcap; double *ma, *mb, *mt, *mf;
   int last_nc;
+  int last_qp_iter;      /* KKT solves of the last Vert QP (diagnostic) */
   /* RKG workspace */
   double *k_v[4], *k_a[4], *xd, *xv, *tv, *ta;
 };
@@ -795,16 +799,15 @@ static void penalty(rkfdOracle *o, int doUpRef)
 
 /* ------------------------------------------------------------------------ */
 /* MLCP plugin, rigid branch: _rkFDSolverConstraint (reference src/rkfd_mlcp.c:287-297) */
-static int mlcp(rkfdOracle *o, int doUpRef)
+/* _rkFDSolverRelationAccForce (reference src/rkfd_mlcp.c:124-142 = src/rkfd_vert.c:153-189): the
+ * free relative accelerations b and, column by column, the response matrix A of the rigid contact
+ * vertices to unit forces along their axes.  Shared by the MLCP and the Vert plugin. */
+static void contact_system(rkfdOracle *o)
 {
   const rkfdModel *m = o->m;
-  int nc = o->nrg, n3 = 3*nc, c, i, r, cnt;
-  double *A = o->ma, *b = o->mb, *t = o->mt, *f = o->mf;
-  double dt = m->dt;
-  (void)doUpRef;
+  int nc = o->nrg, n3 = 3*nc, c, i, r;
+  double *A = o->ma, *b = o->mb, *t = o->mt;
 
-  o->last_nc = nc;
-  /* _rkFDSolverRelationAccForce (reference src/rkfd_mlcp.c:124-142) */
   /* rkFDUpdateAccBias (reference src/rkfd_util.c:149-161): full ABA, save bias, drop wrenches */
   aba_backward_full( o );
   aba_forward( o, o->acc );
@@ -842,6 +845,18 @@ static int mlcp(rkfdOracle *o, int doUpRef)
       aba_restore_bias( o );
     }
   }
+}
+
+static int mlcp(rkfdOracle *o, int doUpRef)
+{
+  const rkfdModel *m = o->m;
+  int nc = o->nrg, n3 = 3*nc, c, i, r, cnt;
+  double *A = o->ma, *b = o->mb, *f = o->mf;
+  double dt = m->dt;
+  (void)doUpRef;
+
+  o->last_nc = nc;
+  contact_system( o );
   /* _rkFDSolverBiasVel (reference src/rkfd_mlcp.c:146-162) */
   for( r=0; r<n3; r++ ) b[r] *= dt;
   for( c=0; c<nc; c++ ){
@@ -917,6 +932,250 @@ static int mlcp(rkfdOracle *o, int doUpRef)
 }
 
 /* ------------------------------------------------------------------------ */
+/* Vert plugin, rigid branch (reference src/rkfd_vert.c:258-336) with its active-set QP solver
+ * (reference src/rkfd_opt_qp.c:43-181).
+ *
+ * [UNVERIFIED-DEP] zLESolveMP( K, rhs, NULL, NULL, x ) (ZM, un-vendored; reference
+ * src/rkfd_opt_qp.c:107) is taken to return the Moore-Penrose solution x = K^+ rhs (minimum-norm
+ * least-squares solution with unit weights).  The KKT matrix K is symmetric, so K^+ is formed here
+ * from a cyclic-Jacobi eigen-decomposition, eigenvalues below 1e-12 |lambda|_max counting as zero
+ * (the rank tolerance is part of the unverifiable dependency).  zQuadraticValue(q,c,x) is taken as
+ * x'Qx/2 + c'x, zEqual(a,b,tol) as |a-b| < tol. */
+static void sym_pinv_solve(int n, double *K, const double *rhs, double *x)
+{
+  /* K (n x n, symmetric, destroyed) = V diag(w) V';  x = V diag(1/w) V' rhs over the non-zero w */
+  double *V = (double *)malloc( sizeof(double)*n*n ), *y = (double *)malloc( sizeof(double)*n );
+  int i, j, k, sweep;
+  double wmax = 0;
+  for( i=0; i<n; i++ ) for( j=0; j<n; j++ ) V[n*i+j] = i == j ? 1.0 : 0.0;
+  for( sweep=0; sweep<60; sweep++ ){
+    double off = 0, diag = 0;
+    for( i=0; i<n; i++ ){ diag += K[n*i+i]*K[n*i+i]; for( j=i+1; j<n; j++ ) off += K[n*i+j]*K[n*i+j]; }
+    if( off <= 1e-30*( diag + off ) || off == 0 ) break;
+    for( i=0; i<n-1; i++ )
+      for( j=i+1; j<n; j++ ){
+        double apq = K[n*i+j], theta, t, c, sn;
+        if( apq == 0.0 ) continue;
+        theta = ( K[n*j+j] - K[n*i+i] )/( 2.0*apq );
+        t = ( theta >= 0 ? 1.0 : -1.0 )/( fabs( theta ) + sqrt( theta*theta + 1.0 ) );
+        c = 1.0/sqrt( t*t + 1.0 ); sn = t*c;
+        for( k=0; k<n; k++ ){
+          double kp = K[n*k+i], kq = K[n*k+j];
+          K[n*k+i] = c*kp - sn*kq; K[n*k+j] = sn*kp + c*kq;
+        }
+        for( k=0; k<n; k++ ){
+          double kp = K[n*i+k], kq = K[n*j+k];
+          K[n*i+k] = c*kp - sn*kq; K[n*j+k] = sn*kp + c*kq;
+        }
+        for( k=0; k<n; k++ ){
+          double vp = V[n*k+i], vq = V[n*k+j];
+          V[n*k+i] = c*vp - sn*vq; V[n*k+j] = sn*vp + c*vq;
+        }
+      }
+  }
+  for( i=0; i<n; i++ ) if( fabs( K[n*i+i] ) > wmax ) wmax = fabs( K[n*i+i] );
+  for( i=0; i<n; i++ ){
+    double s = 0;
+    for( k=0; k<n; k++ ) s += V[n*k+i]*rhs[k];
+    y[i] = fabs( K[n*i+i] ) > 1e-12*wmax ? s/K[n*i+i] : 0.0;
+  }
+  for( k=0; k<n; k++ ){
+    double s = 0;
+    for( i=0; i<n; i++ ) s += V[n*k+i]*y[i];
+    x[k] = s;
+  }
+  free( V ); free( y );
+}
+
+/* _rkFDSolverQPASMCond (reference src/rkfd_vert.c:246-250): constraint i touches only the three
+ * force components of its contact */
+static double qp_cond(const double *nf, int n, int P, const double *ans, int i)
+{
+  int c = i/P;
+  return v3_dot( &nf[n*i+3*c], &ans[3*c] );
+}
+
+#define QP_ASM_TOL 1.0e-8
+/* rkFDQPSolveASM (reference src/rkfd_opt_qp.c:43-181): min x'Qx/2 + c'x  s.t.  nf x >= d.
+ * n unknowns, mc constraints; idx = active-set flags (output as well: used for the stick / slip
+ * decision).  Returns the number of KKT solves. */
+static int qp_asm(int n, int mc, int P, const double *q, const double *c, const double *nf, const double *d, double *ans, int *idx)
+{
+  int nmax = n + mc, m = 0, nm, i, j, k, iter = 0, nhist = 0, caphist = 16;
+  double *qa = (double *)malloc( sizeof(double)*nmax*nmax ), *xy = (double *)malloc( sizeof(double)*nmax );
+  double *cb = (double *)malloc( sizeof(double)*nmax ), *dv = (double *)malloc( sizeof(double)*n );
+  int *hidx = (int *)malloc( sizeof(int)*mc*caphist );
+  double *hmin = (double *)malloc( sizeof(double)*caphist );
+
+  /* _rkFDSolverQPASMInit (reference src/rkfd_vert.c:235-244): unit normal forces */
+  for( i=0; i<n; i++ ) ans[i] = 0.0;
+  for( i=0; i<n/3; i++ ) ans[3*i] = 1.0;
+  /* _rkFDQPSolveASMInitIndex (:29-42) */
+  for( i=0; i<mc; i++ ){
+    idx[i] = fabs( qp_cond( nf, n, P, ans, i ) - d[i] ) < TOL ? 1 : 0;
+    m += idx[i];
+  }
+  for(;;){
+    int step2 = 0;
+    double tempd, tempd2, objv;
+    nm = n + m;
+    for( i=0; i<n; i++ ) for( j=0; j<n; j++ ) qa[nm*i+j] = -q[n*i+j];
+    for( k=0, j=n; j<nm; j++ ){
+      while( !idx[k] ) k++;
+      for( i=0; i<n; i++ ){ qa[nm*i+j] = nf[n*k+i]; qa[nm*j+i] = nf[n*k+i]; }
+      k++;
+    }
+    for( i=n; i<nm; i++ ) for( j=n; j<nm; j++ ) qa[nm*i+j] = 0.0;
+    for( i=0; i<n; i++ ) cb[i] = c[i];
+    for( k=0, i=n; i<nm; i++ ){ while( !idx[k] ) k++; cb[i] = d[k]; k++; }
+    sym_pinv_solve( nm, qa, cb, xy );
+    iter++;
+
+    for( i=0; i<n; i++ ) if( !( fabs( xy[i] - ans[i] ) < TOL ) ){ step2 = 1; break; }
+    if( !step2 ){
+      int neg = 0, tempi;
+      for( i=0; i<n; i++ ) ans[i] = xy[i];
+      for( i=0; i<m; i++ ) if( xy[n+i] < 0 ) neg = 1;
+      if( !neg ) break;                       /* found the optimal solution */
+      tempd = xy[n];
+      for( i=1; i<m; i++ ) if( xy[n+i] < tempd ) tempd = xy[n+i];
+      tempi = 0;
+      for( i=0; i<mc; i++ )
+        if( idx[i] ){
+          if( fabs( xy[tempi+n] - tempd ) < QP_ASM_TOL ){ idx[i] = 0; m--; }
+          tempi++;
+        }
+      continue;
+    }
+    /* STEP2: move towards the equality-constrained minimiser as far as feasibility allows */
+    for( i=0; i<n; i++ ) dv[i] = xy[i] - ans[i];
+    tempd = 1.0;
+    for( i=0; i<mc; i++ ){
+      tempd2 = 0;
+      for( j=0; j<n; j++ ) tempd2 += nf[n*i+j]*dv[j];
+      if( idx[i] == 0 && tempd2 < 0 ){
+        tempd2 = ( d[i] - qp_cond( nf, n, P, ans, i ) )/tempd2;
+        if( tempd2 < tempd ) tempd = tempd2;
+      }
+    }
+    for( i=0; i<n; i++ ) ans[i] += tempd*dv[i];
+    for( i=0; i<mc; i++ )
+      if( idx[i] == 0 && fabs( qp_cond( nf, n, P, ans, i ) - d[i] ) < TOL ){ idx[i] = 1; m++; }
+    /* check if circulation happens due to degeneracy (:150-161) */
+    objv = 0;
+    for( i=0; i<n; i++ ){
+      double s = 0;
+      for( j=0; j<n; j++ ) s += q[n*i+j]*ans[j];
+      objv += 0.5*ans[i]*s + c[i]*ans[i];
+    }
+    {
+      int endflag = 0, h;
+      for( h=0; h<nhist; h++ ){
+        int same = 1;
+        for( i=0; i<mc; i++ ) if( idx[i] != hidx[mc*h+i] ){ same = 0; break; }
+        if( !same ) continue;
+        if( fabs( hmin[h]/objv - 1.0 ) > QP_ASM_TOL ) continue;
+        endflag = 1;
+        break;
+      }
+      if( endflag ) break;
+    }
+    if( nhist == caphist ){
+      caphist *= 2;
+      hidx = (int *)realloc( hidx, sizeof(int)*mc*caphist ); hmin = (double *)realloc( hmin, sizeof(double)*caphist );
+    }
+    for( i=0; i<mc; i++ ) hidx[mc*nhist+i] = idx[i];
+    hmin[nhist++] = objv;
+  }
+  free( qa ); free( xy ); free( cb ); free( dv ); free( hidx ); free( hmin );
+  return iter;
+}
+
+static int vert_rigid(rkfdOracle *o, int doUpRef)
+{
+  const rkfdModel *m = o->m;
+  const int nc = o->nrg, n3 = 3*nc, P = m->pyramid > 0 ? m->pyramid : 8, mc = P*nc;
+  int c, i, r, k;
+  double *A = o->ma, *b = o->mb, *f = o->mf;
+  const double dt = m->dt;
+  double *q = (double *)malloc( sizeof(double)*n3*n3 ), *cv = (double *)malloc( sizeof(double)*n3 );
+  double *nf = (double *)calloc( (size_t)mc*n3, sizeof(double) ), *d = (double *)calloc( mc, sizeof(double) );
+  double *cc = (double *)malloc( sizeof(double)*n3 );
+  int *idx = (int *)malloc( sizeof(int)*mc );
+
+  o->last_nc = nc;
+  /* _rkFDSolverFrictionConstraint (reference src/rkfd_vert.c:73-103); the sine / cosine table of
+   * rkFDCrateSinCosTable( table, P, -pi/P ) (src/rkfd_util.c:199-214, src/rkfd_vert.c:367) */
+  for( c=0; c<nc; c++ ){
+    int j = o->rg[c], ci = o->cci[j];
+    const double off = -M_PI/P, dth = 2.0*M_PI/P;
+    double fric = o->cv_type[j] == RKFD_KF ? m->ci_kf[ci] : m->ci_sf[ci], th = 0.0;
+    fric *= cos( 0.0 + off );
+    for( i=0; i<P; i++, th+=dth ){
+      nf[n3*( P*c+i )+3*c  ] = fric;
+      nf[n3*( P*c+i )+3*c+1] = sin( th + off );
+      nf[n3*( P*c+i )+3*c+2] = cos( th + off );
+    }
+  }
+  /* _rkFDSolverRelationAccForce (:153-189) */
+  contact_system( o );
+  /* _rkFDSolverBiasVel (:193-210) */
+  for( r=0; r<n3; r++ ) b[r] *= dt;
+  for( c=0; c<nc; c++ ){
+    int j = o->rg[c];
+    rel_vel( o, j, &o->cvel[3*j] );
+    for( i=0; i<3; i++ ) b[3*c+i] += v3_dot( &o->cvel[3*j], &o->caxis[9*j+3*i] );
+  }
+  /* _rkFDSolverCompensateDepth (:212-233) */
+  for( c=0; c<nc; c++ ){
+    int j = o->rg[c], ci = o->cci[j];
+    double dd[3], fric = o->cv_type[j] == RKFD_KF ? m->ci_kf[ci] : m->ci_sf[ci], kk = m->ci_k[ci];
+    v3_sub( &o->cx[3*j], &o->crefw[3*j], dd );
+    cc[3*c  ] = b[3*c  ] + kk      * v3_dot( dd, &o->caxis[9*j] );
+    cc[3*c+1] = b[3*c+1] + kk*fric * v3_dot( dd, &o->caxis[9*j+3] );
+    cc[3*c+2] = b[3*c+2] + kk*fric * v3_dot( dd, &o->caxis[9*j+6] );
+  }
+  /* _rkFDSolverQP (:258-283): q = A'A + L, c = A'c */
+  for( i=0; i<n3; i++ )
+    for( k=0; k<n3; k++ ){
+      double s = 0;
+      for( r=0; r<n3; r++ ) s += A[n3*r+i]*A[n3*r+k];
+      q[n3*i+k] = s;
+    }
+  for( i=0; i<n3; i++ ){
+    double s = 0;
+    for( r=0; r<n3; r++ ) s += A[n3*r+i]*cc[r];
+    cv[i] = s;
+  }
+  for( c=0; c<nc; c++ ){
+    int ci = o->cci[o->rg[c]];
+    for( i=0; i<3; i++ ) q[n3*( 3*c+i )+3*c+i] += m->ci_l[ci];
+  }
+  o->last_qp_iter = qp_asm( n3, mc, P, q, cv, nf, d, f, idx );
+  for( r=0; r<n3; r++ ) f[r] /= dt;
+  /* _rkFDSolverSetForce (:286-323): unlike the MLCP plugin, contact state is committed only when doUpRef */
+  for( c=0; c<nc; c++ ){
+    int j = o->rg[c];
+    double *fw = &o->cv_f[3*j];
+    v3_zero( fw );
+    for( i=0; i<3; i++ ) v3_cat( fw, f[3*c+i], &o->caxis[9*j+3*i] );
+    push_wrench( o, j );
+    if( doUpRef ){
+      int flag = 0;
+      for( i=0; i<P; i++ ) if( idx[P*c+i] ){ flag = 1; break; }
+      if( flag ){
+        o->cv_type[j] = RKFD_KF;
+        v3_copy( &o->cpro[3*j], &o->cv_ref[3*j] );
+      } else {
+        o->cv_type[j] = RKFD_SF;      /* rkFDUpdateRefSlide: slide-mode cells are not modelled */
+      }
+    }
+  }
+  free( q ); free( cv ); free( nf ); free( d ); free( cc ); free( idx );
+  return 0;
+}
+
+/* ------------------------------------------------------------------------ */
 /* _rkFDUpdate / _rkFDUpdateRef (reference src/rkfd_sim.c:533-549) */
 static int evaluate(rkfdOracle *o, const double *dis, const double *vel, double *acc, int doUpRef)
 {
@@ -936,8 +1195,9 @@ static int evaluate(rkfdOracle *o, const double *dis, const double *vel, double 
   aba_prepare( o );
   if( o->nel != 0 ) penalty( o, doUpRef );
   if( o->nrg != 0 ){
-    if( m->solver != RKFD_SOLVER_MLCP ) return -1; /* Vert QP / Volume rigid branches: not restated */
-    if( mlcp( o, doUpRef ) < 0 ) return -1;
+    if( m->solver == RKFD_SOLVER_MLCP ){ if( mlcp( o, doUpRef ) < 0 ) return -1; }
+    else if( m->solver == RKFD_SOLVER_VERT ){ if( vert_rigid( o, doUpRef ) < 0 ) return -1; }
+    else return -1;                                 /* Volume plugin: not restated */
     cached = 1;
   }
   /* _rkFDUpdateAcc (reference src/rkfd_sim.c:502-523) */
@@ -1061,4 +1321,20 @@ int rkfdOracleUpdateN(rkfdOracle *o, int nsteps)
   int r = 0, k;
   for( k=0; k<nsteps; k++ ) r |= rkfdOracleUpdate( o );
   return r;
+}
+
+/* number of KKT solves of the last Vert QP (diagnostic) */
+int rkfdOracleLastQPIter(const rkfdOracle *o){ return o->last_qp_iter; }
+
+/* test access to the two numerical building blocks of the Vert rigid branch */
+void rkfdOraclePinvSolve(int n, const double *K, const double *rhs, double *x)
+{
+  double *k = (double *)malloc( sizeof(double)*n*n );
+  memcpy( k, K, sizeof(double)*n*n );
+  sym_pinv_solve( n, k, rhs, x );
+  free( k );
+}
+int rkfdOracleQPASM(int n, int mc, int P, const double *q, const double *c, const double *nf, const double *d, double *ans, int *idx)
+{
+  return qp_asm( n, mc, P, q, c, nf, d, ans, idx );
 }

@@ -44,6 +44,13 @@ void rkfdOracleSetPivot(rkfdOracle *o, const int *type, const double *prev_trq);
 void rkfdOracleUpdateInit(rkfdOracle *o);
 /* rkFDUpdate (reference src/rkfd_sim.c:560-566): RKG stages + committing evaluation */
 int  rkfdOracleUpdate(rkfdOracle *o);
+/* test access to the building blocks of the Vert rigid branch: Moore-Penrose solve of a symmetric
+ * system, and the active-set QP  min x'Qx/2 + c'x  s.t.  nf x >= d  started from unit normal forces
+ * (constraint i acts on the three unknowns of contact i / P) */
+void rkfdOraclePinvSolve(int n, const double *K, const double *rhs, double *x);
+int  rkfdOracleQPASM(int n, int mc, int P, const double *q, const double *c, const double *nf, const double *d, double *ans, int *idx);
+/* number of KKT solves of the last Vert QP (diagnostic) */
+int  rkfdOracleLastQPIter(const rkfdOracle *o);
 /* nsteps x rkFDUpdate */
 int  rkfdOracleUpdateN(rkfdOracle *o, int nsteps);
 /* one dynamics evaluation at the current state: _rkFDUpdate / _rkFDUpdateRef

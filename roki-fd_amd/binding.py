@@ -40,7 +40,7 @@ class RkfdModel(C.Structure):
         ("ncand", C.c_int),
         ("cand_pair", _pi), ("cand_side", _pi), ("cand_vert", _pi),
         ("dt", C.c_double), ("friction_weight", C.c_double),
-        ("max_iter", C.c_int), ("solver", C.c_int),
+        ("max_iter", C.c_int), ("solver", C.c_int), ("pyramid", C.c_int),
     ]
 
     def arr(self, name, n, dtype=None):

@@ -300,6 +300,7 @@ const rkfdModel *rkFDBuildModel(rkFD *fd)
   w->model.dt = fd->prp.dt;
   w->model.friction_weight = fd->prp.friction_weight;
   w->model.max_iter = fd->prp.max_iter;
+  w->model.pyramid = fd->prp.pyramid;
   w->model.solver = p ? p->kind : RKFD_SOLVER_VERT;
   if( rkfdWorldBuild( w ) < 0 ) return NULL;
   return &w->model;

@@ -18,6 +18,7 @@ void rkfdWorldInit(rkfdWorld *w)
   w->model.friction_weight = 100.0;
   w->model.max_iter = 10;
   w->model.solver = RKFD_SOLVER_VERT;
+  w->model.pyramid = 8;
 }
 
 void rkfdWorldDestroy(rkfdWorld *w)
