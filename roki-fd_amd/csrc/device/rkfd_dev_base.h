@@ -294,6 +294,9 @@ typedef struct {
   double *REF;                    /* stick anchors (state): per active slot              */
   double *RTMP;                   /* [maxact*3] copy of REF while the slots are re-assigned; only when ncand > 64 */
   double *CF;                     /* contact forces (output): per active slot              */
+  double *QL, *QW, *QV, *CR;      /* Vert QP (only when the world can have rigid contacts under the Vert plugin):
+                                     [M*(M+1)] Q / its Cholesky factor, [M*(M+1)] L^-1 C', [6M+64] vectors + reduction scratch, [3M] reduced rows */
+  int *CRC;                       /* [M] contact of a reduced constraint row */
   double *MA, *MB, *MF, *PU;      /* MLCP: [M*(M+1)] (ALIASES IST|POOL), [M], [M], [nside*npurow*M] (ALIASES C|PA when it fits) */
   int *act, *typ, *lrg, *lel, *tgt, *cnt;
   int *asl;                       /* [NC] active-contact slot of a candidate              */
@@ -304,7 +307,7 @@ typedef struct {
   unsigned char *PL;              /* [NL*nlevel] ancestor at depth d (MLCP only), one byte each */
 } rkfdLds;
 
-RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int M, int nlevel, int npool, int nfloat, int maxact, int nside, int pu_alias, int npurow)
+RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int M, int nlevel, int npool, int nfloat, int maxact, int nside, int pu_alias, int npurow, int vert_rigid)
 /* must match the byte count computed in rkfd_devmodel.cpp */
 {
   double *d = (double *)base;
@@ -329,10 +332,13 @@ RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int
   L->MB = d; d += M; L->MF = d; d += M;
   /* probe scratch: lives while the contact problem is set up and solved, when C and PA are dead */
   if( pu_alias ) L->PU = L->C; else { L->PU = d; d += nside*npurow*M; }
+  L->QL = d; L->QW = d; L->QV = d; L->CR = d;
+  if( vert_rigid ){ L->QL = d; d += M*( M+1 ); L->QW = d; d += M*( M+1 ); L->QV = d; d += 6*M + RKFD_WAVE; L->CR = d; d += 3*M; }
   int *ip = (int *)d;
   L->act = ip; ip += NC; L->typ = ip; ip += NC; L->asl = ip; ip += NC; L->CIp = ip; ip += NC; L->CFO = ip; ip += NC;
   L->lrg = ip; ip += maxact; L->lel = ip; ip += maxact; L->tgt = ip; ip += 2*maxact; L->cnt = ip; ip += 8;
   L->LI = ip; ip += NL; L->CHI = ip; ip += NL; L->PSL = ip; ip += NL;
+  L->CRC = ip; if( vert_rigid ) ip += M;
   L->PL = (unsigned char *)ip;
 }
 
@@ -356,5 +362,6 @@ typedef struct { double min, pivp; int pivt; } rkfdLaneLink;
 #define CNT_NEL 1
 #define CNT_NTGT 2
 #define CNT_OVF 3
+#define CNT_QPF 4
 
 #endif /* RKFD_DEV_BASE_H */

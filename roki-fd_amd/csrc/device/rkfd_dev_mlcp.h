@@ -70,8 +70,12 @@ RKFD_DEV void rkfd_pgs_registers(const double *Arow, int ld, int nc, int max_ite
  * i.e. no per-column response walks and no second backward sweep; A comes out exactly
  * symmetric.  Output: contact forces CF, committed contact state, and the inputs of the delta
  * sweep (MS slot 1, U slot of float joints). */
-template<bool prof> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L, const double *bv, unsigned long long *pc)
+template<bool prof> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L, const double *bv, bool doUpRef, unsigned long long *pc)
 {
+  /* the Vert plugin's rigid branch (reference src/rkfd_vert.c:325-336) shares the contact system (A, b) and
+   * the way the forces are applied; it differs in the solver (QP instead of PGS), in where the
+   * relaxation enters (the QP objective, not A) and in when contact state is committed */
+  const bool vert = m.solver == RKFD_SOLVER_VERT;
   unsigned long long q0 = prof ? RKFD_CLOCK() : 0ull, q1;
 #define MST(k) do{ if( prof ){ q1 = RKFD_CLOCK(); pc[k] += q1 - q0; q0 = q1; } }while(0)
   const int lane = LANE();
@@ -238,7 +242,7 @@ template<bool prof> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const r
           }
         }
       }
-      if( cr == ck ){
+      if( cr == ck && !vert ){
         /* relaxation on the diagonal */
         const double rl = m.ci_l[RKFD_CI_CI( L.CIp[L.lrg[cr]] )];
         blk[0] += rl; blk[4] += rl; blk[8] += rl;
@@ -254,6 +258,31 @@ template<bool prof> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const r
   }
   SYNC();
   MST(6);
+  if( vert ){
+    const unsigned long long qmask = rkfd_vert_qp( m, L, nc );
+    MST(21);
+    /* _rkFDSolverSetForce (reference src/rkfd_vert.c:286-323): contact state is committed only when doUpRef;
+     * a vertex is in kinetic friction when one of its pyramid faces is active at the solution */
+    if( lane < nc ){
+      const int j = L.lrg[lane];
+      double fw[3] = {0,0,0};
+#pragma unroll
+      for( int i=0; i<3; i++ ){
+        const double fi = L.MF[3*lane+i];
+        fw[0] += fi*L.AX[9*L.asl[j]+3*i]; fw[1] += fi*L.AX[9*L.asl[j]+3*i+1]; fw[2] += fi*L.AX[9*L.asl[j]+3*i+2];
+      }
+      { const int sl_ = L.asl[j]; L.CF[3*sl_] = fw[0]; L.CF[3*sl_+1] = fw[1]; L.CF[3*sl_+2] = fw[2]; }
+      if( doUpRef ){
+        const int P = m.pyramid;
+        if( ( qmask >> ( lane*P ) ) & ( ( 1ull << P ) - 1ull ) ){
+          L.typ[j] = RKFD_KF;
+          { const int ri = RIDX( j ), sl_ = L.asl[j]; L.REF[3*ri] = L.PRO[3*sl_]; L.REF[3*ri+1] = L.PRO[3*sl_+1]; L.REF[3*ri+2] = L.PRO[3*sl_+2]; }
+        } else {
+          L.typ[j] = RKFD_SF;
+        }
+      }
+    }
+  } else {
   /* projected Gauss-Seidel, fixed max_iter sweeps, no warm start (_rkFDSolverMLCP, reference
    * src/rkfd_mlcp.c:190-249), same update order.  lane = contact: each lane keeps the three
    * residuals res = b + A f, forces and inverse diagonals of ITS contact in registers, every lane
@@ -326,6 +355,7 @@ template<bool prof> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const r
     } else {
       L.typ[j] = RKFD_SF;
     }
+  }
   }
   SYNC();
   MST(22);

@@ -44,9 +44,9 @@ template<bool prof> RKFD_DEV int rkfd_evaluate(const rkfdDevModel &m, const rkfd
   rkfd_phase_sweep3<false>( m, L );
   STAMP(3);
   if( L.cnt[CNT_NRG] > 0 ){
-    if( m.solver == RKFD_SOLVER_MLCP ){
+    if( m.solver == RKFD_SOLVER_MLCP || ( m.solver == RKFD_SOLVER_VERT && m.vert_rigid ) ){
       /* contact forces, then their effect on the accelerations (rkChainUpdateCachedABI in the reference) */
-      rkfd_phase_mlcp<prof>( m, L, bv, pc );
+      rkfd_phase_mlcp<prof>( m, L, bv, doUpRef, pc );
       STAMP(4);
       rkfd_phase_sweep3<true>( m, L );
       STAMP(3);
@@ -101,8 +101,8 @@ template<bool prof> RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkf
   const int lane = LANE();
   const int ND = m.ndof, NL = m.nlink, NC = m.ncand;
   rkfdLds L;
-  rkfd_lds_carve( &L, ldsbase, NL, ND, NC, 3*m.maxrg, m.nlevel, m.npool, m.nfloat, m.maxact, m.nside, m.pu_alias, m.npurow );
-  if( lane == 0 ) L.cnt[CNT_OVF] = 0;
+  rkfd_lds_carve( &L, ldsbase, NL, ND, NC, 3*m.maxrg, m.nlevel, m.npool, m.nfloat, m.maxact, m.nside, m.pu_alias, m.npurow, m.vert_rigid );
+  if( lane == 0 ){ L.cnt[CNT_OVF] = 0; L.cnt[CNT_QPF] = 0; }
 
   /* load persistent state */
   double q = 0, qd = 0;
@@ -234,6 +234,7 @@ template<bool prof> RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkf
   if( lane == 0 && errflag ){
     if( err ) *errflag = 1;              /* rigid contact with a solver that has no device path */
     if( L.cnt[CNT_OVF] ) *errflag = 2;   /* more rigid contacts than the configured capacity   */
+    if( L.cnt[CNT_QPF] ) *errflag = 3;   /* the Vert QP ran out of iterations / basis history   */
   }
 }
 

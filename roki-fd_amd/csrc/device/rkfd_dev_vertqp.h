@@ -1,0 +1,296 @@
+/* rkfd_dev_vertqp.h - part of the device code of the batched rkFDUpdate step (see rkfd_device.h):
+ * the Vert plugin's rigid branch - friction pyramids, the objective q = A'A + L, c = A'c and the
+ * active-set QP solver (reference src/rkfd_vert.c:73-103,235-283, src/rkfd_opt_qp.c:43-181).
+ * Included by rkfd_device.h only; compiles for gfx950 and under the lane emulator. */
+#ifndef RKFD_DEV_VERTQP_H
+#define RKFD_DEV_VERTQP_H
+
+/* ------------------------------------------------------------------------ */
+/* wave-cooperative dense kernels on small SPD systems held in LDS (n <= 64, row-major, leading
+ * dimension ld).  All lanes call them (uniform control flow); lane i owns row / entry i. */
+
+/* in-place Cholesky: lower triangle <- factor, diagonal <- 1/L_ii (left-looking; the pivot of
+ * column k travels by v_readlane) */
+RKFD_DEV void rkfd_w_chol(double *Mx, int ld, int n)
+{
+  const int lane = LANE();
+  for( int k=0; k<n; k++ ){
+    double s = 0;
+    if( lane >= k && lane < n ){
+      s = Mx[lane*ld+k];
+      for( int j=0; j<k; j++ ) s -= Mx[lane*ld+j]*Mx[k*ld+j];
+    }
+    const double rinv = RKFD_RCP( sqrt( BCAST( s, k ) ) );
+    if( lane == k ) Mx[k*ld+k] = rinv;
+    else if( lane > k && lane < n ) Mx[lane*ld+k] = s*rinv;
+    LDS_FENCE();
+  }
+}
+/* y = L^-1 b : lane i passes b_i and receives y_i */
+RKFD_DEV double rkfd_w_fwd(const double *Mx, int ld, int n, double bi)
+{
+  const int lane = LANE();
+  double s = bi, yi = 0;
+  for( int j=0; j<n; j++ ){
+    const double yj = BCAST( s, j )*Mx[j*ld+j];
+    if( lane == j ) yi = yj;
+    if( lane > j && lane < n ) s -= Mx[lane*ld+j]*yj;
+  }
+  return yi;
+}
+/* x = L^-T y */
+RKFD_DEV double rkfd_w_back(const double *Mx, int ld, int n, double yi)
+{
+  const int lane = LANE();
+  double s = yi, xi = 0;
+  for( int j=n-1; j>=0; j-- ){
+    const double xj = BCAST( s, j )*Mx[j*ld+j];
+    if( lane == j ) xi = xj;
+    if( lane < j ) s -= Mx[j*ld+lane]*xj;
+  }
+  return xi;
+}
+/* minimum / sum over the wave through a 64-entry LDS scratch (log-depth tree) */
+RKFD_DEV double rkfd_w_min(double v, double *scr)
+{
+  const int lane = LANE();
+  scr[lane] = v;
+  SYNC();
+  for( int h=RKFD_WAVE/2; h>0; h>>=1 ){
+    double a = 0, b = 0;
+    if( lane < h ){ a = scr[lane]; b = scr[lane+h]; }
+    SYNC();
+    if( lane < h ) scr[lane] = a < b ? a : b;
+    SYNC();
+  }
+  const double r = scr[0];
+  SYNC();
+  return r;
+}
+RKFD_DEV double rkfd_w_sum(double v, double *scr)
+{
+  const int lane = LANE();
+  scr[lane] = v;
+  SYNC();
+  for( int h=RKFD_WAVE/2; h>0; h>>=1 ){
+    double a = 0, b = 0;
+    if( lane < h ){ a = scr[lane]; b = scr[lane+h]; }
+    SYNC();
+    if( lane < h ) scr[lane] = a + b;
+    SYNC();
+  }
+  const double r = scr[0];
+  SYNC();
+  return r;
+}
+
+#define RKFD_QP_ASM_TOL 1.0e-8
+#define RKFD_QP_MAXITER 256
+
+/* ------------------------------------------------------------------------ */
+/* The QP of the Vert plugin:  min f'Qf/2 + c'f  s.t.  mu' f_n + sin(th_i) f_1 + cos(th_i) f_2 >= 0
+ * for the P faces of every contact's friction pyramid, solved by the reference's active-set method
+ * from the start point f_n = 1 (src/rkfd_opt_qp.c:43-181).  lane = constraint (P nc <= 64).
+ *
+ * The reference solves each KKT system [ -Q N' ; N 0 ] with a Moore-Penrose routine, because with
+ * three or more faces of one pyramid active (a contact carrying no force sits at the apex with all
+ * P faces active) N has dependent rows.  The structure makes that solve cheap and exact here: Q is
+ * positive definite and rows of different contacts touch different unknowns, so
+ *   - a contact with >= 3 active faces is the equality f_c = 0: its rows are replaced by the three
+ *     unit rows, and the reduced constraint matrix C (<= 3 rows per contact) has full row rank;
+ *   - with Q = LL' factored once:  W = L^-1 C',  (W'W) lambda = W' L^-1 c,  f = L^-T ( W lambda - L^-1 c );
+ *   - the minimum-norm multipliers of the original rows are y = G (G'G)^-1 lambda_c per contact
+ *     (G = its active rows), which is what the pseudo-inverse returns.
+ * In:  L.MA = A (n x n, ld = n+1, without relaxation), L.MB = c_vel (bias incl. compensation).
+ * Out: L.MF = f / dt; returns the mask of the constraints active at the solution (bit = lane). */
+RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel &m, const rkfdLds &L, int nc)
+{
+  const int lane = LANE();
+  const int n = 3*nc, ld = n+1;
+  const int P = m.pyramid, mc = P*nc;
+  double *Q = L.QL, *W = L.QW;
+  double *cv = L.QV, *zv = L.QV + n, *ans = L.QV + 2*n, *xv = L.QV + 3*n, *lam = L.QV + 4*n, *dv = L.QV + 5*n, *scr = L.QV + 6*n;
+  const bool onc = lane < mc;                 /* this lane is a constraint */
+  const int cc = onc ? lane/P : 0;            /* its contact */
+
+  /* pyramid row of this lane (_rkFDSolverFrictionConstraint): ( mu cos(pi/P), sin(th), cos(th) ), th = 2 pi i/P - pi/P */
+  double g0 = 0, g1 = 0, g2 = 0;
+  {
+    const double PI = 3.14159265358979323846;
+    const int jc = L.lrg[cc], ci = RKFD_CI_CI( L.CIp[jc] );
+    const double mu = L.typ[jc] == RKFD_KF ? m.ci_kf[ci] : m.ci_sf[ci];
+    double s0, c0, s1, c1;
+    /* d_sincos takes any argument; the reference evaluates sin/cos of th+offset with th accumulated by additions */
+    double th = 0.0;
+    for( int k=0; k<( onc ? lane - cc*P : 0 ); k++ ) th += 2.0*PI/P;
+    d_sincos( th + ( -PI/P ), &s1, &c1 );
+    d_sincos( 0.0 + ( -PI/P ), &s0, &c0 );
+    if( onc ){ g0 = mu*c0; g1 = s1; g2 = c1; }
+  }
+  /* q = A'A + L (lower triangle and mirror), c = A'c */
+  for( int t0=0; t0<n*n; t0+=RKFD_WAVE ){
+    const int t = t0 + lane, i = t/n, k = t - i*n;
+    if( t < n*n && k <= i ){
+      double s = 0;
+      for( int r=0; r<n; r++ ) s = fma( L.MA[r*ld+i], L.MA[r*ld+k], s );
+      if( i == k ) s += m.ci_l[RKFD_CI_CI( L.CIp[L.lrg[i/3]] )];
+      Q[i*ld+k] = s; Q[k*ld+i] = s;
+    }
+  }
+  if( lane < n ){
+    double s = 0;
+    for( int r=0; r<n; r++ ) s = fma( L.MA[r*ld+lane], L.MB[r], s );
+    cv[lane] = s;
+    ans[lane] = ( lane%3 == 0 ) ? 1.0 : 0.0;           /* _rkFDSolverQPASMInit */
+  }
+  SYNC();
+  rkfd_w_chol( Q, ld, n );
+  {
+    const double zi = rkfd_w_fwd( Q, ld, n, lane < n ? cv[lane] : 0.0 );
+    if( lane < n ) zv[lane] = zi;
+  }
+  SYNC();
+  /* initial active set (_rkFDQPSolveASMInitIndex) */
+  int act = 0;
+  if( onc ){
+    const double cnd = g0*ans[3*cc] + g1*ans[3*cc+1] + g2*ans[3*cc+2];
+    act = fabs( cnd - 0.0 ) < RKFD_DEV_TOL;
+  }
+  unsigned long long hmask = 0; double hobj = 0; int nhist = 0;      /* lane h keeps visited basis h */
+  unsigned long long mask = 0;
+  int fail = 0;
+  for( int iter=0; ; iter++ ){
+    if( iter >= RKFD_QP_MAXITER ){ fail = 1; break; }
+    mask = BALLOT( act );
+    /* reduced, full-rank constraint rows: per contact the active faces themselves (1 or 2), or the three unit rows (>= 3) */
+    const unsigned long long cmask = ( P >= 64 ? ~0ull : ( ( 1ull << P ) - 1ull ) );
+    int roff = 0, kc = 0, rho = 0;
+    int r = 0;
+    for( int c=0; c<nc; c++ ){
+      const int k = __builtin_popcountll( ( mask >> ( c*P ) ) & cmask );
+      if( c < cc ) roff += k < 3 ? k : 3;
+      if( c == cc ) kc = k;
+      r += k < 3 ? k : 3;
+    }
+    if( onc ) rho = __builtin_popcountll( ( mask >> ( cc*P ) ) & cmask & ( ( 1ull << ( lane - cc*P ) ) - 1ull ) );
+    if( onc && act ){
+      if( kc < 3 ){
+        L.CR[3*( roff+rho )] = g0; L.CR[3*( roff+rho )+1] = g1; L.CR[3*( roff+rho )+2] = g2; L.CRC[roff+rho] = cc;
+      } else if( rho < 3 ){
+        L.CR[3*( roff+rho )] = rho == 0 ? 1.0 : 0.0; L.CR[3*( roff+rho )+1] = rho == 1 ? 1.0 : 0.0; L.CR[3*( roff+rho )+2] = rho == 2 ? 1.0 : 0.0;
+        L.CRC[roff+rho] = cc;
+      }
+    }
+    SYNC();
+    /* W = L^-1 C' : lane = reduced row; its right-hand side is zero above row 3c */
+    if( lane < r ){
+      const int c3 = 3*L.CRC[lane];
+      const double h0 = L.CR[3*lane], h1 = L.CR[3*lane+1], h2 = L.CR[3*lane+2];
+      for( int i=0; i<n; i++ ){
+        double s = i == c3 ? h0 : ( i == c3+1 ? h1 : ( i == c3+2 ? h2 : 0.0 ) );
+        for( int j=c3; j<i; j++ ) s -= Q[i*ld+j]*W[j*ld+lane];
+        W[i*ld+lane] = i < c3 ? 0.0 : s*Q[i*ld+i];
+      }
+    }
+    SYNC();
+    /* S = W'W (into the matrix that held A), rhs = W'z */
+    double *S = L.MA;
+    for( int t0=0; t0<r*r; t0+=RKFD_WAVE ){
+      const int t = t0 + lane, a = r > 0 ? t/r : 0, b = t - a*r;
+      if( t < r*r && b <= a ){
+        double s = 0;
+        for( int i=0; i<n; i++ ) s = fma( W[i*ld+a], W[i*ld+b], s );
+        S[a*ld+b] = s; S[b*ld+a] = s;
+      }
+    }
+    double rl = 0;
+    if( lane < r ) for( int i=0; i<n; i++ ) rl = fma( W[i*ld+lane], zv[i], rl );
+    SYNC();
+    rkfd_w_chol( S, ld, r );
+    {
+      const double y = rkfd_w_fwd( S, ld, r, rl );
+      const double l = rkfd_w_back( S, ld, r, y );
+      if( lane < r ) lam[lane] = l;
+    }
+    SYNC();
+    /* f = L^-T ( W lambda - z ) */
+    {
+      double ti = 0;
+      if( lane < n ){
+        for( int a=0; a<r; a++ ) ti = fma( W[lane*ld+a], lam[a], ti );
+        ti -= zv[lane];
+      }
+      const double xi = rkfd_w_back( Q, ld, n, ti );
+      if( lane < n ) xv[lane] = xi;
+    }
+    SYNC();
+    const bool moved = BALLOT( lane < n && !( fabs( xv[lane] - ans[lane] ) < RKFD_DEV_TOL ) ) != 0ull;
+    if( !moved ){
+      if( lane < n ) ans[lane] = xv[lane];
+      /* multipliers of the original rows */
+      double y = 0;
+      if( onc && act ){
+        if( kc < 3 ) y = lam[roff+rho];
+        else {
+          /* y = g . (G'G)^-1 lambda_c over the active faces of this contact */
+          double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0;
+          const double PI = 3.14159265358979323846;
+          double th = 0.0;
+          for( int k=0; k<P; k++, th+=2.0*PI/P ){
+            if( !( ( mask >> ( cc*P+k ) ) & 1ull ) ) continue;
+            double sk, ck;
+            d_sincos( th + ( -PI/P ), &sk, &ck );
+            a00 += g0*g0; a01 += g0*sk; a02 += g0*ck; a11 += sk*sk; a12 += sk*ck; a22 += ck*ck;
+          }
+          const double l0 = lam[roff], l1 = lam[roff+1], l2 = lam[roff+2];
+          const double c00 = a11*a22 - a12*a12, c01 = a02*a12 - a01*a22, c02 = a01*a12 - a02*a11;
+          const double c11 = a00*a22 - a02*a02, c12 = a01*a02 - a00*a12, c22 = a00*a11 - a01*a01;
+          const double det = a00*c00 + a01*c01 + a02*c02;
+          const double u0 = ( c00*l0 + c01*l1 + c02*l2 )/det, u1 = ( c01*l0 + c11*l1 + c12*l2 )/det, u2 = ( c02*l0 + c12*l1 + c22*l2 )/det;
+          y = g0*u0 + g1*u1 + g2*u2;
+        }
+      }
+      SYNC();
+      if( BALLOT( onc && act && y < 0 ) == 0ull ) break;                 /* found the optimal solution */
+      const double ymin = rkfd_w_min( ( onc && act ) ? y : HUGE_VAL, scr );
+      if( onc && act && fabs( y - ymin ) < RKFD_QP_ASM_TOL ) act = 0;
+      continue;
+    }
+    /* STEP2: towards the equality-constrained minimiser as far as the inactive constraints allow */
+    if( lane < n ) dv[lane] = xv[lane] - ans[lane];
+    SYNC();
+    double tq = HUGE_VAL;
+    if( onc && !act ){
+      const double gd = g0*dv[3*cc] + g1*dv[3*cc+1] + g2*dv[3*cc+2];
+      if( gd < 0 ) tq = ( 0.0 - ( g0*ans[3*cc] + g1*ans[3*cc+1] + g2*ans[3*cc+2] ) )/gd;
+    }
+    double tmin = rkfd_w_min( tq, scr );
+    if( !( tmin < 1.0 ) ) tmin = 1.0;
+    if( lane < n ) ans[lane] += tmin*dv[lane];
+    SYNC();
+    if( onc && !act && fabs( g0*ans[3*cc] + g1*ans[3*cc+1] + g2*ans[3*cc+2] - 0.0 ) < RKFD_DEV_TOL ) act = 1;
+    /* circulation check (degeneracy): same basis seen before with the same objective value.
+     * f'Qf/2 = |L'f|^2/2 with the stored factor (diagonal kept as 1/L_ii) */
+    double part = 0;
+    if( lane < n ){
+      double u = ans[lane]/Q[lane*ld+lane];
+      for( int j=lane+1; j<n; j++ ) u = fma( Q[j*ld+lane], ans[j], u );
+      part = 0.5*u*u + cv[lane]*ans[lane];
+    }
+    const double objv = rkfd_w_sum( part, scr );
+    const unsigned long long nmask = BALLOT( act );
+    const bool seen = lane < nhist && hmask == nmask && !( fabs( hobj/objv - 1.0 ) > RKFD_QP_ASM_TOL );
+    if( BALLOT( seen ) != 0ull ){ mask = nmask; break; }
+    if( nhist >= RKFD_WAVE ){ fail = 1; break; }
+    if( lane == nhist ){ hmask = nmask; hobj = objv; }
+    nhist++;
+  }
+  mask = BALLOT( act );
+  if( fail && lane == 0 ) L.cnt[CNT_QPF] = 1;
+  SYNC();
+  if( lane < n ) L.MF[lane] = ans[lane]/m.dt;
+  SYNC();
+  return mask;
+}
+
+#endif /* RKFD_DEV_VERTQP_H */

@@ -30,6 +30,7 @@
 #include "device/rkfd_dev_kinematics.h"
 #include "device/rkfd_dev_sweeps.h"
 #include "device/rkfd_dev_contact.h"
+#include "device/rkfd_dev_vertqp.h"
 #include "device/rkfd_dev_mlcp.h"
 #include "device/rkfd_dev_step.h"
 

@@ -308,6 +308,10 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   for( int j=0; j<NC; j++ ){
     if( m->ci_type[cci[j]] == RKFD_CONTACT_RIGID ) has_rigid = true; else has_elastic = true;
   }
+  dm.pyramid = m->pyramid > 0 ? m->pyramid : 8;
+  dm.vert_rigid = ( m->solver == RKFD_SOLVER_VERT && has_rigid && max_rigid > 0 ) ? 1 : 0;
+  if( dm.vert_rigid && (size_t)dm.pyramid*max_rigid > RKFD_WAVE )
+    FAIL( "Vert plugin: pyramid faces x rigid contact capacity exceeds 64 (one constraint per lane)" );
   int maxact = has_elastic ? ( NC < 16 ? NC : 16 ) : 0;
   if( has_rigid && max_rigid > maxact ) maxact = max_rigid < NC ? max_rigid : NC;
   if( NC > 0 && maxact < 1 ) maxact = 1;
@@ -370,8 +374,9 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
     size_t stage = (size_t)14*NL + pool;                         /* inertia staging + Ia pool ...   */
     if( M*(M+1) > stage ) stage = M*(M+1);                       /* ... shared with the MLCP matrix */
     const size_t dbl = (size_t)3*ND + (size_t)NL*( 5*6 + 4 ) + stage + (size_t)48*nfloat
-                     + (size_t)maxact*( 24 + ( NC > RKFD_WAVE ? 3 : 0 ) ) + 2*M + ( dm.pu_alias ? 0 : (size_t)nside*npurow*M );
-    const size_t ints = (size_t)5*NC + (size_t)4*maxact + 8 + 3*(size_t)NL     /* act typ asl CIp CFO, lrg lel tgt, cnt, LI CHI PSL */
+                     + (size_t)maxact*( 24 + ( NC > RKFD_WAVE ? 3 : 0 ) ) + 2*M + ( dm.pu_alias ? 0 : (size_t)nside*npurow*M )
+                     + ( dm.vert_rigid ? 2*M*( M+1 ) + 6*M + RKFD_WAVE + 3*M : 0 );   /* Vert QP: QL, QW, QV, CR */
+    const size_t ints = (size_t)5*NC + (size_t)4*maxact + 8 + 3*(size_t)NL + ( dm.vert_rigid ? M : 0 )     /* act typ asl CIp CFO, lrg lel tgt, cnt, LI CHI PSL */
                       + ( max_rigid > 0 ? ( (size_t)NL*( nlevel+3 ) + 3 )/4 : 0 );   /* PL (bytes) */
     out->lds_bytes = dbl*sizeof(double) + ints*sizeof(int);
     out->lds_bytes = ( out->lds_bytes + 15 ) & ~(size_t)15;

@@ -98,15 +98,15 @@ def test_contact_capacity_overflow_is_reported(R):
     assert b2.status() == 0
 
 
-def test_vert_plugin_reports_rigid_contact(R):
-    """the Vert plugin's rigid QP branch has no device path: a rigid contact under Vert is an error
-    status, never a silent wrong answer"""
+def test_vert_plugin_without_rigid_capacity_reports_rigid_contact(R):
+    """a batch created with no rigid-contact capacity (max_rigid = 0) has no rigid solver set up: a rigid
+    contact is then an error status, never a silent wrong answer"""
     w = R.World(solver=R.SOLVER_VERT)
     w.contact_info(os.path.join(R.scenarios.MODELS, "contactinfo.ztk"))
     w.reg_file(os.path.join(R.scenarios.MODELS, "box.ztk")); w.reg_file(os.path.join(R.scenarios.MODELS, "floor.ztk"))
-    b = R.Batch(w, 1, max_rigid=4)
+    b = R.Batch(w, 1, max_rigid=0)
     b.set_state(np.array([[0, 0, 0.0499, 0, 0, 0.0]]), np.zeros((1, 6))); b.update_init()
-    assert b.status() == 1
+    assert b.status() != 0
 
 
 def test_batch_of_one_and_world_without_contacts(R, oracle_cls):
@@ -243,3 +243,44 @@ def test_elastic_and_rigid_contacts_in_one_evaluation(R, oracle_cls):
         assert _rel(d[i], od) < RTOL and _rel(v[i], ov) < RTOL and _rel(a[i], oa) < RTOL
         assert _rel(f[i], of * (oact[:, None] != 0)) < RTOL
     assert {int(t) for t in cit[cci]} == {R.CONTACT_RIGID, R.CONTACT_ELASTIC}       # both kinds of pairs are registered
+
+
+def _vert_box_world(R):
+    M = R.scenarios.MODELS
+    w = R.World(solver=R.SOLVER_VERT); w.contact_info(os.path.join(M, "contactinfo.ztk"))
+    w.reg_file(os.path.join(M, "box.ztk")); w.reg_file(os.path.join(M, "floor.ztk"))
+    return w
+
+
+def test_vert_plugin_rigid_qp_box(R, oracle_cls):
+    """the reference's DEFAULT plugin with a rigid pair: friction pyramids + active-set QP
+    (reference src/rkfd_vert.c:258-336, src/rkfd_opt_qp.c).  A box dropped flat / tilted / sliding onto
+    the rigid floor: apex-degenerate bases (all faces of a pyramid active), slipping and sticking
+    vertices, make and break; 40 steps vs the oracle, whose KKT solves use a generic pseudo-inverse"""
+    w = _vert_box_world(R)
+    B = 8
+    dis = np.zeros((B, 6)); vel = np.zeros((B, 6))
+    dis[:, 2] = 0.0499
+    dis[1:, 3:6] = np.random.default_rng(1).uniform(-0.3, 0.3, (B - 1, 3))
+    vel[:, 0] = np.linspace(0.0, 0.4, B); vel[2:, 3:6] = np.random.default_rng(2).uniform(-1, 1, (B - 2, 3))
+    m = w.model.contents
+    for i in range(1, B):
+        dis[i, 2] -= R.scenarios.lowest_vertex_z(m, dis[i], 0) + 0.0001
+    b = R.Batch(w, B, max_rigid=8)
+    b.set_state(dis, vel); b.update_init()
+    orc = []
+    for i in range(B):
+        o = oracle_cls(w.model); o.set_state(dis[i], vel[i]); o.update_init(); orc.append(o)
+    seen = kf = 0
+    for chunk in range(4):
+        b.update(10)
+        assert b.status() == 0
+        d, v, a = b.get_state(); act, typ, ref, f = b.get_contact()
+        for i, o in enumerate(orc):
+            o.update_n(10)
+            od, ov, oa = o.get_state(); oact, otyp, _, of = o.get_contact()
+            assert (act[i] == oact).all() and (typ[i] == otyp * (oact != 0)).all(), (i, chunk)
+            assert _rel(d[i], od) < 1e-8 and _rel(v[i], ov) < 1e-8 and _rel(a[i], oa) < 1e-7, (i, chunk)
+            assert _rel(f[i], of * (oact[:, None] != 0)) < 1e-7, (i, chunk)
+            seen += int(oact.sum()); kf += int((otyp[oact != 0] == R.KF).sum())
+    assert seen > 20 and kf > 0
