@@ -48,7 +48,10 @@ int main(int argc, char *argv[])
   rkFDODE2Assign( &fd, Regular );
   rkFDODE2AssignRegular( &fd, RKG );
   rkFDPrpSetDT( &fd, DT );
-  rkFDSetSolver( &fd, MLCP );
+  /* rkFDCreate selects the Vert plugin (reference src/rkfd_sim.c:52); the reference's drivers switch
+   * with rkFDSetSolver( &fd, MLCP ) / ( &fd, Vert ) - the fourth argument picks one here */
+  if( argc > 4 && strcmp( argv[4], "vert" ) == 0 ) rkFDSetSolver( &fd, Vert );
+  else rkFDSetSolver( &fd, MLCP );
 
   rkFDUpdateInit( &fd );
   if( rkFDStatus( &fd ) != 0 ) return 2;

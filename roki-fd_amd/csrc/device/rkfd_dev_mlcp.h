@@ -70,12 +70,12 @@ RKFD_DEV void rkfd_pgs_registers(const double *Arow, int ld, int nc, int max_ite
  * i.e. no per-column response walks and no second backward sweep; A comes out exactly
  * symmetric.  Output: contact forces CF, committed contact state, and the inputs of the delta
  * sweep (MS slot 1, U slot of float joints). */
-template<bool prof> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L, const double *bv, bool doUpRef, unsigned long long *pc)
+template<bool prof, bool vqp> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L, const double *bv, bool doUpRef, unsigned long long *pc)
 {
   /* the Vert plugin's rigid branch (reference src/rkfd_vert.c:325-336) shares the contact system (A, b) and
    * the way the forces are applied; it differs in the solver (QP instead of PGS), in where the
    * relaxation enters (the QP objective, not A) and in when contact state is committed */
-  const bool vert = m.solver == RKFD_SOLVER_VERT;
+  const bool vert = vqp && m.solver == RKFD_SOLVER_VERT;     /* vqp: this kernel variant carries the QP code at all */
   unsigned long long q0 = prof ? RKFD_CLOCK() : 0ull, q1;
 #define MST(k) do{ if( prof ){ q1 = RKFD_CLOCK(); pc[k] += q1 - q0; q0 = q1; } }while(0)
   const int lane = LANE();

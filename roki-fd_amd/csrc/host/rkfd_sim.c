@@ -112,7 +112,13 @@ static bool solver_init(rkFDSolver *s)
   rkFDSolverPrpAMD *p = (rkFDSolverPrpAMD *)s->prp;
   if( im->batch ){ rkfdBatchDestroy( im->batch ); im->batch = NULL; }
   if( !rkFDBuildModel( fd ) ) return false;
-  im->batch = rkfdBatchCreate( &im->world.model, 1, 0, p->max_rigid );
+  {
+    /* rigid contact capacity of the single-instance path: 16 vertices; under the Vert plugin one
+     * pyramid face per lane bounds it to 64 / pyramid (8 for the default 8-face pyramid) */
+    int mr = p->max_rigid;
+    if( p->kind == RKFD_SOLVER_VERT && fd->prp.pyramid > 0 && mr*fd->prp.pyramid > 64 ) mr = 64/fd->prp.pyramid;
+    im->batch = rkfdBatchCreate( &im->world.model, 1, 0, mr );
+  }
   if( !im->batch ){
     fprintf( stderr, "rkfd: %s\n", rkfdHipLastError() );
     return false;

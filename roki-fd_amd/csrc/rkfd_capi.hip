@@ -17,24 +17,24 @@ static thread_local char g_err[512] = "";
  * Register budget: 256 VGPRs = two waves per SIMD = eight instances per CU.  A third wave per
  * SIMD (168 VGPRs, LDS permitting) was measured slower: at two waves the VALU is already ~55 %
  * busy and the tighter budget spills (~230 B of scratch per lane). */
-extern "C" __global__ void __launch_bounds__(RKFD_WAVE, 2)
-rkfd_step_kernel(rkfdDevModel m, rkfdDevState st, int mode, int nsteps, int *errflag)
-{
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int b = blockIdx.x;
-  if( b >= st.batch ) return;
-  rkfd_instance<false>( m, st, b, lds, mode, nsteps, errflag );
+#define RKFD_KERNEL(name, prof, vqp) \
+extern "C" __global__ void __launch_bounds__(RKFD_WAVE, 2) \
+name(rkfdDevModel m, rkfdDevState st, int mode, int nsteps, int *errflag) \
+{ \
+  extern __shared__ __attribute__((aligned(16))) char lds[]; \
+  const int b = blockIdx.x; \
+  if( b >= st.batch ) return; \
+  rkfd_instance<prof, vqp>( m, st, b, lds, mode, nsteps, errflag ); \
 }
+RKFD_KERNEL( rkfd_step_kernel, false, false )
+/* the variant that also carries the Vert plugin's QP (worlds with rigid pairs under the Vert plugin);
+ * kept apart so that its code and registers do not weigh on the MLCP / penalty kernel */
+RKFD_KERNEL( rkfd_step_kernel_vqp, false, true )
+/* diagnostic instantiations with in-kernel phase stamps (rkfdBatchProfile) */
+RKFD_KERNEL( rkfd_step_kernel_prof, true, false )
+RKFD_KERNEL( rkfd_step_kernel_prof_vqp, true, true )
 
-/* diagnostic instantiation with in-kernel phase stamps (rkfdBatchProfile) */
-extern "C" __global__ void __launch_bounds__(RKFD_WAVE, 2)
-rkfd_step_kernel_prof(rkfdDevModel m, rkfdDevState st, int mode, int nsteps, int *errflag)
-{
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int b = blockIdx.x;
-  if( b >= st.batch ) return;
-  rkfd_instance<true>( m, st, b, lds, mode, nsteps, errflag );
-}
+typedef void (*rkfdKernel)(rkfdDevModel, rkfdDevState, int, int, int *);
 
 struct rkfdBatch {
   int device, batch, nlink, ndof, ncand;
@@ -44,6 +44,7 @@ struct rkfdBatch {
   rkfdDevState st;
   int *d_err;
   size_t lds_bytes;
+  rkfdKernel kern, kern_prof;
 };
 
 extern "C" const char *rkfdHipLastError(void){ return g_err; }
@@ -108,9 +109,11 @@ extern "C" rkfdBatch *rkfdBatchCreate(const rkfdModel *m, int batch, int device,
   bad |= dalloc( &b->d_err, 1 );
   b->st.dbg = NULL; b->st.dbg_stride = 0; b->st.batch = batch; b->st.prof = NULL;
   if( bad ){ rkfdBatchDestroy( b ); return NULL; }
+  b->kern = b->dm.vert_rigid ? rkfd_step_kernel_vqp : rkfd_step_kernel;
+  b->kern_prof = b->dm.vert_rigid ? rkfd_step_kernel_prof_vqp : rkfd_step_kernel_prof;
   if( b->lds_bytes > 64*1024 ){
-    hipError_t e = hipFuncSetAttribute( (const void *)rkfd_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes );
-    if( e == hipSuccess ) e = hipFuncSetAttribute( (const void *)rkfd_step_kernel_prof, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes );
+    hipError_t e = hipFuncSetAttribute( (const void *)b->kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes );
+    if( e == hipSuccess ) e = hipFuncSetAttribute( (const void *)b->kern_prof, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes );
     if( e != hipSuccess ){ SETERR( "hipFuncSetAttribute(LDS=%zu) failed: %s", b->lds_bytes, hipGetErrorString( e ) ); rkfdBatchDestroy( b ); return NULL; }
   }
   return b;
@@ -221,12 +224,8 @@ static int launch(rkfdBatch *b, int mode, int nsteps, void *stream)
 {
   if( !b ){ SETERR( "null batch" ); return -1; }
   HIPCHK( hipSetDevice( b->device ), -1 );
-  if( b->st.prof )
-    hipLaunchKernelGGL( rkfd_step_kernel_prof, dim3( b->batch ), dim3( RKFD_WAVE ), b->lds_bytes, (hipStream_t)stream,
-                        b->dm, b->st, mode, nsteps, b->d_err );
-  else
-    hipLaunchKernelGGL( rkfd_step_kernel, dim3( b->batch ), dim3( RKFD_WAVE ), b->lds_bytes, (hipStream_t)stream,
-                        b->dm, b->st, mode, nsteps, b->d_err );
+  hipLaunchKernelGGL( b->st.prof ? b->kern_prof : b->kern, dim3( b->batch ), dim3( RKFD_WAVE ), b->lds_bytes, (hipStream_t)stream,
+                      b->dm, b->st, mode, nsteps, b->d_err );
   HIPCHK( hipGetLastError(), -1 );
   return 0;
 }

@@ -73,7 +73,7 @@ extern "C" int rkfd_emu_run(const rkfdModel *m, int max_rigid, rkfdDevState *st,
     std::memset( lds.data(), 0, lds.size() );
     std::vector<std::thread> th;
     for( int l=0; l<64; l++ )
-      th.emplace_back( [&, l](){ t_lane = l; rkfd_instance<false>( h.dm, *st, b, lds.data(), mode, nsteps, &errflag ); } );
+      th.emplace_back( [&, l](){ t_lane = l; rkfd_instance<false, true>( h.dm, *st, b, lds.data(), mode, nsteps, &errflag ); } );
     for( auto &t : th ) t.join();
   }
   rkfd_devmodel_free( &h );
