@@ -30,9 +30,10 @@ const char *rkfdHipLastError(void);
 /* Creates device state for `batch` instances of world `m` on `device`.
  * Replaces, for the whole batch: rkFDCreate + rkFDChainReg* + rkFDUpdateInit's allocations
  * (reference src/rkfd_sim.c:32-54,188-235,552-558; rkFDCDUpdateInit src/rkfd_cd.c:22-31;
- * plugin _init src/rkfd_mlcp.c:312-325).  max_rigid = capacity of rigid contact vertices
- * solved per instance (3*max_rigid <= 128); exceeding it at run time is reported as an error
- * by rkfdBatchStatus. */
+ * plugin _init src/rkfd_mlcp.c:312-325, src/rkfd_vert.c:350-368).  max_rigid = capacity of rigid
+ * contact vertices solved per instance (MLCP plugin: 3*max_rigid <= 128; Vert plugin: one pyramid
+ * face per lane, pyramid*max_rigid <= 64); exceeding it at run time is reported as an error by
+ * rkfdBatchStatus. */
 rkfdBatch *rkfdBatchCreate(const rkfdModel *m, int batch, int device, int max_rigid);
 void rkfdBatchDestroy(rkfdBatch *b);
 
@@ -65,8 +66,9 @@ int rkfdBatchUpdate(rkfdBatch *b, int nsteps, void *stream);
  * (reference src/rkfd_sim.c:533-549): fills acc and the contact forces.  Asynchronous. */
 int rkfdBatchEval(rkfdBatch *b, int doUpRef, void *stream);
 /* waits for the stream-ordered work, then reports device-side conditions:
- * 0 ok, 1 rigid contact met with a solver that has no device path (Vert QP / Volume),
- * 2 rigid-contact capacity exceeded; negative: HIP error */
+ * 0 ok, 1 rigid contact met without a rigid solver set up (Volume plugin, or max_rigid = 0),
+ * 2 rigid-contact capacity exceeded, 3 the Vert plugin's QP ran out of iterations (256) or of
+ * basis history (64); negative: HIP error */
 int rkfdBatchStatus(rkfdBatch *b, void *stream);
 
 /* diagnostic launch: nsteps x rkFDUpdate with in-kernel phase stamps.  out is [batch][24]

@@ -157,6 +157,14 @@ def config4(batch=4096, model="humanoid30.ztk", max_rigid=8):
     return dict(name="config4_humanoid_mlcp", world=w, dis=dis, vel=vel, max_rigid=max_rigid, steps=1000)
 
 
+def config4_vert(batch=4096, model="humanoid30.ztk"):
+    """config 4 under the reference's DEFAULT plugin: 30-DoF humanoid on flat ground, RIGID ground contact,
+    Vert plugin (8-face friction pyramids + active-set QP).  Capacity 8 contact vertices = 64 pyramid faces,
+    one per lane."""
+    w, dis, vel = _humanoid(batch, "contact_rigid.ztk", B.SOLVER_VERT, 0x5EED0004, model)
+    return dict(name="config4_humanoid_vert_qp", world=w, dis=dis, vel=vel, max_rigid=8, steps=1000)
+
+
 def config5(batch=4096, max_rigid=24):
     """config 4 + clutter: four small boxes resting on the floor around the feet; box-floor and
     box-foot pairs are RIGID ('ground body' / 'body body' of contactinfo.ztk), box-box pairs are
@@ -230,4 +238,4 @@ def arm_press(batch=8, root="fixed", with_box=True, seed=0x5EED00A1):
     return dict(name=f"arm_press_{root}{'_box' if with_box else ''}", world=w, dis=dis, vel=vel, motor_in=inp, max_rigid=12, steps=200)
 
 
-CONFIGS = {"config1": config1, "config1b": config1_rigid, "config2": config2, "config3": config3, "config4": config4, "config5": config5}
+CONFIGS = {"config1": config1, "config1b": config1_rigid, "config2": config2, "config3": config3, "config4": config4, "config4v": config4_vert, "config5": config5}

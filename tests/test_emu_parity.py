@@ -63,3 +63,30 @@ def test_emulated_arm_press_matches_oracle(R, oracle_cls, root, with_box):
         oact, otyp, oref, of = o.get_contact()
         assert (act[i] == oact).all()
         assert np.abs(f[i] - of).max() / max(1.0, np.abs(of).max()) < 1e-9
+
+
+def test_emulated_vert_rigid_qp_matches_oracle(R, oracle_cls):
+    """the Vert plugin's rigid branch (friction pyramids + active-set QP) under the lane emulator: a tilted box
+    landing on the rigid floor (first steps run through apex-degenerate bases with >= 3 faces of a pyramid
+    active) vs the oracle, whose KKT solves use a generic pseudo-inverse"""
+    import os
+    M = R.scenarios.MODELS
+    w = R.World(solver=R.SOLVER_VERT); w.contact_info(os.path.join(M, "contactinfo.ztk"))
+    w.reg_file(os.path.join(M, "box.ztk")); w.reg_file(os.path.join(M, "floor.ztk"))
+    dis = np.zeros((2, 6)); vel = np.zeros((2, 6))
+    dis[:, 2] = 0.0499; dis[1, 3:6] = (0.01, 0.02, 0.3); vel[:, 0] = (0.0, 0.05)
+    eb = EmuBatch(w, 2, max_rigid=8)
+    eb.set_state(dis, vel); eb.update_init(); eb.update(8)
+    assert eb.status() == 0
+    d, v, a = eb.get_state(); act, typ, ref, f = eb.get_contact()
+    iters = 0
+    for i in range(2):
+        o = oracle_cls(w.model); o.set_state(dis[i], vel[i]); o.update_init()
+        for _ in range(8):
+            o.update(); iters = max(iters, o.last_qp_iter())
+        od, ov, oa = o.get_state(); oact, otyp, _, of = o.get_contact()
+        assert (act[i] == oact).all() and (typ[i] == otyp * (oact != 0)).all()
+        for x, y in ((d[i], od), (v[i], ov), (a[i], oa)):
+            assert np.abs(x - y).max() / max(1.0, np.abs(y).max()) < 1e-9
+        assert np.abs(f[i] - of * (oact[:, None] != 0)).max() / max(1.0, np.abs(of).max()) < 1e-8
+    assert iters >= 4          # the run did go through multi-iteration (degenerate) QPs

@@ -284,3 +284,29 @@ def test_vert_plugin_rigid_qp_box(R, oracle_cls):
             assert _rel(f[i], of * (oact[:, None] != 0)) < 1e-7, (i, chunk)
             seen += int(oact.sum()); kf += int((otyp[oact != 0] == R.KF).sum())
     assert seen > 20 and kf > 0
+
+
+def test_vert_plugin_rigid_qp_humanoid(R, oracle_cls):
+    """config 4 under the default plugin: up to 8 sole vertices = 24 unknowns and 64 pyramid faces (one per
+    lane) in the QP; 160 steps (lift-off, touch-down, rocking on 2-5 vertices) vs the oracle, whose KKT
+    systems go up to 88 x 88 through the generic pseudo-inverse"""
+    B = 8
+    sc = R.scenarios.config4_vert(batch=B)
+    b = R.Batch(sc["world"], B, max_rigid=sc["max_rigid"])
+    b.set_state(sc["dis"], sc["vel"]); b.update_init()
+    orc = []
+    for i in range(B):
+        o = oracle_cls(sc["world"].model); o.set_state(sc["dis"][i], sc["vel"][i]); o.update_init(); orc.append(o)
+    seen = 0
+    for chunk in range(4):
+        b.update(40)
+        assert b.status() == 0
+        d, v, a = b.get_state(); act, typ, ref, f = b.get_contact()
+        for i, o in enumerate(orc):
+            o.update_n(40)
+            od, ov, oa = o.get_state(); oact, otyp, _, of = o.get_contact()
+            assert (act[i] == oact).all() and (typ[i] == otyp * (oact != 0)).all(), (i, chunk)
+            assert _rel(d[i], od) < 1e-9 and _rel(v[i], ov) < 1e-9 and _rel(a[i], oa) < 1e-7, (i, chunk)
+            assert _rel(f[i], of * (oact[:, None] != 0)) < 1e-7, (i, chunk)
+            seen += int(oact.sum())
+    assert seen > 40
