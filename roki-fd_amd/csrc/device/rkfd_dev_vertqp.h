@@ -150,6 +150,17 @@ RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel &m, const rkfdLds &L
     if( lane < n ) zv[lane] = zi;
   }
   SYNC();
+  /* L^-1, kept transposed in the strict upper triangle of the factor's matrix (its diagonal is the
+   * stored 1/L_ii): column j by forward substitution, lane = column */
+  if( lane < n ){
+    const int j = lane;
+    for( int i=j+1; i<n; i++ ){
+      double s = -Q[i*ld+j]*Q[j*ld+j];
+      for( int k=j+1; k<i; k++ ) s -= Q[i*ld+k]*Q[j*ld+k];      /* L[i][k] * Linv[k][j] (stored at [j][k]) */
+      Q[j*ld+i] = s*Q[i*ld+i];
+    }
+  }
+  SYNC();
   /* initial active set (_rkFDQPSolveASMInitIndex) */
   int act = 0;
   if( onc ){
@@ -182,14 +193,16 @@ RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel &m, const rkfdLds &L
       }
     }
     SYNC();
-    /* W = L^-1 C' : lane = reduced row; its right-hand side is zero above row 3c */
+    /* W = L^-1 C' : lane = reduced row, a combination of three columns of L^-1 (zero above row 3c) */
     if( lane < r ){
       const int c3 = 3*L.CRC[lane];
       const double h0 = L.CR[3*lane], h1 = L.CR[3*lane+1], h2 = L.CR[3*lane+2];
       for( int i=0; i<n; i++ ){
-        double s = i == c3 ? h0 : ( i == c3+1 ? h1 : ( i == c3+2 ? h2 : 0.0 ) );
-        for( int j=c3; j<i; j++ ) s -= Q[i*ld+j]*W[j*ld+lane];
-        W[i*ld+lane] = i < c3 ? 0.0 : s*Q[i*ld+i];
+        /* Linv[i][j] for j = c3, c3+1, c3+2 (lower triangular; diagonal = stored reciprocal) */
+        const double l0 = i > c3   ? Q[( c3   )*ld+i] : ( i == c3   ? Q[i*ld+i] : 0.0 );
+        const double l1 = i > c3+1 ? Q[( c3+1 )*ld+i] : ( i == c3+1 ? Q[i*ld+i] : 0.0 );
+        const double l2 = i > c3+2 ? Q[( c3+2 )*ld+i] : ( i == c3+2 ? Q[i*ld+i] : 0.0 );
+        W[i*ld+lane] = l0*h0 + l1*h1 + l2*h2;
       }
     }
     SYNC();
