@@ -37,6 +37,7 @@ def lib():
         L.rkfdOracleUpdate.argtypes = [vp]
         L.rkfdOracleUpdateN.argtypes = [vp, C.c_int]
         L.rkfdOracleLastQPIter.argtypes = [vp]
+        L.rkfdOracleQPCycleStops.argtypes = [vp]
         L.rkfdOracleEval.argtypes = [vp, C.c_int]
         L.rkfdOracleGetLinkFrames.argtypes = [vp, vp, vp]
         L.rkfdOracleGetLinkVelAcc.argtypes = [vp, vp, vp]
@@ -113,6 +114,9 @@ class Oracle:
 
     def last_qp_iter(self):
         return self._L.rkfdOracleLastQPIter(self._o)
+
+    def qp_cycle_stops(self):
+        return self._L.rkfdOracleQPCycleStops(self._o)
 
     def update(self):
         return self._L.rkfdOracleUpdate(self._o)

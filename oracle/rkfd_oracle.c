@@ -132,6 +132,7 @@ struct rkfdOracle {
   int mcap; double *ma, *mb, *mt, *mf;
   int last_nc;
   int last_qp_iter;      /* KKT solves of the last Vert QP (diagnostic) */
+  int qp_cycle_stops;    /* how many Vert QPs so far were ended by the circulation check (diagnostic) */
   /* RKG workspace */
   double *k_v[4], *k_a[4], *xd, *xv, *tv, *ta;
 };
@@ -1078,7 +1079,7 @@ static int qp_asm(int n, int mc, int P, const double *q, const double *c, const 
         endflag = 1;
         break;
       }
-      if( endflag ) break;
+      if( endflag ){ iter = -iter; break; }      /* (negative count: stopped by the circulation check, not at the optimum) */
     }
     if( nhist == caphist ){
       caphist *= 2;
@@ -1152,6 +1153,7 @@ static int vert_rigid(rkfdOracle *o, int doUpRef)
     for( i=0; i<3; i++ ) q[n3*( 3*c+i )+3*c+i] += m->ci_l[ci];
   }
   o->last_qp_iter = qp_asm( n3, mc, P, q, cv, nf, d, f, idx );
+  if( o->last_qp_iter < 0 ){ o->last_qp_iter = -o->last_qp_iter; o->qp_cycle_stops++; }
   for( r=0; r<n3; r++ ) f[r] /= dt;
   /* _rkFDSolverSetForce (:286-323): unlike the MLCP plugin, contact state is committed only when doUpRef */
   for( c=0; c<nc; c++ ){
@@ -1325,6 +1327,7 @@ int rkfdOracleUpdateN(rkfdOracle *o, int nsteps)
 
 /* number of KKT solves of the last Vert QP (diagnostic) */
 int rkfdOracleLastQPIter(const rkfdOracle *o){ return o->last_qp_iter; }
+int rkfdOracleQPCycleStops(const rkfdOracle *o){ return o->qp_cycle_stops; }
 
 /* test access to the two numerical building blocks of the Vert rigid branch */
 void rkfdOraclePinvSolve(int n, const double *K, const double *rhs, double *x)
@@ -1336,5 +1339,5 @@ void rkfdOraclePinvSolve(int n, const double *K, const double *rhs, double *x)
 }
 int rkfdOracleQPASM(int n, int mc, int P, const double *q, const double *c, const double *nf, const double *d, double *ans, int *idx)
 {
-  return qp_asm( n, mc, P, q, c, nf, d, ans, idx );
+  return abs( qp_asm( n, mc, P, q, c, nf, d, ans, idx ) );
 }

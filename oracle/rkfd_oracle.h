@@ -51,6 +51,8 @@ void rkfdOraclePinvSolve(int n, const double *K, const double *rhs, double *x);
 int  rkfdOracleQPASM(int n, int mc, int P, const double *q, const double *c, const double *nf, const double *d, double *ans, int *idx);
 /* number of KKT solves of the last Vert QP (diagnostic) */
 int  rkfdOracleLastQPIter(const rkfdOracle *o);
+/* how many Vert QPs so far were ended by the circulation check instead of at the optimum (diagnostic) */
+int  rkfdOracleQPCycleStops(const rkfdOracle *o);
 /* nsteps x rkFDUpdate */
 int  rkfdOracleUpdateN(rkfdOracle *o, int nsteps);
 /* one dynamics evaluation at the current state: _rkFDUpdate / _rkFDUpdateRef
