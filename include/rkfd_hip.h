@@ -71,10 +71,10 @@ int rkfdBatchEval(rkfdBatch *b, int doUpRef, void *stream);
  * basis history (64); negative: HIP error */
 int rkfdBatchStatus(rkfdBatch *b, void *stream);
 
-/* diagnostic launch: nsteps x rkFDUpdate with in-kernel phase stamps.  out is [batch][24]
-  * (RKFD_NPROF = 24 per instance) shader-clock cycles: kinematics, collision+penalty, sweep 2, sweep 3 (both
- * passes), MLCP, tail, MLCP matrix, whole launch, then finer stamps inside sweep 2 (8-13), MLCP (14, 15, 21-23)
- * and kinematics (16-20); tools/prof_phases.py names them.
+/* diagnostic launch: nsteps x rkFDUpdate with in-kernel phase stamps.  out is [batch][32]
+  * (RKFD_NPROF = 32 per instance) shader-clock cycles: kinematics, collision+penalty, sweep 2, sweep 3 (both
+ * passes), MLCP, tail, MLCP matrix, whole launch, then finer stamps inside sweep 2 (8-13), MLCP (14, 15, 21-23),
+ * kinematics (16-20) and the Vert QP (24-30); tools/prof_phases.py names them.
  * Synchronous; not for timing runs (the stamps serialise the phases). */
 int rkfdBatchProfile(rkfdBatch *b, int nsteps, unsigned long long *out);
 

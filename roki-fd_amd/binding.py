@@ -241,8 +241,8 @@ class Batch:
         return r
 
     def profile(self, nsteps=1):
-        """diagnostic launch with in-kernel phase stamps: [B, 8] cycles"""
-        out = np.zeros((self.B, 24), dtype=np.uint64)
+        """diagnostic launch with in-kernel phase stamps: [B, 32] cycles (RKFD_NPROF)"""
+        out = np.zeros((self.B, 32), dtype=np.uint64)
         self._chk(self._L.rkfdBatchProfile(self._b, nsteps, _ptr(out)))
         return out
 

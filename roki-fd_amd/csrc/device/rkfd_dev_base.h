@@ -115,7 +115,7 @@ template<class T> RKFD_DEV const T *rkfd_reload(const T *p){ asm volatile( "" : 
 #endif
 
 /* optional in-kernel phase timing (diagnostic launches only: rkfdBatchProfile) */
-#define RKFD_NPROF 24
+#define RKFD_NPROF 32
 #ifdef RKFD_EMU
 #  define RKFD_CLOCK() 0ull
 #else

@@ -259,7 +259,7 @@ template<bool prof, bool vqp> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &
   SYNC();
   MST(6);
   if( vert ){
-    const unsigned long long qmask = rkfd_vert_qp( m, L, nc );
+    const unsigned long long qmask = rkfd_vert_qp<prof>( m, L, nc, pc );
     MST(21);
     /* _rkFDSolverSetForce (reference src/rkfd_vert.c:286-323): contact state is committed only when doUpRef;
      * a vertex is in kinetic friction when one of its pyramid faces is active at the solution */

@@ -103,8 +103,10 @@ RKFD_DEV double rkfd_w_sum(double v, double *scr)
  *     (G = its active rows), which is what the pseudo-inverse returns.
  * In:  L.MA = A (n x n, ld = n+1, without relaxation), L.MB = c_vel (bias incl. compensation).
  * Out: L.MF = f / dt; returns the mask of the constraints active at the solution (bit = lane). */
-RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel &m, const rkfdLds &L, int nc)
+template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel &m, const rkfdLds &L, int nc, unsigned long long *pc)
 {
+  unsigned long long q0 = prof ? RKFD_CLOCK() : 0ull, q1;
+#define VST(k) do{ if( prof ){ q1 = RKFD_CLOCK(); pc[k] += q1 - q0; q0 = q1; } }while(0)
   const int lane = LANE();
   const int n = 3*nc, ld = n+1;
   const int P = m.pyramid, mc = P*nc;
@@ -161,6 +163,7 @@ RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel &m, const rkfdLds &L
     }
   }
   SYNC();
+  VST(24);
   /* initial active set (_rkFDQPSolveASMInitIndex) */
   int act = 0;
   if( onc ){
@@ -206,6 +209,7 @@ RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel &m, const rkfdLds &L
       }
     }
     SYNC();
+    VST(25);
     /* S = W'W (into the matrix that held A), rhs = W'z */
     double *S = L.MA;
     for( int t0=0; t0<r*r; t0+=RKFD_WAVE ){
@@ -219,6 +223,7 @@ RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel &m, const rkfdLds &L
     double rl = 0;
     if( lane < r ) for( int i=0; i<n; i++ ) rl = fma( W[i*ld+lane], zv[i], rl );
     SYNC();
+    VST(26);
     rkfd_w_chol( S, ld, r );
     {
       const double y = rkfd_w_fwd( S, ld, r, rl );
@@ -226,6 +231,7 @@ RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel &m, const rkfdLds &L
       if( lane < r ) lam[lane] = l;
     }
     SYNC();
+    VST(27);
     /* f = L^-T ( W lambda - z ) */
     {
       double ti = 0;
@@ -237,6 +243,7 @@ RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel &m, const rkfdLds &L
       if( lane < n ) xv[lane] = xi;
     }
     SYNC();
+    VST(28);
     const bool moved = BALLOT( lane < n && !( fabs( xv[lane] - ans[lane] ) < RKFD_DEV_TOL ) ) != 0ull;
     if( !moved ){
       if( lane < n ) ans[lane] = xv[lane];
@@ -267,6 +274,7 @@ RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel &m, const rkfdLds &L
       if( BALLOT( onc && act && y < 0 ) == 0ull ) break;                 /* found the optimal solution */
       const double ymin = rkfd_w_min( ( onc && act ) ? y : HUGE_VAL, scr );
       if( onc && act && fabs( y - ymin ) < RKFD_QP_ASM_TOL ) act = 0;
+      VST(29);
       continue;
     }
     /* STEP2: towards the equality-constrained minimiser as far as the inactive constraints allow */
@@ -297,12 +305,14 @@ RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel &m, const rkfdLds &L
     if( nhist >= RKFD_WAVE ){ fail = 1; break; }
     if( lane == nhist ){ hmask = nmask; hobj = objv; }
     nhist++;
+    VST(30);
   }
   mask = BALLOT( act );
   if( fail && lane == 0 ) L.cnt[CNT_QPF] = 1;
   SYNC();
   if( lane < n ) L.MF[lane] = ans[lane]/m.dt;
   SYNC();
+#undef VST
   return mask;
 }
 
