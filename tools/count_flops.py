@@ -23,7 +23,7 @@ po.LIB_PATH = os.path.join(ROOT, "oracle", "_build", "librkfd_oracle_count.so")
 L = po.lib()
 L.rkfdOracleFlops.restype = C.c_ulonglong
 out = {}
-for name in ("config1", "config2", "config3", "config4", "config5"):
+for name in ("config1", "config2", "config3", "config4", "config4v", "config5"):
     sc = R.scenarios.CONFIGS[name](batch=4)
     tot = 0
     for i in range(sc["dis"].shape[0]):

@@ -69,7 +69,7 @@ LIB_FMA = os.path.join(ROOT, "oracle", "_build", "librkfd_oracle_fma.so")
 print(f"# {NINST} instances per config; rel = max|d| / max(1, max|oracle|) per instance, worst instance shown;")
 print("# 'agree' = instances whose acc and f both agree to 1e-6; 'sets' = identical active-contact sets")
 print("# pair           config     steps   acc: max-abs  max-rel    f: max-abs  max-rel    dis: max-rel   agree   sets")
-for name in ("config1", "config1b", "config2", "config3", "config4", "config5"):
+for name in ("config1", "config1b", "config2", "config3", "config4", "config4v", "config5"):
     sc = R.scenarios.CONFIGS[name](batch=NINST)
     B = sc["dis"].shape[0]
     ref = oracle_run(sc, LIB)
