@@ -24,6 +24,8 @@ ALG_BYTES = {  # algorithmic HBM bytes per instance-step (SURVEY.md 8d / DESIGN.
     "config4": lambda m: 8 * 6 * m.ndof + 8 * 80 + 24 * 24,
     "config4v": lambda m: 8 * 6 * m.ndof + 8 * 80 + 24 * 24,
     "config5": lambda m: 8 * 6 * m.ndof + 24 * 80 + 24 * 24,
+    "config3_26": lambda m: 8 * 6 * m.ndof + 8 * 80 + 20 * 24,
+    "config4_26": lambda m: 8 * 6 * m.ndof + 8 * 80 + 20 * 24,
 }
 HBM_PEAK_GBS = 8000.0
 

@@ -238,4 +238,15 @@ def arm_press(batch=8, root="fixed", with_box=True, seed=0x5EED00A1):
     return dict(name=f"arm_press_{root}{'_box' if with_box else ''}", world=w, dis=dis, vel=vel, motor_in=inp, max_rigid=12, steps=200)
 
 
-CONFIGS = {"config1": config1, "config1b": config1_rigid, "config2": config2, "config3": config3, "config4": config4, "config4v": config4_vert, "config5": config5}
+def config3_26(batch=4096):
+    """config 3 on the 26-DoF model with mighty.ztk's own topology (reported alongside)"""
+    d = config3(batch, model="humanoid26.ztk"); d["name"] = "config3_humanoid26_penalty"; return d
+
+
+def config4_26(batch=4096):
+    """config 4 on the 26-DoF model with mighty.ztk's own topology"""
+    d = config4(batch, model="humanoid26.ztk"); d["name"] = "config4_humanoid26_mlcp"; return d
+
+
+CONFIGS = {"config1": config1, "config1b": config1_rigid, "config2": config2, "config3": config3, "config4": config4, "config4v": config4_vert, "config5": config5,
+           "config3_26": config3_26, "config4_26": config4_26}
