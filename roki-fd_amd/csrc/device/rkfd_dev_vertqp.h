@@ -98,7 +98,8 @@ RKFD_DEV double rkfd_w_sum(double v, double *scr)
  * positive definite and rows of different contacts touch different unknowns, so
  *   - a contact with >= 3 active faces is the equality f_c = 0: its rows are replaced by the three
  *     unit rows, and the reduced constraint matrix C (<= 3 rows per contact) has full row rank;
- *   - with Q = LL' factored once:  W = L^-1 C',  (W'W) lambda = W' L^-1 c,  f = L^-T ( W lambda - L^-1 c );
+ *   - with Q^-1 formed once per evaluation (Cholesky, triangular inverse):  ( C Q^-1 C' ) lambda = C Q^-1 c,
+ *     f = Q^-1 ( C' lambda - c ), every entry a 3x3-block contraction;
  *   - the minimum-norm multipliers of the original rows are y = G (G'G)^-1 lambda_c per contact
  *     (G = its active rows), which is what the pseudo-inverse returns.
  * In:  L.MA = A (n x n, ld = n+1, without relaxation), L.MB = c_vel (bias incl. compensation).
@@ -147,11 +148,6 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
   }
   SYNC();
   rkfd_w_chol( Q, ld, n );
-  {
-    const double zi = rkfd_w_fwd( Q, ld, n, lane < n ? cv[lane] : 0.0 );
-    if( lane < n ) zv[lane] = zi;
-  }
-  SYNC();
   /* L^-1, kept transposed in the strict upper triangle of the factor's matrix (its diagonal is the
    * stored 1/L_ii): column j by forward substitution, lane = column */
   if( lane < n ){
@@ -161,6 +157,24 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
       for( int k=j+1; k<i; k++ ) s -= Q[i*ld+k]*Q[j*ld+k];      /* L[i][k] * Linv[k][j] (stored at [j][k]) */
       Q[j*ld+i] = s*Q[i*ld+i];
     }
+  }
+  SYNC();
+  /* Q^-1 = L^-T L^-1 (symmetric, into W) and qt = Q^-1 c: every later quantity of the iterations is a
+   * small combination of their entries, because a constraint row has only the three entries of its contact */
+  for( int t0=0; t0<n*n; t0+=RKFD_WAVE ){
+    const int t = t0 + lane, i = t/n, k = t - i*n;
+    if( t < n*n && k <= i ){
+      /* sum over rows m >= i of Linv[m][i] Linv[m][k]; Linv[m][j] sits at Q[j][m] for m > j, 1/L_jj on the diagonal */
+      double sacc = Q[i*ld+i]*( k == i ? Q[i*ld+i] : Q[k*ld+i] );
+      for( int mm=i+1; mm<n; mm++ ) sacc = fma( Q[i*ld+mm], Q[k*ld+mm], sacc );
+      W[i*ld+k] = sacc; W[k*ld+i] = sacc;
+    }
+  }
+  SYNC();
+  if( lane < n ){
+    double sacc = 0;
+    for( int j=0; j<n; j++ ) sacc = fma( W[lane*ld+j], cv[j], sacc );
+    zv[lane] = sacc;                                    /* qt */
   }
   SYNC();
   VST(24);
@@ -196,32 +210,26 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
       }
     }
     SYNC();
-    /* W = L^-1 C' : lane = reduced row, a combination of three columns of L^-1 (zero above row 3c) */
-    if( lane < r ){
-      const int c3 = 3*L.CRC[lane];
-      const double h0 = L.CR[3*lane], h1 = L.CR[3*lane+1], h2 = L.CR[3*lane+2];
-      for( int i=0; i<n; i++ ){
-        /* Linv[i][j] for j = c3, c3+1, c3+2 (lower triangular; diagonal = stored reciprocal) */
-        const double l0 = i > c3   ? Q[( c3   )*ld+i] : ( i == c3   ? Q[i*ld+i] : 0.0 );
-        const double l1 = i > c3+1 ? Q[( c3+1 )*ld+i] : ( i == c3+1 ? Q[i*ld+i] : 0.0 );
-        const double l2 = i > c3+2 ? Q[( c3+2 )*ld+i] : ( i == c3+2 ? Q[i*ld+i] : 0.0 );
-        W[i*ld+lane] = l0*h0 + l1*h1 + l2*h2;
-      }
-    }
-    SYNC();
     VST(25);
-    /* S = W'W (into the matrix that held A), rhs = W'z */
+    /* S = C Q^-1 C' : entry (a,b) = g_a' Qinv[3ca.., 3cb..] g_b;  rhs_a = g_a . qt[3ca..] */
     double *S = L.MA;
     for( int t0=0; t0<r*r; t0+=RKFD_WAVE ){
       const int t = t0 + lane, a = r > 0 ? t/r : 0, b = t - a*r;
       if( t < r*r && b <= a ){
-        double s = 0;
-        for( int i=0; i<n; i++ ) s = fma( W[i*ld+a], W[i*ld+b], s );
-        S[a*ld+b] = s; S[b*ld+a] = s;
+        const int ca = 3*L.CRC[a], cb = 3*L.CRC[b];
+        const double a0 = L.CR[3*a], a1 = L.CR[3*a+1], a2 = L.CR[3*a+2];
+        const double b0 = L.CR[3*b], b1 = L.CR[3*b+1], b2 = L.CR[3*b+2];
+        const double *q0r = &W[( ca )*ld+cb], *q1r = &W[( ca+1 )*ld+cb], *q2r = &W[( ca+2 )*ld+cb];
+        const double sacc = a0*( q0r[0]*b0 + q0r[1]*b1 + q0r[2]*b2 ) + a1*( q1r[0]*b0 + q1r[1]*b1 + q1r[2]*b2 )
+                          + a2*( q2r[0]*b0 + q2r[1]*b1 + q2r[2]*b2 );
+        S[a*ld+b] = sacc; S[b*ld+a] = sacc;
       }
     }
     double rl = 0;
-    if( lane < r ) for( int i=0; i<n; i++ ) rl = fma( W[i*ld+lane], zv[i], rl );
+    if( lane < r ){
+      const int ca = 3*L.CRC[lane];
+      rl = L.CR[3*lane]*zv[ca] + L.CR[3*lane+1]*zv[ca+1] + L.CR[3*lane+2]*zv[ca+2];
+    }
     SYNC();
     VST(26);
     rkfd_w_chol( S, ld, r );
@@ -232,15 +240,19 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
     }
     SYNC();
     VST(27);
-    /* f = L^-T ( W lambda - z ) */
-    {
-      double ti = 0;
-      if( lane < n ){
-        for( int a=0; a<r; a++ ) ti = fma( W[lane*ld+a], lam[a], ti );
-        ti -= zv[lane];
-      }
-      const double xi = rkfd_w_back( Q, ld, n, ti );
-      if( lane < n ) xv[lane] = xi;
+    /* f = Q^-1 C' lambda - qt */
+    if( lane < n ){
+      /* v = C' lambda, gathered from the rows of this entry's contact */
+      const int ci = lane/3, k3 = lane - 3*ci;
+      double vi = 0;
+      for( int a=0; a<r; a++ ) if( L.CRC[a] == ci ) vi = fma( L.CR[3*a+k3], lam[a], vi );
+      dv[lane] = vi;
+    }
+    SYNC();
+    if( lane < n ){
+      double xi = -zv[lane];
+      for( int j=0; j<n; j++ ) xi = fma( W[lane*ld+j], dv[j], xi );
+      xv[lane] = xi;
     }
     SYNC();
     VST(28);
