@@ -295,7 +295,8 @@ typedef struct {
   double *RTMP;                   /* [maxact*3] copy of REF while the slots are re-assigned; only when ncand > 64 */
   double *CF;                     /* contact forces (output): per active slot              */
   double *QL, *QW, *QV, *CR;      /* Vert QP (only when the world can have rigid contacts under the Vert plugin):
-                                     [M*(M+1)] Q / its Cholesky factor, [M*(M+1)] L^-1 C', [6M+64] vectors + reduction scratch, [3M] reduced rows */
+                                     [M*M] Cholesky factor of Q with L^-1 in its upper triangle, [M*M] Q^-1, [5M (+64)] vectors (+ reduction scratch
+                                     unless it overlays the link accelerations), [3M] reduced rows */
   int *CRC;                       /* [M] contact of a reduced constraint row */
   double *MA, *MB, *MF, *PU;      /* MLCP: [M*(M+1)] (ALIASES IST|POOL), [M], [M], [nside*npurow*M] (ALIASES C|PA when it fits) */
   int *act, *typ, *lrg, *lel, *tgt, *cnt;
@@ -333,7 +334,7 @@ RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int
   /* probe scratch: lives while the contact problem is set up and solved, when C and PA are dead */
   if( pu_alias ) L->PU = L->C; else { L->PU = d; d += nside*npurow*M; }
   L->QL = d; L->QW = d; L->QV = d; L->CR = d;
-  if( vert_rigid ){ L->QL = d; d += M*( M+1 ); L->QW = d; d += M*( M+1 ); L->QV = d; d += 6*M + RKFD_WAVE; L->CR = d; d += 3*M; }
+  if( vert_rigid ){ L->QL = d; d += M*M; L->QW = d; d += M*M; L->QV = d; d += 5*M + ( vert_rigid == 2 ? 0 : RKFD_WAVE ); L->CR = d; d += 3*M; }
   int *ip = (int *)d;
   L->act = ip; ip += NC; L->typ = ip; ip += NC; L->asl = ip; ip += NC; L->CIp = ip; ip += NC; L->CFO = ip; ip += NC;
   L->lrg = ip; ip += maxact; L->lel = ip; ip += maxact; L->tgt = ip; ip += 2*maxact; L->cnt = ip; ip += 8;

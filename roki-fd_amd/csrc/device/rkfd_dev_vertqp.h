@@ -109,10 +109,12 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
   unsigned long long q0 = prof ? RKFD_CLOCK() : 0ull, q1;
 #define VST(k) do{ if( prof ){ q1 = RKFD_CLOCK(); pc[k] += q1 - q0; q0 = q1; } }while(0)
   const int lane = LANE();
-  const int n = 3*nc, ld = n+1;
+  const int n = 3*nc, ld = n+1, ldq = n;      /* ld: the matrix that held A (now S); ldq: Q's factor and Q^-1 */
   const int P = m.pyramid, mc = P*nc;
   double *Q = L.QL, *W = L.QW;
-  double *cv = L.QV, *zv = L.QV + n, *ans = L.QV + 2*n, *xv = L.QV + 3*n, *lam = L.QV + 4*n, *dv = L.QV + 5*n, *scr = L.QV + 6*n;
+  double *cv = L.QV, *zv = L.QV + n, *ans = L.QV + 2*n, *lam = L.QV + 3*n, *dv = L.QV + 4*n;
+  double *xv = L.MB;                          /* the bias vector is dead once c = A'b is formed */
+  double *scr = m.qscr_alias ? L.AC : L.QV + 5*n;   /* reduction scratch: the link accelerations are dead until the delta sweep */
   const bool onc = lane < mc;                 /* this lane is a constraint */
   const int cc = onc ? lane/P : 0;            /* its contact */
 
@@ -137,7 +139,7 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
       double s = 0;
       for( int r=0; r<n; r++ ) s = fma( L.MA[r*ld+i], L.MA[r*ld+k], s );
       if( i == k ) s += m.ci_l[RKFD_CI_CI( L.CIp[L.lrg[i/3]] )];
-      Q[i*ld+k] = s; Q[k*ld+i] = s;
+      Q[i*ldq+k] = s; Q[k*ldq+i] = s;
     }
   }
   if( lane < n ){
@@ -147,15 +149,15 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
     ans[lane] = ( lane%3 == 0 ) ? 1.0 : 0.0;           /* _rkFDSolverQPASMInit */
   }
   SYNC();
-  rkfd_w_chol( Q, ld, n );
+  rkfd_w_chol( Q, ldq, n );
   /* L^-1, kept transposed in the strict upper triangle of the factor's matrix (its diagonal is the
    * stored 1/L_ii): column j by forward substitution, lane = column */
   if( lane < n ){
     const int j = lane;
     for( int i=j+1; i<n; i++ ){
-      double s = -Q[i*ld+j]*Q[j*ld+j];
-      for( int k=j+1; k<i; k++ ) s -= Q[i*ld+k]*Q[j*ld+k];      /* L[i][k] * Linv[k][j] (stored at [j][k]) */
-      Q[j*ld+i] = s*Q[i*ld+i];
+      double s = -Q[i*ldq+j]*Q[j*ldq+j];
+      for( int k=j+1; k<i; k++ ) s -= Q[i*ldq+k]*Q[j*ldq+k];      /* L[i][k] * Linv[k][j] (stored at [j][k]) */
+      Q[j*ldq+i] = s*Q[i*ldq+i];
     }
   }
   SYNC();
@@ -165,15 +167,15 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
     const int t = t0 + lane, i = t/n, k = t - i*n;
     if( t < n*n && k <= i ){
       /* sum over rows m >= i of Linv[m][i] Linv[m][k]; Linv[m][j] sits at Q[j][m] for m > j, 1/L_jj on the diagonal */
-      double sacc = Q[i*ld+i]*( k == i ? Q[i*ld+i] : Q[k*ld+i] );
-      for( int mm=i+1; mm<n; mm++ ) sacc = fma( Q[i*ld+mm], Q[k*ld+mm], sacc );
-      W[i*ld+k] = sacc; W[k*ld+i] = sacc;
+      double sacc = Q[i*ldq+i]*( k == i ? Q[i*ldq+i] : Q[k*ldq+i] );
+      for( int mm=i+1; mm<n; mm++ ) sacc = fma( Q[i*ldq+mm], Q[k*ldq+mm], sacc );
+      W[i*ldq+k] = sacc; W[k*ldq+i] = sacc;
     }
   }
   SYNC();
   if( lane < n ){
     double sacc = 0;
-    for( int j=0; j<n; j++ ) sacc = fma( W[lane*ld+j], cv[j], sacc );
+    for( int j=0; j<n; j++ ) sacc = fma( W[lane*ldq+j], cv[j], sacc );
     zv[lane] = sacc;                                    /* qt */
   }
   SYNC();
@@ -219,7 +221,7 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
         const int ca = 3*L.CRC[a], cb = 3*L.CRC[b];
         const double a0 = L.CR[3*a], a1 = L.CR[3*a+1], a2 = L.CR[3*a+2];
         const double b0 = L.CR[3*b], b1 = L.CR[3*b+1], b2 = L.CR[3*b+2];
-        const double *q0r = &W[( ca )*ld+cb], *q1r = &W[( ca+1 )*ld+cb], *q2r = &W[( ca+2 )*ld+cb];
+        const double *q0r = &W[( ca )*ldq+cb], *q1r = &W[( ca+1 )*ldq+cb], *q2r = &W[( ca+2 )*ldq+cb];
         const double sacc = a0*( q0r[0]*b0 + q0r[1]*b1 + q0r[2]*b2 ) + a1*( q1r[0]*b0 + q1r[1]*b1 + q1r[2]*b2 )
                           + a2*( q2r[0]*b0 + q2r[1]*b1 + q2r[2]*b2 );
         S[a*ld+b] = sacc; S[b*ld+a] = sacc;
@@ -251,7 +253,7 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
     SYNC();
     if( lane < n ){
       double xi = -zv[lane];
-      for( int j=0; j<n; j++ ) xi = fma( W[lane*ld+j], dv[j], xi );
+      for( int j=0; j<n; j++ ) xi = fma( W[lane*ldq+j], dv[j], xi );
       xv[lane] = xi;
     }
     SYNC();
@@ -306,8 +308,8 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
      * f'Qf/2 = |L'f|^2/2 with the stored factor (diagonal kept as 1/L_ii) */
     double part = 0;
     if( lane < n ){
-      double u = ans[lane]/Q[lane*ld+lane];
-      for( int j=lane+1; j<n; j++ ) u = fma( Q[j*ld+lane], ans[j], u );
+      double u = ans[lane]/Q[lane*ldq+lane];
+      for( int j=lane+1; j<n; j++ ) u = fma( Q[j*ldq+lane], ans[j], u );
       part = 0.5*u*u + cv[lane]*ans[lane];
     }
     const double objv = rkfd_w_sum( part, scr );

@@ -310,6 +310,8 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   }
   dm.pyramid = m->pyramid > 0 ? m->pyramid : 8;
   dm.vert_rigid = ( m->solver == RKFD_SOLVER_VERT && has_rigid && max_rigid > 0 ) ? 1 : 0;
+  dm.qscr_alias = ( dm.vert_rigid && 6*NL >= RKFD_WAVE ) ? 1 : 0;
+  if( dm.qscr_alias ) dm.vert_rigid = 2;
   if( dm.vert_rigid && (size_t)dm.pyramid*max_rigid > RKFD_WAVE )
     FAIL( "Vert plugin: pyramid faces x rigid contact capacity exceeds 64 (one constraint per lane)" );
   int maxact = has_elastic ? ( NC < 16 ? NC : 16 ) : 0;
@@ -375,7 +377,7 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
     if( M*(M+1) > stage ) stage = M*(M+1);                       /* ... shared with the MLCP matrix */
     const size_t dbl = (size_t)3*ND + (size_t)NL*( 5*6 + 4 ) + stage + (size_t)48*nfloat
                      + (size_t)maxact*( 24 + ( NC > RKFD_WAVE ? 3 : 0 ) ) + 2*M + ( dm.pu_alias ? 0 : (size_t)nside*npurow*M )
-                     + ( dm.vert_rigid ? 2*M*( M+1 ) + 6*M + RKFD_WAVE + 3*M : 0 );   /* Vert QP: QL, QW, QV, CR */
+                     + ( dm.vert_rigid ? 2*M*M + 5*M + ( dm.qscr_alias ? 0 : RKFD_WAVE ) + 3*M : 0 );   /* Vert QP: QL, QW, QV, CR */
     const size_t ints = (size_t)5*NC + (size_t)4*maxact + 8 + 3*(size_t)NL + ( dm.vert_rigid ? M : 0 )     /* act typ asl CIp CFO, lrg lel tgt, cnt, LI CHI PSL */
                       + ( max_rigid > 0 ? ( (size_t)NL*( nlevel+3 ) + 3 )/4 : 0 );   /* PL (bytes) */
     out->lds_bytes = dbl*sizeof(double) + ints*sizeof(int);

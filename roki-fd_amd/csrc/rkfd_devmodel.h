@@ -24,7 +24,9 @@ typedef struct {
   int pu_alias;          /* 1: the probe scratch PU fits in (and aliases) the C|PA block                */
   int anchor;            /* link whose position is the origin of the spatial (Pluecker) coordinates in every evaluation:
                             the first link that can move (-1: none, the world origin is used)           */
-  int vert_rigid;        /* 1: Vert plugin and rigid pairs exist -> the QP path and its LDS are set up        */
+  int vert_rigid;        /* > 0: Vert plugin and rigid pairs exist -> the QP path and its LDS are set up;
+                            2: the QP's reduction scratch overlays the link accelerations (qscr_alias)      */
+  int qscr_alias;
   int pyramid;           /* faces of the Vert plugin's friction pyramid                                  */
   int npurow;            /* rows of PU per side: nlevel (+6 with a float joint)                         */
   int nside;             /* 1 when every rigid-capable pair has a static cell (probe walks one-sided) else 2 */
