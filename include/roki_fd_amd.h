@@ -184,6 +184,7 @@ int  rkfdWorldSetContactInfo(rkfdWorldHandle *w, const char *filename);
 void rkfdWorldPairChainUnreg(rkfdWorldHandle *w, int chain);
 /* rkFDPrpSet* + rkFDSetSolver */
 void rkfdWorldSetPrp(rkfdWorldHandle *w, double dt, double friction_weight, int max_iter, int solver);
+void rkfdWorldSetPyramid(rkfdWorldHandle *w, int pyramid);
 const rkfdModel *rkfdWorldModel(rkfdWorldHandle *w);
 int  rkfdWorldChainDofOffset(const rkfdWorldHandle *w, int chain);
 int  rkfdWorldChainLinkOffset(const rkfdWorldHandle *w, int chain);

@@ -15,6 +15,7 @@
  * origin frame).  Every such choice is tagged [UNVERIFIED-DEP] in DESIGN.md.
  */
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 #include <math.h>
 #include "rkfd_oracle.h"
@@ -133,6 +134,8 @@ struct rkfdOracle {
   int last_nc;
   int last_qp_iter;      /* KKT solves of the last Vert QP (diagnostic) */
   int qp_cycle_stops;    /* how many Vert QPs so far were ended by the circulation check (diagnostic) */
+  int qp_n, qp_mc;       /* the last Vert QP, kept for the tests: sizes, then q (n*n), c (n), nf (mc*n), ans (n), idx (mc) */
+  double *qp_q, *qp_c, *qp_nf, *qp_ans; int *qp_idx;
   /* RKG workspace */
   double *k_v[4], *k_a[4], *xd, *xv, *tv, *ta;
 };
@@ -192,6 +195,7 @@ void rkfdOracleDestroy(rkfdOracle *o)
 {
   int k;
   if( !o ) return;
+  free( o->qp_q ); free( o->qp_c ); free( o->qp_nf ); free( o->qp_ans ); free( o->qp_idx );
   free( o->dis ); free( o->vel ); free( o->acc ); free( o->motor_in ); free( o->piv_type ); free( o->piv_prev );
   free( o->cv_active ); free( o->cv_type ); free( o->cv_ref ); free( o->cv_f ); free( o->lk );
   free( o->beta0 ); free( o->ext ); free( o->pA ); free( o->u ); free( o->contrib ); free( o->csum );
@@ -1033,6 +1037,10 @@ static int qp_asm(int n, int mc, int P, const double *q, const double *c, const 
     iter++;
 
     for( i=0; i<n; i++ ) if( !( fabs( xy[i] - ans[i] ) < TOL ) ){ step2 = 1; break; }
+    if( getenv( "RKFD_QP_TRACE" ) ){
+      unsigned long long mk = 0; for( i=0; i<mc && i<64; i++ ) if( idx[i] ) mk |= 1ull << i;
+      printf( "orc it %d mask %016llx m %d moved %d x", iter-1, mk, m, step2 ); for( i=0; i<n; i++ ) printf( " %.6e", xy[i] ); printf( "\n" );
+    }
     if( !step2 ){
       int neg = 0, tempi;
       for( i=0; i<n; i++ ) ans[i] = xy[i];
@@ -1059,6 +1067,7 @@ static int qp_asm(int n, int mc, int P, const double *q, const double *c, const 
         if( tempd2 < tempd ) tempd = tempd2;
       }
     }
+    if( getenv( "RKFD_QP_TRACE" ) ) printf( "orc    step t %.12e\n", tempd );
     for( i=0; i<n; i++ ) ans[i] += tempd*dv[i];
     for( i=0; i<mc; i++ )
       if( idx[i] == 0 && fabs( qp_cond( nf, n, P, ans, i ) - d[i] ) < TOL ){ idx[i] = 1; m++; }
@@ -1154,6 +1163,13 @@ static int vert_rigid(rkfdOracle *o, int doUpRef)
   }
   o->last_qp_iter = qp_asm( n3, mc, P, q, cv, nf, d, f, idx );
   if( o->last_qp_iter < 0 ){ o->last_qp_iter = -o->last_qp_iter; o->qp_cycle_stops++; }
+  free( o->qp_q ); free( o->qp_c ); free( o->qp_nf ); free( o->qp_ans ); free( o->qp_idx );
+  o->qp_n = n3; o->qp_mc = mc;
+  o->qp_q = (double *)malloc( sizeof(double)*n3*n3 ); memcpy( o->qp_q, q, sizeof(double)*n3*n3 );
+  o->qp_c = (double *)malloc( sizeof(double)*n3 ); memcpy( o->qp_c, cv, sizeof(double)*n3 );
+  o->qp_nf = (double *)malloc( sizeof(double)*mc*n3 ); memcpy( o->qp_nf, nf, sizeof(double)*mc*n3 );
+  o->qp_ans = (double *)malloc( sizeof(double)*n3 ); memcpy( o->qp_ans, f, sizeof(double)*n3 );
+  o->qp_idx = (int *)malloc( sizeof(int)*mc ); memcpy( o->qp_idx, idx, sizeof(int)*mc );
   for( r=0; r<n3; r++ ) f[r] /= dt;
   /* _rkFDSolverSetForce (:286-323): unlike the MLCP plugin, contact state is committed only when doUpRef */
   for( c=0; c<nc; c++ ){
@@ -1340,4 +1356,14 @@ void rkfdOraclePinvSolve(int n, const double *K, const double *rhs, double *x)
 int rkfdOracleQPASM(int n, int mc, int P, const double *q, const double *c, const double *nf, const double *d, double *ans, int *idx)
 {
   return abs( qp_asm( n, mc, P, q, c, nf, d, ans, idx ) );
+}
+
+/* the last Vert QP (sizes with NULL pointers; then the data): min x'qx/2 + c'x s.t. nf x >= 0, its result and active set */
+void rkfdOracleGetLastQP(const rkfdOracle *o, int *n, int *mc, double *q, double *c, double *nf, double *ans, int *idx)
+{
+  *n = o->qp_n; *mc = o->qp_mc;
+  if( !q || !o->qp_q ) return;
+  memcpy( q, o->qp_q, sizeof(double)*o->qp_n*o->qp_n ); memcpy( c, o->qp_c, sizeof(double)*o->qp_n );
+  memcpy( nf, o->qp_nf, sizeof(double)*o->qp_mc*o->qp_n ); memcpy( ans, o->qp_ans, sizeof(double)*o->qp_n );
+  memcpy( idx, o->qp_idx, sizeof(int)*o->qp_mc );
 }

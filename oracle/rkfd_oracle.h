@@ -51,6 +51,8 @@ void rkfdOraclePinvSolve(int n, const double *K, const double *rhs, double *x);
 int  rkfdOracleQPASM(int n, int mc, int P, const double *q, const double *c, const double *nf, const double *d, double *ans, int *idx);
 /* number of KKT solves of the last Vert QP (diagnostic) */
 int  rkfdOracleLastQPIter(const rkfdOracle *o);
+/* the last Vert QP (call with NULL data pointers for the sizes): min x'qx/2 + c'x s.t. nf x >= 0, result, active set */
+void rkfdOracleGetLastQP(const rkfdOracle *o, int *n, int *mc, double *q, double *c, double *nf, double *ans, int *idx);
 /* how many Vert QPs so far were ended by the circulation check instead of at the optimum (diagnostic) */
 int  rkfdOracleQPCycleStops(const rkfdOracle *o);
 /* nsteps x rkFDUpdate */

@@ -68,6 +68,7 @@ def lib():
     L.rkfdWorldSetContactInfo.argtypes = [vp, C.c_char_p]
     L.rkfdWorldPairChainUnreg.argtypes = [vp, C.c_int]
     L.rkfdWorldSetPrp.argtypes = [vp, C.c_double, C.c_double, C.c_int, C.c_int]
+    L.rkfdWorldSetPyramid.argtypes = [vp, C.c_int]
     L.rkfdWorldModel.argtypes = [vp]
     L.rkfdWorldModel.restype = C.POINTER(RkfdModel)
     L.rkfdWorldChainDofOffset.argtypes = [vp, C.c_int]
@@ -126,6 +127,10 @@ class World:
             self.close()
         except Exception:
             pass
+
+    def set_pyramid(self, pyramid):
+        """rkFDPrpSetPyramid: faces of the Vert plugin's friction pyramid (default 8)"""
+        self._L.rkfdWorldSetPyramid(self._w, int(pyramid))
 
     def set_prp(self, dt, friction_weight, max_iter, solver):
         self._L.rkfdWorldSetPrp(self._w, dt, friction_weight, max_iter, solver)

@@ -295,7 +295,7 @@ typedef struct {
   double *RTMP;                   /* [maxact*3] copy of REF while the slots are re-assigned; only when ncand > 64 */
   double *CF;                     /* contact forces (output): per active slot              */
   double *QL, *QW, *QV, *CR;      /* Vert QP (only when the world can have rigid contacts under the Vert plugin):
-                                     [M*M] Cholesky factor of Q with L^-1 in its upper triangle, [M*M] Q^-1, [5M (+64)] vectors (+ reduction scratch
+                                     [M*M] Q / its Cholesky factor, [M*M] W = L^-1 C', [5M (+64)] vectors (+ reduction scratch
                                      unless it overlays the link accelerations), [3M] reduced rows */
   int *CRC;                       /* [M] contact of a reduced constraint row */
   double *MA, *MB, *MF, *PU;      /* MLCP: [M*(M+1)] (ALIASES IST|POOL), [M], [M], [nside*npurow*M] (ALIASES C|PA when it fits) */

@@ -408,6 +408,8 @@ void rkfdWorldSetPrp(rkfdWorld *w, double dt, double friction_weight, int max_it
   w->cidef.type = RKFD_CONTACT_RIGID; w->cidef.k = 1000.0; w->cidef.l = 1.0; w->cidef.sf = 0.5; w->cidef.kf = 0.3;
   w->built = 0;
 }
+/* rkFDPrpSetPyramid for the flat loader: faces of the Vert plugin's friction pyramid */
+void rkfdWorldSetPyramid(rkfdWorld *w, int pyramid){ w->model.pyramid = pyramid; w->built = 0; }
 const rkfdModel *rkfdWorldModel(rkfdWorld *w)
 {
   if( !w->built && rkfdWorldBuild( w ) < 0 ) return NULL;

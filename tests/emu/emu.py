@@ -71,6 +71,14 @@ class EmuBatch:
         act = self.cv_active[:, :n].copy(); on = act != 0
         return act, self.cv_type[:, :n] * on, self.cv_ref[:, :n] * on[:, :, None], self.cv_f[:, :n] * on[:, :, None]
 
+    def set_contact(self, act, typ, ref):
+        n = self.ncand
+        self.cv_active[:, :n] = np.asarray(act).reshape(self.B, n); self.cv_type[:, :n] = np.asarray(typ).reshape(self.B, n)
+        self.cv_ref[:, :n] = np.asarray(ref).reshape(self.B, n, 3)
+
+    def set_pivot(self, typ, prev):
+        self.piv_type[...] = np.asarray(typ).reshape(self.B, self.nlink); self.piv_prev[...] = np.asarray(prev).reshape(self.B, self.nlink)
+
     def get_pivot(self):
         return self.piv_type.copy(), self.piv_prev.copy()
 

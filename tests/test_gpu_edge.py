@@ -310,3 +310,28 @@ def test_vert_plugin_rigid_qp_humanoid(R, oracle_cls):
             assert _rel(f[i], of * (oact[:, None] != 0)) < 1e-7, (i, chunk)
             seen += int(oact.sum())
     assert seen > 40
+
+
+@pytest.mark.parametrize("P,cap", [(4, 8), (6, 8), (12, 5), (16, 4)])
+def test_vert_plugin_other_pyramids(R, oracle_cls, P, cap):
+    """rkFDPrpSetPyramid: pyramids with 4 / 6 / 12 / 16 faces (capacity = 64 lanes / faces), a tilted
+    sliding box on the rigid floor vs the oracle"""
+    w = _vert_box_world(R); w.set_pyramid(P)
+    B = 4
+    dis = np.zeros((B, 6)); vel = np.zeros((B, 6))
+    dis[:, 2] = 0.0499; dis[1:, 3:6] = np.random.default_rng(3).uniform(-0.25, 0.25, (B - 1, 3))
+    vel[:, 0] = np.linspace(0.1, 0.5, B); vel[:, 1] = 0.07
+    m = w.model.contents
+    for i in range(1, B):
+        dis[i, 2] -= R.scenarios.lowest_vertex_z(m, dis[i], 0) + 0.0001
+    b = R.Batch(w, B, max_rigid=cap)
+    b.set_state(dis, vel); b.update_init(); b.update(30)
+    assert b.status() == 0
+    d, v, a = b.get_state(); act, typ, ref, f = b.get_contact()
+    for i in range(B):
+        o = oracle_cls(w.model); o.set_state(dis[i], vel[i]); o.update_init(); o.update_n(30)
+        od, ov, oa = o.get_state(); oact, otyp, _, of = o.get_contact()
+        assert (act[i] == oact).all() and (typ[i] == otyp * (oact != 0)).all()
+        assert _rel(d[i], od) < 1e-8 and _rel(v[i], ov) < 1e-8 and _rel(a[i], oa) < 1e-6
+    with pytest.raises(R.RkfdError, match="pyramid"):
+        R.Batch(w, 1, max_rigid=64 // P + 1)
