@@ -1,7 +1,7 @@
 """How often does the device's Vert QP path leave the oracle's?  N random box drops (tilted, sliding, spinning)
 onto the rigid floor, S steps; an instance 'agrees' while contact sets, stick/slip types and velocities (1e-6)
 match.  Diagnostic for the knife-edge decisions of the active-set method (1e-12 absolute tests).
-usage: python3 tools/vert_agreement.py [N] [S] [pyramid]"""
+usage: python3 tools/vert_agreement.py [N] [S] [pyramid] [vert|mlcp]"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
@@ -11,8 +11,9 @@ from oracle.pyoracle import Oracle
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 P = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+PLUG = sys.argv[4] if len(sys.argv) > 4 else "vert"
 M = R.scenarios.MODELS
-w = R.World(solver=R.SOLVER_VERT); w.contact_info(os.path.join(M, "contactinfo.ztk")); w.set_pyramid(P)
+w = R.World(solver=R.SOLVER_VERT if PLUG == "vert" else R.SOLVER_MLCP); w.contact_info(os.path.join(M, "contactinfo.ztk")); w.set_pyramid(P)
 w.reg_file(os.path.join(M, "box.ztk")); w.reg_file(os.path.join(M, "floor.ztk"))
 m = w.model.contents
 rng = np.random.default_rng(11)
@@ -38,5 +39,5 @@ for s in range(1, S + 1):
         ok = (act[i] == oact).all() and (typ[i] == otyp * (oact != 0)).all() and np.abs(v[i] - ov).max() < 1e-6 * max(1, np.abs(ov).max())
         if not ok:
             alive[i] = False; first_bad[i] = s
-print(f"pyramid {P}: {alive.sum()}/{N} instances agree through {S} steps; status {b.status()}; steps with contact (while agreeing): {contact_steps}; "
+print(f"{PLUG} pyramid {P}: {alive.sum()}/{N} instances agree through {S} steps; status {b.status()}; steps with contact (while agreeing): {contact_steps}; "
       f"first disagreements at steps {sorted(first_bad[first_bad > 0].tolist())[:12]}; oracle cycle stops total {sum(o.qp_cycle_stops() for o in orc)}")
