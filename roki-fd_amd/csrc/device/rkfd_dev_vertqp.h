@@ -306,6 +306,8 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
     VST(30);
   }
   mask = BALLOT( act );
+  /* a Q that is not numerically positive definite (no relaxation and a singular A) ends in NaNs: report it */
+  if( BALLOT( lane < n && !( ans[lane] == ans[lane] ) ) != 0ull ) fail = 1;
   if( fail && lane == 0 ) L.cnt[CNT_QPF] = 1;
   SYNC();
   if( lane < n ) L.MF[lane] = ans[lane]/m.dt;
