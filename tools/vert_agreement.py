@@ -40,4 +40,4 @@ for s in range(1, S + 1):
         if not ok:
             alive[i] = False; first_bad[i] = s
 print(f"{PLUG} pyramid {P}: {alive.sum()}/{N} instances agree through {S} steps; status {b.status()}; steps with contact (while agreeing): {contact_steps}; "
-      f"first disagreements at steps {sorted(first_bad[first_bad > 0].tolist())[:12]}; oracle cycle stops total {sum(o.qp_cycle_stops() for o in orc)}")
+      f"first disagreements at steps {sorted(first_bad[first_bad > 0].tolist())[:12]} (instances {np.argsort(np.where(first_bad > 0, first_bad, 10**9))[:int((first_bad > 0).sum())][:12].tolist()}); oracle cycle stops total {sum(o.qp_cycle_stops() for o in orc)}")
