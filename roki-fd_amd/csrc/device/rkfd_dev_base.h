@@ -23,7 +23,11 @@
 #  define BALLOT(p)     rkfd_emu_ballot(p)
 #else
 #  define RKFD_DEV __device__ __forceinline__
-#  define LANE()        ((int)threadIdx.x)
+/* the lane index is read through an opaque asm in every phase: otherwise the compiler hoists dozens of
+ * lane-derived addresses out of the step loop (loop-invariant code motion) and keeps them in registers
+ * across all phases - ~100 VGPRs of the whole-kernel pressure that no single phase needs */
+static __device__ __forceinline__ int rkfd_lane(void){ int l = (int)threadIdx.x; asm volatile( "" : "+v"(l) ); return l; }
+#  define LANE()        rkfd_lane()
 /* One workgroup is one wavefront: lanes exchange data through LDS in program order, so a
  * "barrier" only has to (a) stop the compiler from moving LDS accesses across it and (b) wait
  * for the wave's own outstanding LDS operations.  __syncthreads() would also drain vmcnt (the

@@ -14,9 +14,10 @@ static thread_local char g_err[512] = "";
   SETERR( "%s failed: %s", #call, hipGetErrorString( e_ ) ); return ret; } }while(0)
 
 /* one workgroup = one wavefront = one world instance; state lives in LDS for the whole launch.
- * Register budget: 256 VGPRs = two waves per SIMD = eight instances per CU.  A third wave per
- * SIMD (168 VGPRs, LDS permitting) was measured slower: at two waves the VALU is already ~55 %
- * busy and the tighter budget spills (~230 B of scratch per lane). */
+ * Register budget: 256 VGPRs = two waves per SIMD = eight instances per CU (the kernels use ~185).
+ * A third wave per SIMD (168-VGPR build: 14 spilled registers, LDS allows 10 instances per CU for the
+ * humanoid) was measured: +4 % at 16384 instances, -4 % at the 4096 of the headline metric, where
+ * 2560 slots still mean two rounds, the second one thinly filled.  So the budget stays at two. */
 #define RKFD_KERNEL(name, prof, vqp) \
 extern "C" __global__ void __launch_bounds__(RKFD_WAVE, 2) \
 name(rkfdDevModel m, rkfdDevState st, int mode, int nsteps, int *errflag) \
