@@ -8,9 +8,9 @@ import pytest
 from randtree import random_tree_ztk
 
 
-def _world(R, tmp_path, seed, nlink, root, shapes=0, solver=None, floor=False):
+def _world(R, tmp_path, seed, nlink, root, shapes=0, solver=None, floor=False, motors=False):
     f = tmp_path / f"rand{seed}.ztk"
-    f.write_text(random_tree_ztk(seed, nlink, root=root, shapes=shapes))
+    f.write_text(random_tree_ztk(seed, nlink, root=root, shapes=shapes, motors=motors))
     w = R.World(solver=R.SOLVER_MLCP if solver is None else solver)
     if floor:
         w.contact_info(os.path.join(R.scenarios.MODELS, "contactinfo.ztk"))
@@ -110,3 +110,30 @@ def test_gpu_on_random_trees_with_contacts(R, oracle_cls, tmp_path):
                 assert np.abs(a[i] - oa).max() / max(1.0, np.abs(oa).max()) < 10 * tol, (seed, nlink, chunk)
                 ncontact += int(oact.sum())
     assert ncontact > 50
+
+
+@pytest.mark.gpu
+def test_gpu_on_random_trees_with_motors(R, oracle_cls, tmp_path):
+    """random trees whose joints carry DC motors (with stick/slip joint friction), torque motors or nothing,
+    driven by random inputs (beyond the saturation limits too); 20 steps vs the oracle incl. the friction pivots"""
+    rng = np.random.default_rng(9)
+    for k in range(30):
+        seed = 900 + k
+        nlink = int(rng.integers(3, 30)); root = ["float", "fixed", "revolute"][k % 3]
+        w, _ = _world(R, tmp_path, seed, nlink, root, motors=True)
+        m = w.model.contents
+        dis, vel = _state(w, seed, 4)
+        vel *= 0.3
+        inp = np.random.default_rng(seed).uniform(-30, 30, (4, m.nlink))
+        b = R.Batch(w, 4, max_rigid=0)
+        b.set_state(dis, vel); b.set_motor_input(inp); b.update_init(); b.update(20)
+        assert b.status() == 0
+        d, v, a = b.get_state(); pt, pp = b.get_pivot()
+        mt = m.arr("mtype", m.nlink)
+        for i in range(4):
+            o = oracle_cls(w.model); o.set_state(dis[i], vel[i]); o.set_motor_input(inp[i]); o.update_init(); o.update_n(20)
+            od, ov, oa = o.get_state(); opt, opp = o.get_pivot()
+            for x, y in ((d[i], od), (v[i], ov), (a[i], oa)):
+                assert np.abs(x - y).max() / max(1.0, np.abs(y).max()) < 1e-7, (seed, nlink, root)
+            dc = mt == 2          # RKFD_MOTOR_DC
+            assert (pt[i][dc] == opt[dc]).all(), (seed, nlink, root)
