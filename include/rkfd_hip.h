@@ -49,7 +49,8 @@ int rkfdBatchGetState(rkfdBatch *b, double *dis, double *vel, double *acc);
 int rkfdBatchSetMotorInput(rkfdBatch *b, const double *input);
 /* contact-vertex state rkCDVert{type,_ref} and force f per candidate vertex
  * (consumed at reference src/rkfd_util.c:256-263, src/rkfd_mlcp.c:263-279): [batch][ncand], [batch][ncand*3] */
-/* (entries of a candidate that is not in contact are reported as 0) */
+/* (entries of a candidate that is not in contact are reported as 0; the anchors `ref` are in the frame of the
+ * other cell's link as registered - links rigidly attached to it are merged on the device, the boundary converts) */
 int rkfdBatchGetContact(rkfdBatch *b, int *active, int *type, double *ref, double *f);
 int rkfdBatchSetContact(rkfdBatch *b, const int *active, const int *type, const double *ref);
 /* joint friction pivots rkJointFrictionPivot{type,prev_trq} (reference src/rkfd_util.c:289-311): [batch][nlink] */

@@ -67,6 +67,11 @@ typedef struct {
   const int *shape_foff;   /* [nshape+1] prefix offsets into planes         */
   const double *verts;     /* [nvert*3]                                     */
   const double *planes;    /* [nplane*4] outward unit normal n and offset d: inside <=> n.x - d <= 0 */
+  /* slide mode of a shape's collision cell (rkFDCDCellSetSlideMode / Vel / Axis, reference src/rkfd_sim.c:384-401):
+   * the surface is taken to run along itself like a crawler belt */
+  const int *shape_slide_mode;      /* [nshape] 0 / 1                         */
+  const double *shape_slide_vel;    /* [nshape]                               */
+  const double *shape_slide_axis;   /* [nshape*3] in the link frame           */
   /* ---- collision pairs (rkCD plist) and contact infos ------------------ */
   int npair;
   const int *pair_shape;   /* [npair*2]                                     */

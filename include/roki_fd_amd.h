@@ -140,6 +140,9 @@ void rkFDDestroy(rkFD *fd);
 rkFDCell *rkFDChainReg(rkFD *fd, rkChain *chain);
 rkFDCell *rkFDChainRegFile(rkFD *fd, char filename[]);
 bool rkFDChainUnreg(rkFD *fd, rkFDCell *cell);
+/* slide mode of a collision cell (fake crawler; reference rkFDShape3DSetSlideMode / Vel / Axis, src/rkfd_sim.c:412-440):
+ * the shape is named by its number in the cell's chain; axis in the link frame */
+bool rkFDCellSetSlide(rkFDCell *cell, int shape, bool mode, double vel, const double axis[3]);
 void rkFDChainSetDis(rkFDCell *lc, zVec dis);
 void rkFDChainSetVel(rkFDCell *lc, zVec vel);
 bool rkFDContactInfoScanFile(rkFD *fd, char filename[]);
@@ -185,6 +188,7 @@ void rkfdWorldPairChainUnreg(rkfdWorldHandle *w, int chain);
 /* rkFDPrpSet* + rkFDSetSolver */
 void rkfdWorldSetPrp(rkfdWorldHandle *w, double dt, double friction_weight, int max_iter, int solver);
 void rkfdWorldSetPyramid(rkfdWorldHandle *w, int pyramid);
+int  rkfdWorldSetSlide(rkfdWorldHandle *w, int chain, int shape, int mode, double vel, const double axis[3]);
 const rkfdModel *rkfdWorldModel(rkfdWorldHandle *w);
 int  rkfdWorldChainDofOffset(const rkfdWorldHandle *w, int chain);
 int  rkfdWorldChainLinkOffset(const rkfdWorldHandle *w, int chain);

@@ -672,14 +672,65 @@ static void link_point_acc(const Link *l, const double *x, double *a)
   al[0] = l->a[0]+t[0]+s[0]; al[1] = l->a[1]+t[1]+s[1]; al[2] = l->a[2]+t[2]+s[2];
   m3_mulv( l->R, al, a );
 }
+/* the two shapes (collision cells) of candidate j: owner of the vertex, the other one */
+static void cand_shapes(const rkfdOracle *o, int j, int *own, int *oth)
+{
+  const rkfdModel *m = o->m;
+  int pr = m->cand_pair[j], sd = m->cand_side[j];
+  *own = m->pair_shape[2*pr+sd]; *oth = m->pair_shape[2*pr+1-sd];
+}
+/* rkFDLinkAddSlideVel (reference src/rkfd_util.c:26-40): a cell in slide mode adds the velocity of a surface
+ * running around its slide axis, tangential to the contact normal n, of magnitude slide_vel */
+static void slide_dir(const rkfdOracle *o, int shape, const double *p, const double *n, double *sv)
+{
+  const rkfdModel *m = o->m;
+  const Link *l = &o->lk[m->shape_link[shape]];
+  double tmpv[3], ax[3];
+  v3_sub( p, l->p, tmpv );
+  m3_mulv( l->R, &m->shape_slide_axis[3*shape], ax );
+  v3_cross( ax, tmpv, sv );
+  v3_cat( sv, -v3_dot( sv, n ), n );
+}
+static void add_slide_vel(const rkfdOracle *o, int shape, const double *p, const double *n, double *v)
+{
+  double sv[3], nr;
+  slide_dir( o, shape, p, n, sv );
+  nr = v3_norm( sv );
+  if( is_tiny( nr ) ) return;
+  v3_cat( v, o->m->shape_slide_vel[shape]/nr, sv );
+}
 /* rkFDChainPointRelativeVel / ...Acc (reference src/rkfd_util.c:42-60,103-118): owner minus other;
- * every cell is RK_CD_CELL_MOVE (reference src/rkfd_sim.c:198); slide mode is not modelled */
+ * every cell is RK_CD_CELL_MOVE (reference src/rkfd_sim.c:198) */
 static void rel_vel(const rkfdOracle *o, int j, double *v)
 {
   double a[3], b[3];
+  int own, oth;
   link_point_vel( &o->lk[o->clinkA[j]], &o->cx[3*j], a );
   link_point_vel( &o->lk[o->clinkB[j]], &o->cx[3*j], b );
+  cand_shapes( o, j, &own, &oth );
+  if( o->m->shape_slide_mode[own] ) add_slide_vel( o, own, &o->cx[3*j], &o->cnorm[3*j], a );
+  if( o->m->shape_slide_mode[oth] ) add_slide_vel( o, oth, &o->cx[3*j], &o->cnorm[3*j], b );
   v3_sub( a, b, v );
+}
+/* rkFDUpdateRefSlide (reference src/rkfd_util.c:218-237): when a vertex stays in static friction on a cell in
+ * slide mode, its anchor _ref is carried along by dt * slide_vel.  cell[0], cell[1] are the pair's shapes in
+ * registration order; the anchor lives in the frame named by the reference's index expression. */
+static void update_ref_slide(rkfdOracle *o, int j)
+{
+  const rkfdModel *m = o->m;
+  int pr = m->cand_pair[j], sd = m->cand_side[j], i;
+  for( i=0; i<2; i++ ){
+    int sh = m->pair_shape[2*pr+i], isown = ( i == sd ), tgt;
+    double sv[3], nr, t[3];
+    if( !m->shape_slide_mode[sh] ) continue;
+    slide_dir( o, sh, &o->cx[3*j], &o->cnorm[3*j], sv );
+    nr = v3_norm( sv );
+    if( is_tiny( nr ) ) continue;
+    v3_mul( sv, ( isown ? -1.0 : 1.0 )*m->dt*m->shape_slide_vel[sh]/nr, sv );
+    tgt = m->pair_shape[2*pr+( isown ? 1 : 0 )];
+    m3_tmulv( o->lk[m->shape_link[tgt]].R, sv, t );
+    v3_add( &o->cv_ref[3*j], t, &o->cv_ref[3*j] );
+  }
 }
 static void rel_acc(const rkfdOracle *o, int j, double *r)
 {
@@ -780,7 +831,7 @@ static void modify_friction(rkfdOracle *o, int j, const double *vr, int doUpRef)
       v3_copy( &o->cpro[3*j], &o->cv_ref[3*j] );
     }
   } else {
-    if( doUpRef ) o->cv_type[j] = RKFD_SF; /* rkFDUpdateRefSlide: no slide-mode cells */
+    if( doUpRef ){ o->cv_type[j] = RKFD_SF; update_ref_slide( o, j ); }
   }
 }
 
@@ -931,6 +982,7 @@ static int mlcp(rkfdOracle *o, int doUpRef)
       v3_copy( &o->cpro[3*j], &o->cv_ref[3*j] );
     } else {
       o->cv_type[j] = RKFD_SF;
+      update_ref_slide( o, j );      /* reference src/rkfd_mlcp.c:279 */
     }
   }
   return 0;
@@ -1185,7 +1237,8 @@ static int vert_rigid(rkfdOracle *o, int doUpRef)
         o->cv_type[j] = RKFD_KF;
         v3_copy( &o->cpro[3*j], &o->cv_ref[3*j] );
       } else {
-        o->cv_type[j] = RKFD_SF;      /* rkFDUpdateRefSlide: slide-mode cells are not modelled */
+        o->cv_type[j] = RKFD_SF;
+        update_ref_slide( o, j );     /* reference src/rkfd_vert.c:318 */
       }
     }
   }

@@ -32,6 +32,7 @@ class RkfdModel(C.Structure):
         ("nshape", C.c_int),
         ("shape_link", _pi), ("shape_voff", _pi), ("shape_foff", _pi),
         ("verts", _pd), ("planes", _pd),
+        ("shape_slide_mode", _pi), ("shape_slide_vel", _pd), ("shape_slide_axis", _pd),
         ("npair", C.c_int),
         ("pair_shape", _pi), ("pair_ci", _pi),
         ("nci", C.c_int),
@@ -69,6 +70,7 @@ def lib():
     L.rkfdWorldPairChainUnreg.argtypes = [vp, C.c_int]
     L.rkfdWorldSetPrp.argtypes = [vp, C.c_double, C.c_double, C.c_int, C.c_int]
     L.rkfdWorldSetPyramid.argtypes = [vp, C.c_int]
+    L.rkfdWorldSetSlide.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, vp]; L.rkfdWorldSetSlide.restype = C.c_int
     L.rkfdWorldModel.argtypes = [vp]
     L.rkfdWorldModel.restype = C.POINTER(RkfdModel)
     L.rkfdWorldChainDofOffset.argtypes = [vp, C.c_int]
@@ -127,6 +129,12 @@ class World:
             self.close()
         except Exception:
             pass
+
+    def set_slide(self, chain, shape, mode, vel=0.0, axis=(0.0, 1.0, 0.0)):
+        """rkFDCDCellSetSlideMode / Vel / Axis on shape number `shape` of a chain (its order in the ZTK file)"""
+        ax = (C.c_double * 3)(*axis)
+        if self._L.rkfdWorldSetSlide(self._w, int(chain), int(shape), int(bool(mode)), float(vel), ax) != 0:
+            raise RkfdError("no such chain / shape")
 
     def set_pyramid(self, pyramid):
         """rkFDPrpSetPyramid: faces of the Vert plugin's friction pyramid (default 8)"""

@@ -298,6 +298,8 @@ typedef struct {
   double *REF;                    /* stick anchors (state): per active slot              */
   double *RTMP;                   /* [maxact*3] copy of REF while the slots are re-assigned; only when ncand > 64 */
   double *CF;                     /* contact forces (output): per active slot              */
+  double *SV, *SD;                /* slide mode only: relative slide velocity of the two cells (world), anchor drift of one
+                                     committing evaluation (anchor frame); per active slot, 3 each */
   double *QL, *QW, *QV, *CR;      /* Vert QP (only when the world can have rigid contacts under the Vert plugin):
                                      [M*M] Q / its Cholesky factor, [M*M] W = L^-1 C', [5M (+64)] vectors (+ reduction scratch
                                      unless it overlays the link accelerations), [3M] reduced rows */
@@ -312,7 +314,7 @@ typedef struct {
   unsigned char *PL;              /* [NL*nlevel] ancestor at depth d (MLCP only), one byte each */
 } rkfdLds;
 
-RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int M, int nlevel, int npool, int nfloat, int maxact, int nside, int pu_alias, int npurow, int vert_rigid)
+RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int M, int nlevel, int npool, int nfloat, int maxact, int nside, int pu_alias, int npurow, int vert_rigid, int has_slide)
 /* must match the byte count computed in rkfd_devmodel.cpp */
 {
   double *d = (double *)base;
@@ -334,6 +336,7 @@ RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int
   L->CX = d; d += maxact*3; L->AX = d; d += maxact*9; L->RW = d; d += maxact*3; L->PRO = d; d += maxact*3;
   L->REF = d; d += maxact*3; L->RTMP = d; if( NC > RKFD_WAVE ) d += maxact*3;
   L->CF = d; d += maxact*3;
+  L->SV = d; L->SD = d; if( has_slide ){ L->SV = d; d += maxact*3; L->SD = d; d += maxact*3; }
   L->MB = d; d += M; L->MF = d; d += M;
   /* probe scratch: lives while the contact problem is set up and solved, when C and PA are dead */
   if( pu_alias ) L->PU = L->C; else { L->PU = d; d += nside*npurow*M; }

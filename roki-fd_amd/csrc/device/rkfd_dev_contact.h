@@ -40,14 +40,14 @@ RKFD_DEV void rkfd_phase_collision(const rkfdDevModel &m, const rkfdLds &L)
     const bool on = c0+lane < m.ncand;
     const int j = on ? c0+lane : 0;
     int is_act = 0, is_rg = 0, is_el = 0, fbest = -1;
-    double x[3] = {0,0,0}, y[3] = {0,0,0}, smax = -HUGE_VAL, RB[9], pB[3];
+    double x[3] = {0,0,0}, y[3] = {0,0,0}, smax = -HUGE_VAL, RB[9], pB[3], RA[9], pA[3] = {0,0,0};
     const int cinf = L.CIp[j];
 #pragma unroll
-    for( int k=0; k<9; k++ ) RB[k] = 0;
+    for( int k=0; k<9; k++ ){ RB[k] = 0; RA[k] = 0; }
     pB[0] = pB[1] = pB[2] = 0;
     if( on ){
       const int la = RKFD_CI_A( cinf ), lb = RKFD_CI_B( cinf );
-      double RA[9], pA[3], vl[3], rr[3];
+      double vl[3], rr[3];
 #pragma unroll
       for( int k=0; k<6; k++ ){ RA[k] = L.XA[6*la+k]; RB[k] = L.XA[6*lb+k]; }
 #pragma unroll
@@ -94,6 +94,38 @@ RKFD_DEV void rkfd_phase_collision(const rkfdDevModel &m, const rkfdLds &L)
         d_ortho_space( nw, t1, t2 );
 #pragma unroll
         for( int k=0; k<3; k++ ){ L.AX[9*slot+k] = nw[k]; L.AX[9*slot+3+k] = t1[k]; L.AX[9*slot+6+k] = t2[k]; }
+        if( m.has_slide ){
+          /* cells in slide mode (rkFDLinkAddSlideVel, rkFDUpdateRefSlide; reference src/rkfd_util.c:26-40,218-237):
+           * the surface runs around its slide axis, tangentially to the contact normal.  The frames are at hand
+           * only here, so the relative slide velocity and the anchor drift of a committing evaluation are kept per slot. */
+          double sv[3] = {0,0,0}, sd[3] = {0,0,0};
+#pragma unroll
+          for( int k=0; k<2; k++ ){
+            const int md = RELOAD( m.cs_mode )[2*j+k];
+            if( !md ) continue;
+            const double *pr = &RELOAD( m.cs_par )[14*j+7*k];
+            const double *Rk = k == 0 ? RA : RB, *pk = k == 0 ? pA : pB;
+            const double axl[3] = { pr[1], pr[2], pr[3] }, orl[3] = { pr[4], pr[5], pr[6] };
+            double axw[3], orw[3], t[3], s[3];
+            d_mulv( Rk, axl, axw ); d_mulv( Rk, orl, orw );
+            t[0] = x[0]-pk[0]-orw[0]; t[1] = x[1]-pk[1]-orw[1]; t[2] = x[2]-pk[2]-orw[2];
+            d_cross( axw, t, s );
+            const double sn = d_dot( s, nw );
+            s[0] -= sn*nw[0]; s[1] -= sn*nw[1]; s[2] -= sn*nw[2];
+            const double nr = sqrt( d_dot( s, s ) );
+            if( fabs( nr ) < RKFD_DEV_TOL ) continue;
+            const double g = pr[0]/nr, sg = k == 0 ? 1.0 : -1.0;
+            sv[0] += sg*g*s[0]; sv[1] += sg*g*s[1]; sv[2] += sg*g*s[2];
+            /* anchor drift: -+ dt slide_vel along s, rotated into the frame the reference's index picks */
+            const double h = ( k == 0 ? -1.0 : 1.0 )*m.dt*g;
+            const double w3[3] = { h*s[0], h*s[1], h*s[2] };
+            double l3[3];
+            d_tmulv( ( md & 2 ) ? RA : RB, w3, l3 );
+            sd[0] += l3[0]; sd[1] += l3[1]; sd[2] += l3[2];
+          }
+          L.SV[3*slot] = sv[0]; L.SV[3*slot+1] = sv[1]; L.SV[3*slot+2] = sv[2];
+          L.SD[3*slot] = sd[0]; L.SD[3*slot+1] = sd[1]; L.SD[3*slot+2] = sd[2];
+        }
         const int ct = m.ci_type[RKFD_CI_CI( cinf )];
         is_rg = ct == RKFD_CONTACT_RIGID; is_el = ct == RKFD_CONTACT_ELASTIC;
       } else {
@@ -186,7 +218,10 @@ RKFD_DEV void d_modify_friction(const rkfdDevModel &m, const rkfdLds &L, int j, 
       { const int ri = RIDX( j ), sl_ = L.asl[j]; L.REF[3*ri] = L.PRO[3*sl_]; L.REF[3*ri+1] = L.PRO[3*sl_+1]; L.REF[3*ri+2] = L.PRO[3*sl_+2]; }
     }
   } else {
-    if( doUpRef ) L.typ[j] = RKFD_SF;
+    if( doUpRef ){
+      L.typ[j] = RKFD_SF;
+      if( m.has_slide ){ const int ri = RIDX( j ), sl_ = L.asl[j]; L.REF[3*ri] += L.SD[3*sl_]; L.REF[3*ri+1] += L.SD[3*sl_+1]; L.REF[3*ri+2] += L.SD[3*sl_+2]; }
+    }
   }
 }
 
@@ -204,7 +239,7 @@ RKFD_DEV void rkfd_phase_penalty(const rkfdDevModel &m, const rkfdLds &L, bool d
     const double E = m.ci_e[ci], kv = -1.0*( m.ci_v[ci] + E*m.dt );
 #pragma unroll
     for( int k=0; k<3; k++ ){
-      vr[k] = va[k]-vb[k];
+      vr[k] = va[k]-vb[k] + ( m.has_slide ? L.SV[3*L.asl[j]+k] : 0.0 );
       f[k] = -E*( x[k]-L.RW[3*L.asl[j]+k] ) + kv*vr[k];
     }
     if( d_dot( f, &L.AX[9*L.asl[j]] ) < 0.0 ){
@@ -239,6 +274,7 @@ RKFD_DEV void rkfd_phase_bvel(const rkfdDevModel &m, const rkfdLds &L, double *b
     for( int i=0; i<3; i++ ){
       const double *ax = &L.AX[9*sl+3*i];
       bv[i]   = ax[0]*( va[0]-vb[0] ) + ax[1]*( va[1]-vb[1] ) + ax[2]*( va[2]-vb[2] );
+      if( m.has_slide ) bv[i] += ax[0]*L.SV[3*sl] + ax[1]*L.SV[3*sl+1] + ax[2]*L.SV[3*sl+2];
       bv[3+i] = ax[0]*( ca[0]-cb[0] ) + ax[1]*( ca[1]-cb[1] ) + ax[2]*( ca[2]-cb[2] );
     }
   }

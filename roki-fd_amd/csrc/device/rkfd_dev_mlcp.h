@@ -279,6 +279,7 @@ template<bool prof, bool vqp> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &
           { const int ri = RIDX( j ), sl_ = L.asl[j]; L.REF[3*ri] = L.PRO[3*sl_]; L.REF[3*ri+1] = L.PRO[3*sl_+1]; L.REF[3*ri+2] = L.PRO[3*sl_+2]; }
         } else {
           L.typ[j] = RKFD_SF;
+          if( m.has_slide ){ const int ri = RIDX( j ), sl_ = L.asl[j]; L.REF[3*ri] += L.SD[3*sl_]; L.REF[3*ri+1] += L.SD[3*sl_+1]; L.REF[3*ri+2] += L.SD[3*sl_+2]; }
         }
       }
     }
@@ -354,6 +355,7 @@ template<bool prof, bool vqp> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &
       { const int ri = RIDX( j ), sl_ = L.asl[j]; L.REF[3*ri] = L.PRO[3*sl_]; L.REF[3*ri+1] = L.PRO[3*sl_+1]; L.REF[3*ri+2] = L.PRO[3*sl_+2]; }
     } else {
       L.typ[j] = RKFD_SF;
+      if( m.has_slide ){ const int ri = RIDX( j ), sl_ = L.asl[j]; L.REF[3*ri] += L.SD[3*sl_]; L.REF[3*ri+1] += L.SD[3*sl_+1]; L.REF[3*ri+2] += L.SD[3*sl_+2]; }
     }
   }
   }

@@ -101,7 +101,7 @@ template<bool prof, bool vqp> RKFD_DEV void rkfd_instance(const rkfdDevModel &m,
   const int lane = LANE();
   const int ND = m.ndof, NL = m.nlink, NC = m.ncand;
   rkfdLds L;
-  rkfd_lds_carve( &L, ldsbase, NL, ND, NC, 3*m.maxrg, m.nlevel, m.npool, m.nfloat, m.maxact, m.nside, m.pu_alias, m.npurow, m.vert_rigid );
+  rkfd_lds_carve( &L, ldsbase, NL, ND, NC, 3*m.maxrg, m.nlevel, m.npool, m.nfloat, m.maxact, m.nside, m.pu_alias, m.npurow, m.vert_rigid, m.has_slide );
   if( lane == 0 ){ L.cnt[CNT_OVF] = 0; L.cnt[CNT_QPF] = 0; }
 
   /* load persistent state */

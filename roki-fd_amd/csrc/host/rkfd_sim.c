@@ -408,6 +408,27 @@ void rkfdWorldSetPrp(rkfdWorld *w, double dt, double friction_weight, int max_it
   w->cidef.type = RKFD_CONTACT_RIGID; w->cidef.k = 1000.0; w->cidef.l = 1.0; w->cidef.sf = 0.5; w->cidef.kf = 0.3;
   w->built = 0;
 }
+/* rkFDCDCellSetSlideMode / Vel / Axis (reference src/rkfd_sim.c:384-401) on shape number `shape` of a chain
+ * (its order in the ZTK file); axis in the link frame.  Returns 0, -1 for an unknown chain / shape. */
+int rkfdWorldSetSlide(rkfdWorld *w, int chain, int shape, int mode, double vel, const double axis[3])
+{
+  rkfdShape *sh;
+  if( chain < 0 || chain >= w->nchain || shape < 0 || shape >= w->chain[chain]->nshape ) return -1;
+  sh = &w->chain[chain]->shape[shape];
+  sh->slide_mode = mode ? 1 : 0; sh->slide_vel = vel;
+  if( axis ){ sh->slide_axis[0] = axis[0]; sh->slide_axis[1] = axis[1]; sh->slide_axis[2] = axis[2]; }
+  w->built = 0;
+  return 0;
+}
+/* the same through the rkFD mirror: the role of rkFDShape3DSetSlideMode / Vel / Axis (reference src/rkfd_sim.c:412-440),
+ * the shape named by its number in the cell's chain */
+bool rkFDCellSetSlide(rkFDCell *cell, int shape, bool mode, double vel, const double axis[3])
+{
+  rkFDImpl *im = IMPL( cell->chain.fd );
+  if( rkfdWorldSetSlide( &im->world, cell->chain.id, shape, mode, vel, axis ) != 0 ) return false;
+  im->dirty = 1;
+  return true;
+}
 /* rkFDPrpSetPyramid for the flat loader: faces of the Vert plugin's friction pyramid */
 void rkfdWorldSetPyramid(rkfdWorld *w, int pyramid){ w->model.pyramid = pyramid; w->built = 0; }
 const rkfdModel *rkfdWorldModel(rkfdWorld *w)

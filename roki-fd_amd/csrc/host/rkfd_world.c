@@ -138,6 +138,7 @@ int rkfdWorldBuild(rkfdWorld *w)
   double *stiff = NULL, *visc = NULL, *coulomb = NULL, *sfric = NULL;
   double *mot_k = NULL, *mot_admit = NULL, *mot_vmax = NULL, *mot_vmin = NULL, *mot_gear = NULL, *mot_inertia = NULL;
   int *shape_link = NULL, *shape_voff = NULL, *shape_foff = NULL, *shape_chain = NULL;
+  int *shape_slide_mode = NULL; double *shape_slide_vel = NULL, *shape_slide_axis = NULL;
   double *verts = NULL, *planes = NULL;
   int *pair_shape = NULL, *pair_ci = NULL, *ci_type = NULL;
   double *ci_sf = NULL, *ci_kf = NULL, *ci_k = NULL, *ci_l = NULL, *ci_e = NULL, *ci_v = NULL;
@@ -196,6 +197,7 @@ int rkfdWorldBuild(rkfdWorld *w)
     GET( mot_vmin, double, nlink ); GET( mot_gear, double, nlink ); GET( mot_inertia, double, nlink );
     GET( shape_link, int, nshape ); GET( shape_voff, int, nshape+1 ); GET( shape_foff, int, nshape+1 );
     GET( shape_chain, int, nshape );
+    GET( shape_slide_mode, int, nshape ); GET( shape_slide_vel, double, nshape ); GET( shape_slide_axis, double, nshape*3 );
     GET( shape_stuff, const char *, nshape );
     GET( verts, double, nvert*3 ); GET( planes, double, nplane*4 );
     GET( pair_shape, int, npair*2 ); GET( pair_ci, int, npair );
@@ -231,6 +233,8 @@ int rkfdWorldBuild(rkfdWorld *w)
           if( sh->nvert == 0 || sh->nplane == 0 ) continue;
           shape_link[si] = li; shape_chain[si] = c; shape_stuff[si] = l->stuff;
           shape_voff[si] = vi; shape_foff[si] = fi;
+          shape_slide_mode[si] = sh->slide_mode; shape_slide_vel[si] = sh->slide_vel;
+          memcpy( &shape_slide_axis[3*si], sh->slide_axis, sizeof(double)*3 );
           memcpy( &verts[3*vi], sh->vert, sizeof(double)*3*sh->nvert );
           memcpy( &planes[4*fi], sh->plane, sizeof(double)*4*sh->nplane );
           vi += sh->nvert; fi += sh->nplane; si++;
@@ -271,6 +275,7 @@ int rkfdWorldBuild(rkfdWorld *w)
   m->mtype = mtype; m->mot_k = mot_k; m->mot_admit = mot_admit; m->mot_vmax = mot_vmax;
   m->mot_vmin = mot_vmin; m->mot_gear = mot_gear; m->mot_inertia = mot_inertia;
   m->nshape = nshape; m->shape_link = shape_link; m->shape_voff = shape_voff; m->shape_foff = shape_foff;
+  m->shape_slide_mode = shape_slide_mode; m->shape_slide_vel = shape_slide_vel; m->shape_slide_axis = shape_slide_axis;
   m->verts = verts; m->planes = planes;
   m->npair = npair; m->pair_shape = pair_shape; m->pair_ci = pair_ci;
   m->nci = w->nci+1; m->ci_type = ci_type; m->ci_sf = ci_sf; m->ci_kf = ci_kf;

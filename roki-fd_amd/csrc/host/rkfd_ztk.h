@@ -29,6 +29,8 @@ typedef struct {
   double *vert;      /* [nvert*3] link frame */
   int nplane;
   double *plane;     /* [nplane*4] outward unit normal + offset */
+  /* slide mode of the shape's collision cell (fake crawler; reference src/rkfd_sim.c:384-440): off by default */
+  int slide_mode; double slide_vel, slide_axis[3];
 } rkfdShape;
 
 typedef struct {

@@ -186,6 +186,7 @@ extern "C" int rkfdBatchGetContact(rkfdBatch *b, int *active, int *type, double 
   D2H( ref, b->st.cv_ref, sizeof(double)*3*n ); D2H( f, b->st.cv_f, sizeof(double)*3*n );
   /* a candidate out of contact has no state: the device keeps whatever it last held there
    * (it is rewritten at the next first contact), the boundary reports zeros */
+  if( ref && n ) rkfd_ref_to_model( &b->host, ref, n );      /* device link frame -> model link frame */
   for( size_t i=0; i<n; i++ ){
     if( active ) active[i] = act[i];
     if( act[i] ) continue;
@@ -201,7 +202,11 @@ extern "C" int rkfdBatchSetContact(rkfdBatch *b, const int *active, const int *t
   HIPCHK( hipSetDevice( b->device ), -1 );
   const size_t n = (size_t)b->batch*b->ncand;
   H2D( b->st.cv_active, active, sizeof(int)*n ); H2D( b->st.cv_type, type, sizeof(int)*n );
-  H2D( b->st.cv_ref, ref, sizeof(double)*3*n );
+  if( ref && n ){
+    std::vector<double> rd( ref, ref + 3*n );
+    rkfd_ref_to_device( &b->host, rd.data(), n );             /* model link frame -> device link frame */
+    HIPCHK( hipMemcpy( b->st.cv_ref, rd.data(), sizeof(double)*3*n, hipMemcpyHostToDevice ), -1 );
+  }
   return 0;
 }
 extern "C" int rkfdBatchGetPivot(rkfdBatch *b, int *type, double *prev_trq)

@@ -197,6 +197,33 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
     const double *T = &Trep[12*m->shape_link[shA]], *v = &m->verts[3*m->cand_vert[j]];
     for( int a=0; a<3; a++ ) cv[3*j+a] = T[9+a] + T[3*a]*v[0] + T[3*a+1]*v[1] + T[3*a+2]*v[2];
   }
+  std::vector<double> refT( (size_t)12*( NC ? NC : 1 ), 0.0 );
+  for( int j=0; j<NC; j++ ){
+    const int pr = m->cand_pair[j], sd = m->cand_side[j];
+    memcpy( &refT[12*j], &Trep[12*m->shape_link[m->pair_shape[2*pr+1-sd]]], sizeof(double)*12 );
+  }
+  /* slide-mode cells of the candidates */
+  int has_slide = 0;
+  for( int sh=0; sh<m->nshape; sh++ ) if( m->shape_slide_mode && m->shape_slide_mode[sh] ) has_slide = 1;
+  std::vector<int> csm( has_slide ? (size_t)2*NC : 1, 0 );
+  std::vector<double> csp( has_slide ? (size_t)14*NC : 1, 0.0 );
+  if( has_slide ){
+    for( int j=0; j<NC; j++ ){
+      const int pr = m->cand_pair[j], sd = m->cand_side[j];
+      for( int k=0; k<2; k++ ){            /* k = 0: the cell that owns the vertex, 1: the other cell */
+        const int i = k == 0 ? sd : 1-sd;  /* index of that cell in the pair */
+        const int sh = m->pair_shape[2*pr+i];
+        const int isown = k == 0;
+        /* the anchor drift is rotated into the frame of cell[ isown ? 1 : 0 ] (reference src/rkfd_util.c:232) */
+        const int tgt_is_own = ( isown ? 1 : 0 ) == sd;
+        csm[2*j+k] = m->shape_slide_mode[sh] ? ( tgt_is_own ? 3 : 1 ) : 0;
+        const double *T = &Trep[12*m->shape_link[sh]], *ax = &m->shape_slide_axis[3*sh];
+        double *o = &csp[14*j+7*k];
+        o[0] = m->shape_slide_vel[sh];
+        for( int a=0; a<3; a++ ){ o[1+a] = T[3*a]*ax[0] + T[3*a+1]*ax[1] + T[3*a+2]*ax[2]; o[4+a] = T[9+a]; }
+      }
+    }
+  }
   const int nplane = m->nshape > 0 ? m->shape_foff[m->nshape] : 0;
   if( m->nci > 255 ) FAIL( "too many contact infos" );
   /* packed link / candidate info */
@@ -357,6 +384,8 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   PUT( cand_linkA, cA.data(), sizeof(int)*NC ); PUT( cand_linkB, cB.data(), sizeof(int)*NC );
   PUT( cand_foff, cfo.data(), sizeof(int)*NC ); PUT( cand_nf, cnf.data(), sizeof(int)*NC );
   PUT( cand_ci, cci.data(), sizeof(int)*NC ); PUT( cand_vert, cv.data(), sizeof(double)*3*NC );
+  dm.has_slide = has_slide;
+  PUT( cs_mode, csm.data(), sizeof(int)*csm.size() ); PUT( cs_par, csp.data(), sizeof(double)*csp.size() );
   PUT( planes, planes_d.data(), sizeof(double)*4*nplane );
   PUT( ci_type, m->ci_type, sizeof(int)*m->nci );
   PUT( ci_sf, m->ci_sf, sizeof(double)*m->nci ); PUT( ci_kf, m->ci_kf, sizeof(double)*m->nci );
@@ -369,6 +398,13 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   memcpy( out->blob, b.buf.data(), out->bytes );
   for( size_t k=0; k<ents.size(); k++ ) *ents[k].slot = (const char *)out->blob + ents[k].off;
   out->dm = dm;
+  {
+    /* host-only table, appended to the blob's allocation lifetime through a separate copy */
+    double *rf = (double *)malloc( sizeof(double)*refT.size() );
+    if( !rf ) FAIL( "out of memory" );
+    memcpy( rf, refT.data(), sizeof(double)*refT.size() );
+    out->ref_frame = rf; out->ncand = NC;
+  }
   /* LDS bytes one instance needs (must match rkfd_lds_carve in rkfd_device.h) */
   {
     const size_t M = 3*(size_t)max_rigid;
@@ -376,7 +412,7 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
     size_t stage = (size_t)14*NL + pool;                         /* inertia staging + Ia pool ...   */
     if( M*(M+1) > stage ) stage = M*(M+1);                       /* ... shared with the MLCP matrix */
     const size_t dbl = (size_t)3*ND + (size_t)NL*( 5*6 + 4 ) + stage + (size_t)48*nfloat
-                     + (size_t)maxact*( 24 + ( NC > RKFD_WAVE ? 3 : 0 ) ) + 2*M + ( dm.pu_alias ? 0 : (size_t)nside*npurow*M )
+                     + (size_t)maxact*( 24 + ( NC > RKFD_WAVE ? 3 : 0 ) + ( dm.has_slide ? 6 : 0 ) ) + 2*M + ( dm.pu_alias ? 0 : (size_t)nside*npurow*M )
                      + ( dm.vert_rigid ? 2*M*M + 5*M + ( dm.qscr_alias ? 0 : RKFD_WAVE ) + 3*M : 0 );   /* Vert QP: QL, QW, QV, CR */
     const size_t ints = (size_t)5*NC + (size_t)4*maxact + 8 + 3*(size_t)NL + ( dm.vert_rigid ? M : 0 )     /* act typ asl CIp CFO, lrg lel tgt, cnt, LI CHI PSL */
                       + ( max_rigid > 0 ? ( (size_t)NL*( nlevel+3 ) + 3 )/4 : 0 );   /* PL (bytes) */
@@ -389,7 +425,7 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
 
 extern "C" void rkfd_devmodel_free(rkfdDevModelHost *h)
 {
-  if( h ){ free( h->blob ); h->blob = NULL; }
+  if( h ){ free( h->blob ); h->blob = NULL; free( (void *)h->ref_frame ); h->ref_frame = NULL; }
 }
 
 extern "C" void rkfd_devmodel_rebase(rkfdDevModel *dm, const void *from, const void *to)
@@ -400,7 +436,25 @@ extern "C" void rkfd_devmodel_rebase(rkfdDevModel *dm, const void *from, const v
   RB(org); RB(mass); RB(com); RB(inertia); RB(stiff); RB(visc); RB(coulomb); RB(sfric);
   RB(mot_k); RB(mot_admit); RB(mot_vmax); RB(mot_vmin); RB(mot_gear); RB(mot_inertia);
   RB(anc); RB(level_off); RB(level_link); RB(child_off); RB(child_idx); RB(pathlink); RB(linfo); RB(sched); RB(cinfo); RB(pslot); RB(orig); RB(dofkind);
-  RB(cand_linkA); RB(cand_linkB); RB(cand_foff); RB(cand_nf); RB(cand_ci); RB(cand_vert); RB(planes);
+  RB(cand_linkA); RB(cand_linkB); RB(cand_foff); RB(cand_nf); RB(cand_ci); RB(cand_vert); RB(cs_mode); RB(cs_par); RB(planes);
   RB(ci_type); RB(ci_sf); RB(ci_kf); RB(ci_k); RB(ci_l); RB(ci_e); RB(ci_v);
 #undef RB
+}
+
+extern "C" void rkfd_ref_to_device(const rkfdDevModelHost *h, double *ref, size_t n)
+{
+  for( size_t k=0; k<n; k++ ){
+    const double *T = &h->ref_frame[12*( k % (size_t)h->ncand )];
+    double *r = &ref[3*k], o[3];
+    for( int a=0; a<3; a++ ) o[a] = T[3*a]*r[0] + T[3*a+1]*r[1] + T[3*a+2]*r[2] + T[9+a];
+    r[0] = o[0]; r[1] = o[1]; r[2] = o[2];
+  }
+}
+extern "C" void rkfd_ref_to_model(const rkfdDevModelHost *h, double *ref, size_t n)
+{
+  for( size_t k=0; k<n; k++ ){
+    const double *T = &h->ref_frame[12*( k % (size_t)h->ncand )];
+    double *r = &ref[3*k], d[3] = { r[0]-T[9], r[1]-T[10], r[2]-T[11] };
+    for( int a=0; a<3; a++ ) r[a] = T[a]*d[0] + T[3+a]*d[1] + T[6+a]*d[2];
+  }
 }

@@ -57,6 +57,13 @@ typedef struct {
   /* per candidate contact vertex */
   const int *cand_linkA, *cand_linkB, *cand_foff, *cand_nf, *cand_ci;
   const double *cand_vert; /* [ncand*3] vertex in link A's frame                         */
+  /* slide mode (fake crawler), only when has_slide: per candidate the two cells, owner first:
+   * cs_mode [ncand*2] 0/1 | 2 when the anchor drift is expressed in the OWNER link's frame (reference index quirk,
+   * src/rkfd_util.c:232), cs_par [ncand*14]: slide_vel, axis(3), origin of the shape's model link (3), both in the
+   * device link's frame, owner then other */
+  int has_slide;
+  const int *cs_mode;
+  const double *cs_par;
   const int *cinfo;        /* [ncand] packed: linkA | linkB<<8 | ci<<16 | nf<<24              */
   const double *planes;    /* [nplane*4] in link B's frame                               */
   /* contact infos */

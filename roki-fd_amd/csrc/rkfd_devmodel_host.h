@@ -15,7 +15,18 @@ typedef struct {
   void *blob;
   size_t bytes;
   size_t lds_bytes;  /* LDS one instance needs */
+  /* stick anchors (rkCDVert _ref) live in the frame of the other cell's link.  On the device that is the
+   * DEVICE link (rigidly attached model links are merged into it); at the boundary they are given in the
+   * model link's frame, as in the reference.  ref_frame[12*j]: frame (R row-major, p) of candidate j's
+   * other model link in its device link (inside blob). */
+  const double *ref_frame;
+  int ncand;
 } rkfdDevModelHost;
+
+/* anchors between the model link's frame (boundary) and the device link's frame (device state), in place:
+ * n = batch * ncand anchors, candidate index = k % ncand */
+void rkfd_ref_to_device(const rkfdDevModelHost *h, double *ref, size_t n);
+void rkfd_ref_to_model(const rkfdDevModelHost *h, double *ref, size_t n);
 
 /* max_rigid: capacity of rigid contact vertices solved per instance */
 int  rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevModelHost *out, char *err, int errlen);

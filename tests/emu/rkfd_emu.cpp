@@ -65,6 +65,8 @@ extern "C" int rkfd_emu_run(const rkfdModel *m, int max_rigid, rkfdDevState *st,
   rkfdDevModelHost h;
   char err[256];
   if( rkfd_devmodel_build( m, max_rigid, &h, err, sizeof(err) ) < 0 ) return -1;
+  /* the harness keeps the state arrays at the boundary convention (anchors in model link frames) */
+  if( h.ncand > 0 ) rkfd_ref_to_device( &h, st->cv_ref, (size_t)st->batch*h.ncand );
   std::vector<char> lds( h.lds_bytes + 64 );
   int errflag = 0;
   for( int b=0; b<st->batch; b++ ){
@@ -76,6 +78,7 @@ extern "C" int rkfd_emu_run(const rkfdModel *m, int max_rigid, rkfdDevState *st,
       th.emplace_back( [&, l](){ t_lane = l; rkfd_instance<false, true>( h.dm, *st, b, lds.data(), mode, nsteps, &errflag ); } );
     for( auto &t : th ) t.join();
   }
+  if( h.ncand > 0 ) rkfd_ref_to_model( &h, st->cv_ref, (size_t)st->batch*h.ncand );
   rkfd_devmodel_free( &h );
   return errflag;
 }

@@ -29,6 +29,8 @@ def test_emulated_kernel_matches_oracle(R, oracle_cls, cfg, B, nsteps):
             oact, otyp, oref, of = o.get_contact()
             assert (act[i] == oact).all()
             assert np.abs(f[i] - of).max() / max(1.0, np.abs(of).max()) < 1e-9
+            # stick anchors: at the boundary they are in the model link's frame (floor_hardsoft's second link is merged on the device)
+            assert np.abs(ref[i] - oref * (oact[:, None] != 0)).max() < 1e-9
 
 
 def test_contact_capacity_overflow_is_reported(R):
@@ -90,3 +92,32 @@ def test_emulated_vert_rigid_qp_matches_oracle(R, oracle_cls):
             assert np.abs(x - y).max() / max(1.0, np.abs(y).max()) < 1e-9
         assert np.abs(f[i] - of * (oact[:, None] != 0)).max() / max(1.0, np.abs(of).max()) < 1e-8
     assert iters >= 4          # the run did go through multi-iteration (degenerate) QPs
+
+
+@pytest.mark.parametrize("solver,floor,who", [("mlcp", "floor.ztk", "box"), ("vert", "floor.ztk", "floor"), ("vert", "floor_hardsoft.ztk", "box"), ("mlcp", "floor.ztk", "both")])
+def test_emulated_slide_mode_matches_oracle(R, oracle_cls, solver, floor, who):
+    """cells in slide mode (fake crawler; rkFDLinkAddSlideVel, rkFDUpdateRefSlide, reference src/rkfd_util.c:26-40,218-237):
+    a box whose bottom runs like a belt, a floor that does, both; rigid (MLCP / Vert QP) and elastic contacts"""
+    import os
+    M = R.scenarios.MODELS
+    w = R.World(solver=R.SOLVER_MLCP if solver == "mlcp" else R.SOLVER_VERT); w.contact_info(os.path.join(M, "contactinfo.ztk"))
+    bx = w.reg_file(os.path.join(M, "box.ztk")); fl = w.reg_file(os.path.join(M, floor))
+    if who in ("box", "both"):
+        w.set_slide(bx, 0, True, 0.2, (0.0, 1.0, 0.0))
+    if who in ("floor", "both"):
+        w.set_slide(fl, 0, True, -0.1, (0.3, 1.0, 0.0))
+    dis = np.zeros((1, 6)); vel = np.zeros((1, 6)); dis[0, 2] = 0.0499; dis[0, 5] = 0.2
+    if floor == "floor_hardsoft.ztk":
+        dis[0, 1] = -1.0
+    eb = EmuBatch(w, 1, max_rigid=8); eb.set_state(dis, vel); eb.update_init(); eb.update(25)
+    assert eb.status() == 0
+    o = oracle_cls(w.model); o.set_state(dis[0], vel[0]); o.update_init(); o.update_n(25)
+    d, v, a = eb.get_state(); od, ov, oa = o.get_state(); act, typ, ref, f = eb.get_contact(); oact, otyp, oref, of = o.get_contact()
+    assert (act[0] == oact).all() and (typ[0] == otyp * (oact != 0)).all() and oact.sum() > 0
+    assert np.abs(d[0] - od).max() < 1e-9 and np.abs(v[0] - ov).max() < 1e-9
+    assert np.abs(ref[0] - oref * (oact[:, None] != 0)).max() < 1e-9
+    # and the belt does move the box: a world without slide mode ends elsewhere
+    w0 = R.World(solver=R.SOLVER_MLCP if solver == "mlcp" else R.SOLVER_VERT); w0.contact_info(os.path.join(M, "contactinfo.ztk"))
+    w0.reg_file(os.path.join(M, "box.ztk")); w0.reg_file(os.path.join(M, floor))
+    o0 = oracle_cls(w0.model); o0.set_state(dis[0], vel[0]); o0.update_init(); o0.update_n(25)
+    assert np.abs(o0.get_state()[0][:2] - od[:2]).max() > 1e-6

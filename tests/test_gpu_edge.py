@@ -370,3 +370,29 @@ def test_agreement_rate_on_random_box_drops(R, oracle_cls, plugin, need):
                                 and np.abs(v[i] - ov).max() < 1e-6 * max(1.0, np.abs(ov).max()))
     assert b.status() == 0
     assert alive.sum() >= need, int(alive.sum())
+
+
+@pytest.mark.parametrize("solver,floor,who", [("mlcp", "floor.ztk", "box"), ("vert", "floor.ztk", "floor"), ("vert", "floor_hardsoft.ztk", "box"), ("mlcp", "floor.ztk", "both")])
+def test_slide_mode(R, oracle_cls, solver, floor, who):
+    """cells in slide mode (fake crawler): belt on the box, on the floor, on both; MLCP, Vert QP and penalty
+    contacts; 60 steps vs the oracle incl. the drifting stick anchors"""
+    M = R.scenarios.MODELS
+    w = R.World(solver=R.SOLVER_MLCP if solver == "mlcp" else R.SOLVER_VERT); w.contact_info(os.path.join(M, "contactinfo.ztk"))
+    bx = w.reg_file(os.path.join(M, "box.ztk")); fl = w.reg_file(os.path.join(M, floor))
+    if who in ("box", "both"):
+        w.set_slide(bx, 0, True, 0.2, (0.0, 1.0, 0.0))
+    if who in ("floor", "both"):
+        w.set_slide(fl, 0, True, -0.1, (0.3, 1.0, 0.0))
+    B = 4
+    dis = np.zeros((B, 6)); vel = np.zeros((B, 6)); dis[:, 2] = 0.0499; dis[:, 5] = np.linspace(0.0, 0.6, B)
+    if floor == "floor_hardsoft.ztk":
+        dis[:, 1] = -1.0
+    b = R.Batch(w, B, max_rigid=8); b.set_state(dis, vel); b.update_init(); b.update(60)
+    assert b.status() == 0
+    d, v, a = b.get_state(); act, typ, ref, f = b.get_contact()
+    for i in range(B):
+        o = oracle_cls(w.model); o.set_state(dis[i], vel[i]); o.update_init(); o.update_n(60)
+        od, ov, oa = o.get_state(); oact, otyp, oref, of = o.get_contact(); on = oact != 0
+        assert (act[i] == oact).all() and (typ[i] == otyp * on).all()
+        assert _rel(d[i], od) < 1e-8 and _rel(v[i], ov) < 1e-8
+        assert np.abs(ref[i] - oref * on[:, None]).max() < 1e-8

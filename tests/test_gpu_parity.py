@@ -52,3 +52,6 @@ def test_step_parity(R, oracle_cls, cfg, B, nsteps):
             oact, otyp, oref, of = o.get_contact()
             assert (act[i] == oact).all()
             assert _relerr(f[i], of) < tol
+            on = oact != 0
+            assert (typ[i] == otyp * on).all()
+            assert np.abs(ref[i] - oref * on[:, None]).max() < 1e-9      # anchors, in the model link's frame
