@@ -66,6 +66,19 @@ int rkfdBatchUpdate(rkfdBatch *b, int nsteps, void *stream);
 /* one evaluation _rkFDUpdate (doUpRef=0) or _rkFDUpdateRef (doUpRef=1) at the current state
  * (reference src/rkfd_sim.c:533-549): fills acc and the contact forces.  Asynchronous. */
 int rkfdBatchEval(rkfdBatch *b, int doUpRef, void *stream);
+/* Split launches: the batch goes out as `nsplit` (1..8) kernels over contiguous parts on internal streams.  The
+ * instances are independent, so the parts need not wait for each other: the thinly occupied tail of one
+ * step of one part then overlaps the next step of another (+20 % at 4096 instances per GPU).  The parts start
+ * after whatever `stream` holds at the time of the call; `stream` itself does NOT wait for them until
+ * rkfdBatchJoin( b, stream ) or rkfdBatchStatus( b, stream ); the host-side accessors (Get / Set) wait.
+ * nsplit = 1 (default): one launch on the caller's stream, plain stream order. */
+int rkfdBatchSetSplit(rkfdBatch *b, int nsplit);
+int rkfdBatchJoin(rkfdBatch *b, void *stream);
+/* measurement aid: with on = 1 every launch is bracketed by HIP events on the stream it runs on;
+ * rkfdBatchLaunchTiming synchronises the device and returns their number and summed duration */
+int rkfdBatchTimeLaunches(rkfdBatch *b, int on);
+int rkfdBatchLaunchTiming(rkfdBatch *b, int *launches, double *total_ms);
+
 /* waits for the stream-ordered work, then reports device-side conditions:
  * 0 ok, 1 rigid contact met without a rigid solver set up (Volume plugin, or max_rigid = 0),
  * 2 rigid-contact capacity exceeded, 3 the Vert plugin's QP ran out of iterations (256) or of

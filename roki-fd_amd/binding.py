@@ -95,6 +95,8 @@ def lib():
     L.rkfdLdsBytesFor.argtypes = [C.POINTER(RkfdModel), C.c_int]
     L.rkfdBatchStatus.argtypes = [vp, vp]
     L.rkfdBatchProfile.argtypes = [vp, C.c_int, vp]
+    L.rkfdBatchSetSplit.argtypes = [vp, C.c_int]; L.rkfdBatchJoin.argtypes = [vp, vp]
+    L.rkfdBatchTimeLaunches.argtypes = [vp, C.c_int]; L.rkfdBatchLaunchTiming.argtypes = [vp, vp, vp]
     for f in ("rkfdBatchDevDis", "rkfdBatchDevVel", "rkfdBatchDevAcc"):
         getattr(L, f).argtypes = [vp]
         getattr(L, f).restype = vp
@@ -252,6 +254,23 @@ class Batch:
         if r < 0:
             raise RkfdError(self._L.rkfdHipLastError().decode())
         return r
+
+    def set_split(self, nsplit):
+        """rkfdBatchSetSplit: launch the batch as nsplit kernels on internal streams (tails overlap)"""
+        self._chk(self._L.rkfdBatchSetSplit(self._b, int(nsplit)))
+
+    def join(self, stream=None):
+        """rkfdBatchJoin: make `stream` wait for the split launches (no host synchronisation)"""
+        self._chk(self._L.rkfdBatchJoin(self._b, C.c_void_p(stream or 0)))
+
+    def time_launches(self, on=True):
+        self._chk(self._L.rkfdBatchTimeLaunches(self._b, int(bool(on))))
+
+    def launch_timing(self):
+        """(number of launches, their summed duration in ms) since time_launches(True); synchronises the device"""
+        n = C.c_int(); ms = C.c_double()
+        self._chk(self._L.rkfdBatchLaunchTiming(self._b, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
 
     def profile(self, nsteps=1):
         """diagnostic launch with in-kernel phase stamps: [B, 32] cycles (RKFD_NPROF)"""

@@ -20,10 +20,10 @@ static thread_local char g_err[512] = "";
  * 2560 slots still mean two rounds, the second one thinly filled.  So the budget stays at two. */
 #define RKFD_KERNEL(name, prof, vqp) \
 extern "C" __global__ void __launch_bounds__(RKFD_WAVE, 2) \
-name(rkfdDevModel m, rkfdDevState st, int mode, int nsteps, int *errflag) \
+name(rkfdDevModel m, rkfdDevState st, int first, int mode, int nsteps, int *errflag) \
 { \
   extern __shared__ __attribute__((aligned(16))) char lds[]; \
-  const int b = blockIdx.x; \
+  const int b = first + (int)blockIdx.x; \
   if( b >= st.batch ) return; \
   rkfd_instance<prof, vqp>( m, st, b, lds, mode, nsteps, errflag ); \
 }
@@ -35,7 +35,8 @@ RKFD_KERNEL( rkfd_step_kernel_vqp, false, true )
 RKFD_KERNEL( rkfd_step_kernel_prof, true, false )
 RKFD_KERNEL( rkfd_step_kernel_prof_vqp, true, true )
 
-typedef void (*rkfdKernel)(rkfdDevModel, rkfdDevState, int, int, int *);
+typedef void (*rkfdKernel)(rkfdDevModel, rkfdDevState, int, int, int, int *);
+#define RKFD_MAX_SPLIT 8
 
 struct rkfdBatch {
   int device, batch, nlink, ndof, ncand;
@@ -46,6 +47,16 @@ struct rkfdBatch {
   int *d_err;
   size_t lds_bytes;
   rkfdKernel kern, kern_prof;
+  /* split launches (rkfdBatchSetSplit): the batch goes out as nsplit kernels on internal streams, so that the
+   * tail of one step of one part overlaps the next step of another (the instances are independent) */
+  int nsplit;
+  hipStream_t sub[RKFD_MAX_SPLIT];
+  hipEvent_t fork, done[RKFD_MAX_SPLIT];
+  int pending;                       /* work on the internal streams that no stream has been joined with yet */
+  /* optional per-launch timing (rkfdBatchTimeLaunches) */
+  int timing;
+  std::vector<hipEvent_t> *tev;      /* pool of pre-created events; start / stop pairs occupy [0, tused) */
+  size_t tused;
 };
 
 extern "C" const char *rkfdHipLastError(void){ return g_err; }
@@ -78,6 +89,7 @@ extern "C" rkfdBatch *rkfdBatchCreate(const rkfdModel *m, int batch, int device,
   HIPCHK( hipSetDevice( device ), NULL );
 
   rkfdBatch *b = (rkfdBatch *)calloc( 1, sizeof(rkfdBatch) );
+  if( b ){ b->nsplit = 1; b->tev = new std::vector<hipEvent_t>(); }
   if( !b ){ SETERR( "out of memory" ); return NULL; }
   char err[256];
   if( rkfd_devmodel_build( m, max_rigid, &b->host, err, sizeof(err) ) < 0 ){
@@ -126,6 +138,11 @@ extern "C" void rkfdBatchDestroy(rkfdBatch *b)
   (void)hipFree( b->st.dis ); (void)hipFree( b->st.vel ); (void)hipFree( b->st.acc );
   (void)hipFree( b->st.motor_in ); (void)hipFree( b->st.piv_type ); (void)hipFree( b->st.piv_prev );
   (void)hipFree( b->st.cv_active ); (void)hipFree( b->st.cv_type ); (void)hipFree( b->st.cv_ref ); (void)hipFree( b->st.cv_f );
+  if( b->fork ){
+    (void)hipEventDestroy( b->fork );
+    for( int k=0; k<RKFD_MAX_SPLIT; k++ ){ (void)hipStreamSynchronize( b->sub[k] ); (void)hipStreamDestroy( b->sub[k] ); (void)hipEventDestroy( b->done[k] ); }
+  }
+  if( b->tev ){ for( size_t i=0; i<b->tev->size(); i++ ) (void)hipEventDestroy( (*b->tev)[i] ); delete b->tev; }
   (void)hipFree( b->d_err ); (void)hipFree( b->dblob );
   rkfd_devmodel_free( &b->host );
   free( b );
@@ -152,10 +169,13 @@ extern "C" double *rkfdBatchDevAcc(rkfdBatch *b){ return b ? b->st.acc : NULL; }
 #define H2D(dst, src, bytes) do{ if( src ) HIPCHK( hipMemcpy( dst, src, bytes, hipMemcpyHostToDevice ), -1 ); }while(0)
 #define D2H(dst, src, bytes) do{ if( dst ) HIPCHK( hipMemcpy( dst, src, bytes, hipMemcpyDeviceToHost ), -1 ); }while(0)
 
+static int sync_streams(rkfdBatch *b);      /* the synchronous accessors wait for split launches first */
+
 extern "C" int rkfdBatchSetState(rkfdBatch *b, const double *dis, const double *vel)
 {
   if( !b ){ SETERR( "null batch" ); return -1; }
   HIPCHK( hipSetDevice( b->device ), -1 );
+  if( sync_streams( b ) < 0 ) return -1;
   const size_t n = sizeof(double)*(size_t)b->batch*b->ndof;
   H2D( b->st.dis, dis, n ); H2D( b->st.vel, vel, n );
   return 0;
@@ -164,6 +184,7 @@ extern "C" int rkfdBatchGetState(rkfdBatch *b, double *dis, double *vel, double 
 {
   if( !b ){ SETERR( "null batch" ); return -1; }
   HIPCHK( hipSetDevice( b->device ), -1 );
+  if( sync_streams( b ) < 0 ) return -1;
   const size_t n = sizeof(double)*(size_t)b->batch*b->ndof;
   D2H( dis, b->st.dis, n ); D2H( vel, b->st.vel, n ); D2H( acc, b->st.acc, n );
   return 0;
@@ -172,6 +193,7 @@ extern "C" int rkfdBatchSetMotorInput(rkfdBatch *b, const double *input)
 {
   if( !b ){ SETERR( "null batch" ); return -1; }
   HIPCHK( hipSetDevice( b->device ), -1 );
+  if( sync_streams( b ) < 0 ) return -1;
   H2D( b->st.motor_in, input, sizeof(double)*(size_t)b->batch*b->nlink );
   return 0;
 }
@@ -179,6 +201,7 @@ extern "C" int rkfdBatchGetContact(rkfdBatch *b, int *active, int *type, double 
 {
   if( !b ){ SETERR( "null batch" ); return -1; }
   HIPCHK( hipSetDevice( b->device ), -1 );
+  if( sync_streams( b ) < 0 ) return -1;
   const size_t n = (size_t)b->batch*b->ncand;
   std::vector<int> act( n );
   HIPCHK( hipMemcpy( act.data(), b->st.cv_active, sizeof(int)*n, hipMemcpyDeviceToHost ), -1 );
@@ -200,6 +223,7 @@ extern "C" int rkfdBatchSetContact(rkfdBatch *b, const int *active, const int *t
 {
   if( !b ){ SETERR( "null batch" ); return -1; }
   HIPCHK( hipSetDevice( b->device ), -1 );
+  if( sync_streams( b ) < 0 ) return -1;
   const size_t n = (size_t)b->batch*b->ncand;
   H2D( b->st.cv_active, active, sizeof(int)*n ); H2D( b->st.cv_type, type, sizeof(int)*n );
   if( ref && n ){
@@ -213,6 +237,7 @@ extern "C" int rkfdBatchGetPivot(rkfdBatch *b, int *type, double *prev_trq)
 {
   if( !b ){ SETERR( "null batch" ); return -1; }
   HIPCHK( hipSetDevice( b->device ), -1 );
+  if( sync_streams( b ) < 0 ) return -1;
   const size_t n = (size_t)b->batch*b->nlink;
   D2H( type, b->st.piv_type, sizeof(int)*n ); D2H( prev_trq, b->st.piv_prev, sizeof(double)*n );
   return 0;
@@ -221,18 +246,113 @@ extern "C" int rkfdBatchSetPivot(rkfdBatch *b, const int *type, const double *pr
 {
   if( !b ){ SETERR( "null batch" ); return -1; }
   HIPCHK( hipSetDevice( b->device ), -1 );
+  if( sync_streams( b ) < 0 ) return -1;
   const size_t n = (size_t)b->batch*b->nlink;
   H2D( b->st.piv_type, type, sizeof(int)*n ); H2D( b->st.piv_prev, prev_trq, sizeof(double)*n );
   return 0;
 }
 
+/* next event of the timing pool (grown in blocks: creating events inside the launch path is expensive) */
+static hipEvent_t timing_event(rkfdBatch *b)
+{
+  if( b->tused == b->tev->size() ){
+    for( int i=0; i<1024; i++ ){
+      hipEvent_t e = NULL;
+      if( hipEventCreate( &e ) != hipSuccess ) return NULL;
+      b->tev->push_back( e );
+    }
+  }
+  return (*b->tev)[b->tused++];
+}
+/* make `stream` wait for everything the internal streams hold (no host synchronisation) */
+static int join_streams(rkfdBatch *b, hipStream_t stream)
+{
+  if( b->nsplit > 1 && b->pending ){
+    for( int k=0; k<b->nsplit; k++ ) HIPCHK( hipStreamWaitEvent( stream, b->done[k], 0 ), -1 );
+    b->pending = 0;
+  }
+  return 0;
+}
+/* host waits for the internal streams (used by the synchronous accessors) */
+static int sync_streams(rkfdBatch *b)
+{
+  if( b->nsplit > 1 ) for( int k=0; k<b->nsplit; k++ ) HIPCHK( hipStreamSynchronize( b->sub[k] ), -1 );
+  b->pending = 0;
+  return 0;
+}
 static int launch(rkfdBatch *b, int mode, int nsteps, void *stream)
 {
   if( !b ){ SETERR( "null batch" ); return -1; }
   HIPCHK( hipSetDevice( b->device ), -1 );
-  hipLaunchKernelGGL( b->st.prof ? b->kern_prof : b->kern, dim3( b->batch ), dim3( RKFD_WAVE ), b->lds_bytes, (hipStream_t)stream,
-                      b->dm, b->st, mode, nsteps, b->d_err );
-  HIPCHK( hipGetLastError(), -1 );
+  rkfdKernel kern = b->st.prof ? b->kern_prof : b->kern;
+  if( b->nsplit <= 1 || b->st.prof ){
+    if( b->st.prof && sync_streams( b ) < 0 ) return -1;
+    hipEvent_t e0 = NULL, e1 = NULL;
+    if( b->timing && !b->st.prof && ( e0 = timing_event( b ) ) && ( e1 = timing_event( b ) ) ) HIPCHK( hipEventRecord( e0, (hipStream_t)stream ), -1 );
+    hipLaunchKernelGGL( kern, dim3( b->batch ), dim3( RKFD_WAVE ), b->lds_bytes, (hipStream_t)stream,
+                        b->dm, b->st, 0, mode, nsteps, b->d_err );
+    HIPCHK( hipGetLastError(), -1 );
+    if( e0 && e1 ) HIPCHK( hipEventRecord( e1, (hipStream_t)stream ), -1 );
+    return 0;
+  }
+  /* fork: the parts start after what the caller's stream holds now; they do NOT wait for each other, and the
+   * caller's stream does not wait for them until rkfdBatchJoin / rkfdBatchStatus */
+  HIPCHK( hipEventRecord( b->fork, (hipStream_t)stream ), -1 );
+  for( int k=0; k<b->nsplit; k++ ){
+    const int lo = (int)( (long long)b->batch*k/b->nsplit ), hi = (int)( (long long)b->batch*( k+1 )/b->nsplit );
+    if( hi <= lo ) continue;
+    HIPCHK( hipStreamWaitEvent( b->sub[k], b->fork, 0 ), -1 );
+    hipEvent_t e0 = NULL, e1 = NULL;
+    if( b->timing && ( e0 = timing_event( b ) ) && ( e1 = timing_event( b ) ) ) HIPCHK( hipEventRecord( e0, b->sub[k] ), -1 );
+    hipLaunchKernelGGL( kern, dim3( hi-lo ), dim3( RKFD_WAVE ), b->lds_bytes, b->sub[k],
+                        b->dm, b->st, lo, mode, nsteps, b->d_err );
+    HIPCHK( hipGetLastError(), -1 );
+    if( e0 && e1 ) HIPCHK( hipEventRecord( e1, b->sub[k] ), -1 );
+    HIPCHK( hipEventRecord( b->done[k], b->sub[k] ), -1 );
+  }
+  b->pending = 1;
+  return 0;
+}
+extern "C" int rkfdBatchSetSplit(rkfdBatch *b, int nsplit)
+{
+  if( !b || nsplit < 1 || nsplit > RKFD_MAX_SPLIT ){ SETERR( "rkfdBatchSetSplit: 1 <= nsplit <= %d", RKFD_MAX_SPLIT ); return -1; }
+  HIPCHK( hipSetDevice( b->device ), -1 );
+  if( sync_streams( b ) < 0 ) return -1;
+  if( nsplit > 1 && !b->fork ){
+    HIPCHK( hipEventCreateWithFlags( &b->fork, hipEventDisableTiming ), -1 );
+    for( int k=0; k<RKFD_MAX_SPLIT; k++ ){
+      HIPCHK( hipStreamCreateWithFlags( &b->sub[k], hipStreamNonBlocking ), -1 );
+      HIPCHK( hipEventCreateWithFlags( &b->done[k], hipEventDisableTiming ), -1 );
+    }
+  }
+  b->nsplit = nsplit;
+  return 0;
+}
+extern "C" int rkfdBatchJoin(rkfdBatch *b, void *stream)
+{
+  if( !b ){ SETERR( "null batch" ); return -1; }
+  HIPCHK( hipSetDevice( b->device ), -1 );
+  return join_streams( b, (hipStream_t)stream );
+}
+extern "C" int rkfdBatchTimeLaunches(rkfdBatch *b, int on)
+{
+  if( !b ){ SETERR( "null batch" ); return -1; }
+  b->tused = 0;
+  b->timing = on ? 1 : 0;
+  if( on && b->tev->empty() ){ b->tused = 0; (void)timing_event( b ); b->tused = 0; }     /* pre-create the first block */
+  return 0;
+}
+extern "C" int rkfdBatchLaunchTiming(rkfdBatch *b, int *launches, double *total_ms)
+{
+  if( !b || !launches || !total_ms ){ SETERR( "rkfdBatchLaunchTiming: bad arguments" ); return -1; }
+  HIPCHK( hipSetDevice( b->device ), -1 );
+  HIPCHK( hipDeviceSynchronize(), -1 );
+  *launches = (int)( b->tused/2 ); *total_ms = 0;
+  for( size_t i=0; i+1<b->tused; i+=2 ){
+    float ms = 0;
+    HIPCHK( hipEventElapsedTime( &ms, (*b->tev)[i], (*b->tev)[i+1] ), -1 );
+    *total_ms += ms;
+  }
   return 0;
 }
 extern "C" int rkfdBatchUpdateInit(rkfdBatch *b, void *stream){ return launch( b, 1, 0, stream ); }
@@ -268,6 +388,7 @@ extern "C" int rkfdBatchStatus(rkfdBatch *b, void *stream)
 {
   if( !b ){ SETERR( "null batch" ); return -1; }
   HIPCHK( hipSetDevice( b->device ), -1 );
+  if( join_streams( b, (hipStream_t)stream ) < 0 ) return -1;
   HIPCHK( hipStreamSynchronize( (hipStream_t)stream ), -1 );
   int e = 0;
   HIPCHK( hipMemcpy( &e, b->d_err, sizeof(int), hipMemcpyDeviceToHost ), -1 );

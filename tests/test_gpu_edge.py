@@ -396,3 +396,22 @@ def test_slide_mode(R, oracle_cls, solver, floor, who):
         assert (act[i] == oact).all() and (typ[i] == otyp * on).all()
         assert _rel(d[i], od) < 1e-8 and _rel(v[i], ov) < 1e-8
         assert np.abs(ref[i] - oref * on[:, None]).max() < 1e-8
+
+
+def test_split_launches_give_the_same_results(R):
+    """rkfdBatchSetSplit: the batch launched as 1, 2, 3, 4, 8 kernels on internal streams - bit-identical states
+    (instances are independent), with and without intermediate joins; accessors and status wait for the parts"""
+    sc = R.scenarios.config4(batch=300)          # not a multiple of the split counts
+    out = []
+    for K in (1, 2, 3, 4, 8):
+        b = R.Batch(sc["world"], 300, max_rigid=sc["max_rigid"]); b.set_split(K)
+        b.set_state(sc["dis"], sc["vel"]); b.update_init()
+        for s in range(12):
+            b.update(1 if s % 3 else 2)
+            if s == 5:
+                b.join(); assert b.status() == 0
+        out.append(b.get_state() + b.get_contact() + b.get_pivot())
+        assert b.status() == 0
+    for o in out[1:]:
+        for x, y in zip(out[0], o):
+            assert np.array_equal(x, y)

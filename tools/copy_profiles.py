@@ -7,8 +7,9 @@ for w in ("config2", "config3", "config4"):
     shutil.copy(f"gpurun_out/prof_{tag}_{w}_summary.json", f"profiles/{tag}_{w}_rocprof_summary.json")
     ks = sorted(glob.glob(f"gpurun_out/prof_{tag}_{w}/trace/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)[-1]
     shutil.copy(ks, f"profiles/{tag}_{w}_kernel_stats.csv")
-    tr[w] = {"batch": 4096, "hbm_bytes_per_launch": s["hbm_bytes_per_launch"], "fetch_size_raw_kib": s["FETCH_SIZE"], "write_size_kib": s["WRITE_SIZE"],
-             "note": "FETCH_SIZE*1024*2 (gfx950 under-count of wide reads) + WRITE_SIZE*1024; separate --pmc passes; median over the launches of a 20-step run (traffic per launch does not depend on the step count)"}
+    dj = json.loads(open(f"gpurun_out/prof_{tag}_{w}.bench.json").read().strip().splitlines()[-1])
+    tr[w] = {"batch": dj["roofline"].get("instances_per_launch", 4096), "hbm_bytes_per_launch": s["hbm_bytes_per_launch"], "fetch_size_raw_kib": s["FETCH_SIZE"], "write_size_kib": s["WRITE_SIZE"],
+             "note": "FETCH_SIZE*1024*2 (gfx950 under-count of wide reads) + WRITE_SIZE*1024; separate --pmc passes; median over the launches of a 20-step run (traffic per launch does not depend on the step count); `batch` = instances per launch"}
     name = f"{tag}_bench_default.json" if w == "config4" else f"{tag}_bench_{w}.json"
     d = json.loads(open(f"gpurun_out/prof_{tag}_{w}.bench.json").read().strip().splitlines()[-1]); d["roofline"]["traffic"] = s["hbm_bytes_per_launch"]
     open("profiles/" + name, "w").write(json.dumps(d) + "\n")
