@@ -9,7 +9,8 @@ CSRC     = $(PKG)/csrc
 BUILD    = $(PKG)/build
 INC      = -Iinclude -I$(CSRC) -I$(CSRC)/host
 CFLAGS   = -O2 -Wall -fPIC $(INC)
-HIPFLAGS = --offload-arch=$(ARCH) -O3 -fPIC $(INC) -Wno-unused-value
+# machine LICM off: hoisted literals / addresses held across the step loop cost ~35 VGPRs and the third wave per SIMD
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -fPIC $(INC) -Wno-unused-value -mllvm -disable-machine-licm
 
 HOST_OBJS = $(BUILD)/rkfd_ztk.o $(BUILD)/rkfd_world.o $(BUILD)/rkfd_sim.o $(BUILD)/rkfd_devmodel.o
 LIB = $(PKG)/librkfd_amd.so

@@ -14,12 +14,12 @@ static thread_local char g_err[512] = "";
   SETERR( "%s failed: %s", #call, hipGetErrorString( e_ ) ); return ret; } }while(0)
 
 /* one workgroup = one wavefront = one world instance; state lives in LDS for the whole launch.
- * Register budget: 256 VGPRs = two waves per SIMD = eight instances per CU (the kernels use ~185).
- * A third wave per SIMD (168-VGPR build: 14 spilled registers, LDS allows 10 instances per CU for the
- * humanoid) was measured: +4 % at 16384 instances, -4 % at the 4096 of the headline metric, where
- * 2560 slots still mean two rounds, the second one thinly filled.  So the budget stays at two. */
+ * Register budget: the kernels need ~150-160 VGPRs when built with -mllvm -disable-machine-licm (see Makefile):
+ * three waves per SIMD, i.e. up to twelve instances per CU where the LDS allows (10 for the humanoid worlds).
+ * With machine LICM on, the backend hoists ~35 registers of literals (sincos polynomial coefficients, fp64
+ * constants) and addresses out of the step loop and the kernels need 184-193. */
 #define RKFD_KERNEL(name, prof, vqp) \
-extern "C" __global__ void __launch_bounds__(RKFD_WAVE, 2) \
+extern "C" __global__ void __launch_bounds__(RKFD_WAVE, 3) \
 name(rkfdDevModel m, rkfdDevState st, int first, int mode, int nsteps, int *errflag) \
 { \
   extern __shared__ __attribute__((aligned(16))) char lds[]; \
