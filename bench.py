@@ -203,6 +203,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload, per_launch),
                          "kernel": "rkfd_step_kernel", "kernel_ms": kernel_ms, "alg_bytes_per_instance_step": alg,
                          "instances_per_launch": per_launch, "launches_per_step": args.split, "step_ms_hip_events": step_ms,
+                         "lds_bytes_per_instance": b.lds_bytes, "resident_instances_per_cu": b.residency(),
                          "achieved_all_launches_of_a_step": alg * Bn / (step_ms * 1e-3) / 1e9},
             "device_status": st,
         }

@@ -100,6 +100,9 @@ double *rkfdBatchDevAcc(rkfdBatch *b);
 
 /* kernel resource facts for measurement: LDS bytes per instance */
 int rkfdBatchLdsBytes(const rkfdBatch *b);
+/* instances that can be resident on one compute unit at a time (registers and LDS of the step kernel), as the HIP
+ * runtime reports it; -1 on error */
+int rkfdBatchResidency(const rkfdBatch *b);
 /* the same figure computed on the host for a model and contact capacity (no GPU needed) */
 int rkfdLdsBytesFor(const rkfdModel *m, int max_rigid);
 

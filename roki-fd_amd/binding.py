@@ -80,7 +80,7 @@ def lib():
     L.rkfdBatchCreate.argtypes = [C.POINTER(RkfdModel), C.c_int, C.c_int, C.c_int]
     L.rkfdBatchCreate.restype = vp
     L.rkfdBatchDestroy.argtypes = [vp]
-    for f in ("rkfdBatchSize", "rkfdBatchDof", "rkfdBatchLdsBytes"):
+    for f in ("rkfdBatchSize", "rkfdBatchDof", "rkfdBatchLdsBytes", "rkfdBatchResidency"):
         getattr(L, f).argtypes = [vp]
     L.rkfdBatchSetState.argtypes = [vp, vp, vp]
     L.rkfdBatchGetState.argtypes = [vp, vp, vp, vp]
@@ -281,6 +281,10 @@ class Batch:
     @property
     def lds_bytes(self):
         return self._L.rkfdBatchLdsBytes(self._b)
+
+    def residency(self):
+        """instances per compute unit the HIP runtime can keep resident (registers + LDS)"""
+        return self._L.rkfdBatchResidency(self._b)
 
     def dev_tensors(self):
         """torch tensors ALIASING the live device state [B, ndof] (dis, vel, acc): zero-copy views

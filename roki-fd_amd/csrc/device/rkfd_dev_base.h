@@ -305,20 +305,20 @@ typedef struct {
                                      unless it overlays the link accelerations), [3M] reduced rows */
   int *CRC;                       /* [M] contact of a reduced constraint row */
   double *MA, *MB, *MF, *PU;      /* MLCP: [M*(M+1)] (ALIASES IST|POOL), [M], [M], [nside*npurow*M] (ALIASES C|PA when it fits) */
-  int *act, *typ, *lrg, *lel, *tgt, *cnt;
-  int *asl;                       /* [NC] active-contact slot of a candidate              */
+  int *lrg, *lel, *tgt, *cnt;
+  unsigned char *act, *typ;       /* [NC] in contact, stick / slip type                   */
+  unsigned char *asl;             /* [NC] active-contact slot of a candidate              */
   int *LI;                        /* [NL] packed link info (RKFD_LI_*)                    */
   int *CIp, *CFO;                 /* [NC] packed candidate info, first plane              */
-  int *CHI;                       /* [NL] children lists (CSR values; offsets in the schedule)     */
-  int *PSL;                       /* [NL] pool slot of a link (-1 none)                   */
+  unsigned short *CHP;            /* [NL] children lists (CSR values; offsets in the schedule): child | ( its pool slot + 1 ) << 8 */
   unsigned char *PL;              /* [NL*nlevel] ancestor at depth d (MLCP only), one byte each */
 } rkfdLds;
 
-RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int M, int nlevel, int npool, int nfloat, int maxact, int nside, int pu_alias, int npurow, int vert_rigid, int has_slide)
+RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int M, int nlevel, int npool, int nfloat, int maxact, int nside, int pu_alias, int npurow, int vert_rigid, int has_slide, int ma_size)
 /* must match the byte count computed in rkfd_devmodel.cpp */
 {
   double *d = (double *)base;
-  L->q = d; d += ND; L->qd = d; d += ND; L->acc = d; d += ND;
+  L->q = d; d += ND; L->qd = d; d += ND;
   L->S = d; d += NL*6;
   L->V = d; L->U = d; L->tmp = d; d += NL*6;
   L->PB = d; L->AC = d; d += NL*6;
@@ -329,7 +329,12 @@ RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int
     const int pool = 36*npool > 6*NL ? 36*npool : 6*NL;
     int stage = 14*NL + pool;
     L->IST = d; L->POOL = d + 14*NL; L->XB = d + 14*NL; L->MA = d;
-    if( M*(M+1) > stage ) stage = M*(M+1);
+    /* the joint accelerations leave sweep 3 through the head of the (by then dead) inertia staging; the contact
+     * matrix overwrites them, so rkfd_evaluate carries them in a lane register across the contact phase */
+    L->acc = d;
+    /* the contact matrix: rows padded to an odd stride while there is room, i.e. unless every slot is taken (the Vert
+     * QP keeps the padded layout throughout) */
+    if( ma_size > stage ) stage = ma_size;
     d += stage;
   }
   L->CHOL = d; d += 36*nfloat; L->XF = d; d += 12*nfloat;
@@ -337,17 +342,22 @@ RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int
   L->REF = d; d += maxact*3; L->RTMP = d; if( NC > RKFD_WAVE ) d += maxact*3;
   L->CF = d; d += maxact*3;
   L->SV = d; L->SD = d; if( has_slide ){ L->SV = d; d += maxact*3; L->SD = d; d += maxact*3; }
-  L->MB = d; d += M; L->MF = d; d += M;
+  /* PGS: a lane reads its three entries of b before it writes its three forces, so they share storage */
+  L->MB = d; d += M; L->MF = L->MB; if( vert_rigid ){ L->MF = d; d += M; }
   /* probe scratch: lives while the contact problem is set up and solved, when C and PA are dead */
   if( pu_alias ) L->PU = L->C; else { L->PU = d; d += nside*npurow*M; }
   L->QL = d; L->QW = d; L->QV = d; L->CR = d;
   if( vert_rigid ){ L->QL = d; d += M*M; L->QW = d; d += M*M; L->QV = d; d += 5*M + ( vert_rigid == 2 ? 0 : RKFD_WAVE ); L->CR = d; d += 3*M; }
   int *ip = (int *)d;
-  L->act = ip; ip += NC; L->typ = ip; ip += NC; L->asl = ip; ip += NC; L->CIp = ip; ip += NC; L->CFO = ip; ip += NC;
-  L->lrg = ip; ip += maxact; L->lel = ip; ip += maxact; L->tgt = ip; ip += 2*maxact; L->cnt = ip; ip += 8;
-  L->LI = ip; ip += NL; L->CHI = ip; ip += NL; L->PSL = ip; ip += NL;
+  L->CIp = ip; ip += NC; L->CFO = ip; ip += NC;
+  L->lrg = ip; ip += maxact; L->lel = ip; ip += maxact; L->tgt = ip; ip += 2*maxact; L->cnt = ip; ip += NC > 0 ? 8 : 4;
+  L->LI = ip; ip += NL;
   L->CRC = ip; if( vert_rigid ) ip += M;
-  L->PL = (unsigned char *)ip;
+  unsigned short *sp = (unsigned short *)ip;
+  L->CHP = sp; sp += NL;
+  unsigned char *bp = (unsigned char *)sp;
+  L->act = bp; bp += NC; L->typ = bp; bp += NC; L->asl = bp; bp += NC;
+  L->PL = bp;
 }
 
 /* per-lane state that only lane = link ever touches: kept in registers for the whole launch */
@@ -368,8 +378,8 @@ typedef struct { double min, pivp; int pivt; } rkfdLaneLink;
 /* counters in L->cnt */
 #define CNT_NRG 0
 #define CNT_NEL 1
-#define CNT_NTGT 2
-#define CNT_OVF 3
-#define CNT_QPF 4
+#define CNT_OVF 2
+#define CNT_QPF 3
+#define CNT_NTGT 4      /* (worlds with contact candidates only: four counters otherwise) */
 
 #endif /* RKFD_DEV_BASE_H */

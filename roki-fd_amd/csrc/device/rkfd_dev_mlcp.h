@@ -81,7 +81,7 @@ template<bool prof, bool vqp> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &
   const int lane = LANE();
   const int nc = L.cnt[CNT_NRG];
   const int M = 3*nc;
-  const int ld = M+1;
+  const int ld = ( m.vert_rigid || nc < m.maxrg ) ? M+1 : M;   /* odd row stride unless every slot is taken (see rkfd_lds_carve) */
   const int NLV = m.nlevel, NL = m.nlink, NR = m.npurow;
   const int NSD = m.nside;
   const int PUS = NR*M;                               /* stride between the two sides of PU */

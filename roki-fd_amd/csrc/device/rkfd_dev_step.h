@@ -15,7 +15,6 @@ template<bool prof, bool vqp> RKFD_DEV int rkfd_evaluate(const rkfdDevModel &m, 
   unsigned long long t0 = 0, t1;
 #define STAMP(k) do{ if( prof ){ t1 = RKFD_CLOCK(); pc[k] += t1 - t0; t0 = t1; } }while(0)
   if( prof ) t0 = RKFD_CLOCK();
-  if( lane < m.ndof ) L.acc[lane] = 0.0;
   rkfd_phase_kinematics<prof>( m, L, ll, pc );
   STAMP(0);
   /* commit joint friction pivots (the reference does so inside rkFDJointFrictionRevolDC) */
@@ -45,10 +44,16 @@ template<bool prof, bool vqp> RKFD_DEV int rkfd_evaluate(const rkfdDevModel &m, 
   STAMP(3);
   if( L.cnt[CNT_NRG] > 0 ){
     if( m.solver == RKFD_SOLVER_MLCP || ( vqp && m.solver == RKFD_SOLVER_VERT && m.vert_rigid ) ){
+      /* L.acc shares its LDS with the contact matrix: the free accelerations wait in a register (lane = dof) */
+      SYNC();
+      const double afree = lane < m.ndof ? L.acc[lane] : 0.0;
       /* contact forces, then their effect on the accelerations (rkChainUpdateCachedABI in the reference) */
       rkfd_phase_mlcp<prof, vqp>( m, L, bv, doUpRef, pc );
       STAMP(4);
       rkfd_phase_sweep3<true>( m, L );
+      SYNC();
+      if( lane < m.ndof ) L.acc[lane] += afree;
+      SYNC();
       STAMP(3);
     } else {
       err = 1;
@@ -101,7 +106,7 @@ template<bool prof, bool vqp> RKFD_DEV void rkfd_instance(const rkfdDevModel &m,
   const int lane = LANE();
   const int ND = m.ndof, NL = m.nlink, NC = m.ncand;
   rkfdLds L;
-  rkfd_lds_carve( &L, ldsbase, NL, ND, NC, 3*m.maxrg, m.nlevel, m.npool, m.nfloat, m.maxact, m.nside, m.pu_alias, m.npurow, m.vert_rigid, m.has_slide );
+  rkfd_lds_carve( &L, ldsbase, NL, ND, NC, 3*m.maxrg, m.nlevel, m.npool, m.nfloat, m.maxact, m.nside, m.pu_alias, m.npurow, m.vert_rigid, m.has_slide, m.ma_size );
   if( lane == 0 ){ L.cnt[CNT_OVF] = 0; L.cnt[CNT_QPF] = 0; }
 
   /* load persistent state */
@@ -111,8 +116,7 @@ template<bool prof, bool vqp> RKFD_DEV void rkfd_instance(const rkfdDevModel &m,
   rkfdLaneLink ll; ll.min = 0; ll.pivp = 0; ll.pivt = 0;
   if( lane < NL ){
     L.LI[lane]   = m.linfo[lane];
-    L.CHI[lane]  = m.child_idx[lane];
-    L.PSL[lane]  = m.pslot[lane];
+    { const int ch = m.child_idx[lane]; L.CHP[lane] = (unsigned short)( ch | ( ( m.pslot[ch]+1 ) << 8 ) ); }
     const int lm = m.orig[lane];
     ll.min  = st.motor_in[(size_t)b*m.nlink_model+lm];
     ll.pivt = st.piv_type[(size_t)b*m.nlink_model+lm];
@@ -137,7 +141,7 @@ template<bool prof, bool vqp> RKFD_DEV void rkfd_instance(const rkfdDevModel &m,
     base += __builtin_popcountll( ma );
     if( a && sl >= m.maxact ) a = 0;
     if( onj ){
-      L.act[j] = a;
+      L.act[j] = a != 0;
       L.asl[j] = a ? sl : 0;
       if( a ){
 #pragma unroll

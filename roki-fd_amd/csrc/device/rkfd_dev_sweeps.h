@@ -148,9 +148,9 @@ template<bool prof> RKFD_DEV void rkfd_phase_sweep2(const rkfdDevModel &m, const
       for( int k=0; k<6; k++ ) row[k] += crow[k];
     } else {
       for( int cc=0; cc<REC_NCHILD( rec ); cc++ ){
-        const int ch = L.CHI[rec.coff+cc];
+        const int chp = L.CHP[rec.coff+cc], ch = chp & 0xFF;
         pr += L.PA[6*ch+rr];
-        const int ps = L.PSL[ch];
+        const int ps = ( chp >> 8 ) - 1;
         if( ps >= 0 ){
 #pragma unroll
           for( int k=0; k<6; k++ ) row[k] += L.POOL[36*ps+6*rr+k];
@@ -265,7 +265,7 @@ template<bool delta> RKFD_DEV void rkfd_phase_sweep3(const rkfdDevModel &m, cons
       const double qdd = delta ? fma( -uy, pre.Dinv, pre.u ) : ( pre.u - uy )*pre.Dinv;
       a = fma( pre.S_r, qdd, y );
       if( on && rr == 0 ){
-        if( delta ) L.acc[off] += qdd; else L.acc[off] = qdd;
+        L.acc[off] = qdd;     /* delta: the change of the joint acceleration; rkfd_evaluate adds the free one */
       }
     } else if( jt == RKFD_JOINT_FLOAT ){
       if( onl && r == 0 ){
@@ -295,13 +295,8 @@ template<bool delta> RKFD_DEV void rkfd_phase_sweep3(const rkfdDevModel &m, cons
         d_cross( p, d, t3 );
         lin[0] = d[3]-t3[0]; lin[1] = d[4]-t3[1]; lin[2] = d[5]-t3[2];
         d_tmulv( Row, lin, o1 ); d_tmulv( Row, d, o2 );
-        if( delta ){
-          L.acc[off] += o1[0]; L.acc[off+1] += o1[1]; L.acc[off+2] += o1[2];
-          L.acc[off+3] += o2[0]; L.acc[off+4] += o2[1]; L.acc[off+5] += o2[2];
-        } else {
-          L.acc[off] = o1[0]; L.acc[off+1] = o1[1]; L.acc[off+2] = o1[2];
-          L.acc[off+3] = o2[0]; L.acc[off+4] = o2[1]; L.acc[off+5] = o2[2];
-        }
+        L.acc[off] = o1[0]; L.acc[off+1] = o1[1]; L.acc[off+2] = o1[2];
+        L.acc[off+3] = o2[0]; L.acc[off+4] = o2[1]; L.acc[off+5] = o2[2];
       }
     }
     LDS_FENCE();

@@ -99,6 +99,8 @@ extern "C" rkfdBatch *rkfdBatchCreate(const rkfdModel *m, int batch, int device,
   }
   b->device = device; b->batch = batch; b->nlink = m->nlink; b->ndof = m->ndof; b->ncand = m->ncand;
   b->lds_bytes = b->host.lds_bytes;
+  /* diagnostic (tools/sweep_residency.sh): ask for more LDS than needed, to measure throughput against residency */
+  if( const char *pad = getenv( "RKFD_LDS_PAD_BYTES" ) ) b->lds_bytes += (size_t)( atoi( pad ) > 0 ? atoi( pad ) : 0 );
   if( b->lds_bytes > 160*1024 ){
     SETERR( "rkfdBatchCreate: one instance needs %zu bytes of LDS (> 160 KiB)", b->lds_bytes );
     rkfd_devmodel_free( &b->host ); free( b );
@@ -162,6 +164,13 @@ extern "C" int rkfdLdsBytesFor(const rkfdModel *m, int max_rigid)
 extern "C" int rkfdBatchSize(const rkfdBatch *b){ return b ? b->batch : -1; }
 extern "C" int rkfdBatchDof(const rkfdBatch *b){ return b ? b->ndof : -1; }
 extern "C" int rkfdBatchLdsBytes(const rkfdBatch *b){ return b ? (int)b->lds_bytes : -1; }
+extern "C" int rkfdBatchResidency(const rkfdBatch *b)
+{
+  int n = 0;
+  if( !b ) return -1;
+  if( hipOccupancyMaxActiveBlocksPerMultiprocessor( &n, (const void *)b->kern, RKFD_WAVE, b->lds_bytes ) != hipSuccess ) return -1;
+  return n;
+}
 extern "C" double *rkfdBatchDevDis(rkfdBatch *b){ return b ? b->st.dis : NULL; }
 extern "C" double *rkfdBatchDevVel(rkfdBatch *b){ return b ? b->st.vel : NULL; }
 extern "C" double *rkfdBatchDevAcc(rkfdBatch *b){ return b ? b->st.acc : NULL; }

@@ -339,6 +339,7 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   dm.vert_rigid = ( m->solver == RKFD_SOLVER_VERT && has_rigid && max_rigid > 0 ) ? 1 : 0;
   dm.qscr_alias = ( dm.vert_rigid && 6*NL >= RKFD_WAVE ) ? 1 : 0;
   if( dm.qscr_alias ) dm.vert_rigid = 2;
+  dm.ma_size = dm.vert_rigid ? 3*max_rigid*( 3*max_rigid+1 ) : 9*max_rigid*max_rigid;
   if( dm.vert_rigid && (size_t)dm.pyramid*max_rigid > RKFD_WAVE )
     FAIL( "Vert plugin: pyramid faces x rigid contact capacity exceeds 64 (one constraint per lane)" );
   int maxact = has_elastic ? ( NC < 16 ? NC : 16 ) : 0;
@@ -410,14 +411,18 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
     const size_t M = 3*(size_t)max_rigid;
     const size_t pool = (size_t)36*npool > (size_t)6*NL ? (size_t)36*npool : (size_t)6*NL;   /* Ia pool | second half of the world frames */
     size_t stage = (size_t)14*NL + pool;                         /* inertia staging + Ia pool ...   */
-    if( M*(M+1) > stage ) stage = M*(M+1);                       /* ... shared with the MLCP matrix */
-    const size_t dbl = (size_t)3*ND + (size_t)NL*( 5*6 + 4 ) + stage + (size_t)48*nfloat
-                     + (size_t)maxact*( 24 + ( NC > RKFD_WAVE ? 3 : 0 ) + ( dm.has_slide ? 6 : 0 ) ) + 2*M + ( dm.pu_alias ? 0 : (size_t)nside*npurow*M )
+    if( (size_t)dm.ma_size > stage ) stage = (size_t)dm.ma_size;   /* ... shared with the contact matrix */
+    const size_t dbl = (size_t)2*ND + (size_t)NL*( 5*6 + 4 ) + stage + (size_t)48*nfloat
+                     + (size_t)maxact*( 24 + ( NC > RKFD_WAVE ? 3 : 0 ) + ( dm.has_slide ? 6 : 0 ) ) + ( dm.vert_rigid ? 2 : 1 )*M + ( dm.pu_alias ? 0 : (size_t)nside*npurow*M )
                      + ( dm.vert_rigid ? 2*M*M + 5*M + ( dm.qscr_alias ? 0 : RKFD_WAVE ) + 3*M : 0 );   /* Vert QP: QL, QW, QV, CR */
-    const size_t ints = (size_t)5*NC + (size_t)4*maxact + 8 + 3*(size_t)NL + ( dm.vert_rigid ? M : 0 )     /* act typ asl CIp CFO, lrg lel tgt, cnt, LI CHI PSL */
-                      + ( max_rigid > 0 ? ( (size_t)NL*( nlevel+3 ) + 3 )/4 : 0 );   /* PL (bytes) */
-    out->lds_bytes = dbl*sizeof(double) + ints*sizeof(int);
+    const size_t ints = (size_t)2*NC + (size_t)4*maxact + ( NC > 0 ? 8 : 4 ) + (size_t)NL + ( dm.vert_rigid ? M : 0 );     /* CIp CFO, lrg lel tgt, cnt, LI, CRC */
+    const size_t bytes = (size_t)2*NL + (size_t)3*NC                                     /* CHP (16 bit), act typ asl (bytes) */
+                       + ( max_rigid > 0 ? (size_t)NL*( nlevel+3 ) : 0 );                /* PL */
+    out->lds_bytes = dbl*sizeof(double) + ints*sizeof(int) + bytes;
     out->lds_bytes = ( out->lds_bytes + 15 ) & ~(size_t)15;
+    if( getenv( "RKFD_DEVMODEL_DUMP" ) )
+      fprintf( stderr, "rkfd devmodel: NL %d ND %d NC %d nlevel %d npool %d nfloat %d maxact %d nside %d npurow %d pu_alias %d M %d stage %zu (staging %zu) vert %d -> %zu B of LDS\n",
+               NL, ND, NC, nlevel, npool, nfloat, maxact, nside, npurow, dm.pu_alias, (int)M, stage, (size_t)14*NL + pool, dm.vert_rigid, out->lds_bytes );
   }
   return 0;
 #undef FAIL

@@ -1,0 +1,41 @@
+"""The step kernels' register and scratch budget, from the compiler's own report of the build that
+ships (roki-fd_amd/kernel_resources.txt, written by the Makefile from -Rpass-analysis=kernel-resource-usage).
+Residency is what the throughput hangs on: a change that pushes a kernel over 168 VGPRs costs
+the third wave per SIMD, and one that makes it spill adds megabytes of scratch traffic per launch -
+both have happened silently (a two-line change in the LDS carve-up moved the kernels from 150 to 182)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPORT = os.path.join(ROOT, "roki-fd_amd", "kernel_resources.txt")
+
+
+def _kernels():
+    if not os.path.exists(REPORT):
+        import subprocess
+        subprocess.run(["make", "-C", ROOT], check=True, stdout=subprocess.DEVNULL)
+    out, cur = {}, None
+    for line in open(REPORT):
+        m = re.match(r"Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.match(r"\s*(VGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]): (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).split(" ")[0]] = int(m.group(2))
+    return out
+
+
+def test_every_kernel_variant_is_reported():
+    k = _kernels()
+    assert set(k) == {"rkfd_step_kernel", "rkfd_step_kernel_vqp", "rkfd_step_kernel_prof", "rkfd_step_kernel_prof_vqp"}
+
+
+@pytest.mark.parametrize("name", ["rkfd_step_kernel", "rkfd_step_kernel_vqp", "rkfd_step_kernel_prof", "rkfd_step_kernel_prof_vqp"])
+def test_kernel_fits_three_waves_per_simd_without_scratch(name):
+    k = _kernels()[name]
+    assert k["ScratchSize"] == 0, k
+    assert k["VGPRs"] <= 168, k
+    assert k["Occupancy"] >= 3, k

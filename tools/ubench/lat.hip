@@ -79,9 +79,28 @@ __global__ void k_gload(double *out, long long *cyc, const int *tab){
   long long t1 = __builtin_amdgcn_s_memtime();
   out[threadIdx.x] = p; if( threadIdx.x == 0 ) cyc[blockIdx.x] = t1 - t0;
 }
+
+// frequency of the s_memtime counter: spin for a fixed number of ticks, time the launch with HIP events
+__global__ void k_spin(long long *cyc, long long ticks){
+  long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime(), t1;
+  do { t1 = __builtin_amdgcn_s_memtime(); } while( t1 - t0 < ticks );
+  long long r1 = __builtin_amdgcn_s_memrealtime();
+  if( threadIdx.x == 0 ){ cyc[0] = t1 - t0; cyc[1] = r1 - r0; }
+}
+// dependent fp64 FMA chain, long enough to time with HIP events: wall time per instruction
+__global__ void k_fma_long(double *out, long long *cyc, double a, double b, int n){
+  double x = out[threadIdx.x];
+  long long t0 = __builtin_amdgcn_s_memtime();
+  for( int j=0; j<n; j++ ){
+#pragma unroll 16
+    for( int i=0; i<N; i++ ) x = fma( x, a, b );
+  }
+  long long t1 = __builtin_amdgcn_s_memtime();
+  out[threadIdx.x] = x; if( threadIdx.x == 0 ) cyc[blockIdx.x] = t1 - t0;
+}
 int main(){
   double *out; long long *cyc; int *tab;
-  hipMalloc( &out, 64*8 ); hipMemset( out, 0, 64*8 ); hipMalloc( &cyc, 8*1024 ); hipMalloc( &tab, 4096*4 );
+  hipMalloc( &out, 64*8 ); hipMemset( out, 0, 64*8 ); hipMalloc( &cyc, 8*4096 ); hipMalloc( &tab, 4096*4 );
   int h[4096]; for( int i=0; i<4096; i++ ) h[i] = ( i*33 + 7 ) & 4095;
   hipMemcpy( tab, h, sizeof(h), hipMemcpyHostToDevice );
   long long c;
@@ -100,5 +119,21 @@ int main(){
   hipEventRecord( e0 ); for( int r=0; r<50; r++ ) hipLaunchKernelGGL( k_fma, dim3(1), dim3(64), 0, 0, out, cyc, 0.999, 0.001 ); hipEventRecord( e1 ); hipEventSynchronize( e1 );
   float ms; hipEventElapsedTime( &ms, e0, e1 ); hipMemcpy( &c, cyc, 8, hipMemcpyDeviceToHost );
   printf( "k_fma: %lld ticks per launch, %.3f ms per launch (incl. launch gaps)\n", c, ms/50 );
+  {
+    long long tk[2]; float msx;
+    hipEventRecord( e0 ); hipLaunchKernelGGL( k_spin, dim3(1), dim3(64), 0, 0, cyc, 1ll<<28 ); hipEventRecord( e1 ); hipEventSynchronize( e1 );
+    hipEventElapsedTime( &msx, e0, e1 ); hipMemcpy( tk, cyc, 16, hipMemcpyDeviceToHost );
+    printf( "k_spin: %lld s_memtime ticks, %lld s_memrealtime ticks in %.3f ms -> s_memtime %.1f MHz, s_memrealtime %.1f MHz\n", tk[0], tk[1], msx, tk[0]/(msx*1e3), tk[1]/(msx*1e3) );
+    hipEventRecord( e0 ); hipLaunchKernelGGL( k_fma_long, dim3(1), dim3(64), 0, 0, out, cyc, 0.999, 0.001, 2048 ); hipEventRecord( e1 ); hipEventSynchronize( e1 );
+    hipEventElapsedTime( &msx, e0, e1 ); hipMemcpy( tk, cyc, 8, hipMemcpyDeviceToHost );
+    printf( "k_fma_long (1 wave): %.3f ns and %.2f ticks per dependent v_fma_f64\n", msx*1e6/( 2048.0*N ), (double)tk[0]/( 2048.0*N ) );
+    /* the same with every SIMD busy: 4 waves per CU on all CUs */
+    hipEventRecord( e0 ); hipLaunchKernelGGL( k_fma_long, dim3(1024), dim3(64), 0, 0, out, cyc, 0.999, 0.001, 2048 ); hipEventRecord( e1 ); hipEventSynchronize( e1 );
+    hipEventElapsedTime( &msx, e0, e1 ); hipMemcpy( tk, cyc, 8, hipMemcpyDeviceToHost );
+    printf( "k_fma_long (1024 waves): %.3f ns and %.2f ticks per dependent v_fma_f64\n", msx*1e6/( 2048.0*N ), (double)tk[0]/( 2048.0*N ) );
+    hipEventRecord( e0 ); hipLaunchKernelGGL( k_fma_long, dim3(2048), dim3(64), 0, 0, out, cyc, 0.999, 0.001, 2048 ); hipEventRecord( e1 ); hipEventSynchronize( e1 );
+    hipEventElapsedTime( &msx, e0, e1 ); hipMemcpy( tk, cyc, 8, hipMemcpyDeviceToHost );
+    printf( "k_fma_long (2048 waves, 2 per SIMD): %.3f ns per v_fma_f64 per wave -> %.3f ns per SIMD instruction\n", msx*1e6/( 2048.0*N ), msx*1e6/( 2048.0*N )/2 );
+  }
   return 0;
 }
