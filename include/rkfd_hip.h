@@ -100,8 +100,8 @@ double *rkfdBatchDevAcc(rkfdBatch *b);
 
 /* kernel resource facts for measurement: LDS bytes per instance */
 int rkfdBatchLdsBytes(const rkfdBatch *b);
-/* instances that can be resident on one compute unit at a time (registers and LDS of the step kernel), as the HIP
- * runtime reports it; -1 on error */
+/* instances that can be resident on one compute unit at a time: the HIP runtime's occupancy answer for the step
+ * kernel (registers, LDS), corrected for the 1280-byte pieces in which the hardware allocates LDS; -1 on error */
 int rkfdBatchResidency(const rkfdBatch *b);
 /* the same figure computed on the host for a model and contact capacity (no GPU needed) */
 int rkfdLdsBytesFor(const rkfdModel *m, int max_rigid);

@@ -169,6 +169,10 @@ extern "C" int rkfdBatchResidency(const rkfdBatch *b)
   int n = 0;
   if( !b ) return -1;
   if( hipOccupancyMaxActiveBlocksPerMultiprocessor( &n, (const void *)b->kern, RKFD_WAVE, b->lds_bytes ) != hipSuccess ) return -1;
+  /* the runtime's answer is optimistic about LDS: the hardware hands it out in 1280-byte pieces, 128 per CU
+   * (measured with tools/ubench/residency.hip, profiles/r01_lds_residency.txt), e.g. 16160 bytes -> 9, not 10 */
+  const int pieces = (int)( ( b->lds_bytes + 1279 )/1280 );
+  if( pieces > 0 && 128/pieces < n ) n = 128/pieces;
   return n;
 }
 extern "C" double *rkfdBatchDevDis(rkfdBatch *b){ return b ? b->st.dis : NULL; }
