@@ -288,7 +288,7 @@ typedef struct {
   double *PA;                     /* [NL*6]  bias force handed to the parent (sweep 2)                      */
   double *XA, *XB;                /* [NL*6] each: world frames, R rows 0-1 | R row 2, p.  Valid from the kinematics
                                      phase to the end of the collision phase: XA ALIASES PA, XB the Ia pool */
-  double *MS;                     /* [NL*4]  Dinv, u, tau, jm                             */
+  double *MS;                     /* [NL*3]  Dinv, u, tau (slots re-used, see the phases)   */
   double *IST;                    /* [NL*14] inertia staging: A = Iw + m(|r|^2 1 - r r') (xx,xy,xz,yy,yz,zz),
                                      +m r (3), -m r (3), m, 0: every entry of the 6x6 is one of these */
   double *POOL;                   /* [npool*36] Ia of links whose parent gathers through LDS */
@@ -305,7 +305,8 @@ typedef struct {
                                      unless it overlays the link accelerations), [3M] reduced rows */
   int *CRC;                       /* [M] contact of a reduced constraint row */
   double *MA, *MB, *MF, *PU;      /* MLCP: [M*(M+1)] (ALIASES IST|POOL), [M], [M], [nside*npurow*M] (ALIASES C|PA when it fits) */
-  int *lrg, *lel, *tgt, *cnt;
+  int *tgt, *cnt;
+  unsigned char *lrg, *lel;       /* [maxact] candidates in rigid / elastic contact, in candidate order */
   unsigned char *act, *typ;       /* [NC] in contact, stick / slip type                   */
   unsigned char *asl;             /* [NC] active-contact slot of a candidate              */
   int *LI;                        /* [NL] packed link info (RKFD_LI_*)                    */
@@ -318,13 +319,16 @@ RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int
 /* must match the byte count computed in rkfd_devmodel.cpp */
 {
   double *d = (double *)base;
-  L->q = d; d += ND; L->qd = d; d += ND;
   L->S = d; d += NL*6;
   L->V = d; L->U = d; L->tmp = d; d += NL*6;
+  /* the joint coordinates and rates (2 ND <= 12 NL doubles) are read when an evaluation starts and written by the
+   * integrator after it ended: they borrow the bias-force / acceleration block and the velocity-product block,
+   * which the kinematics phase fills only after its last look at them */
+  L->q = d; L->qd = d + ND;
   L->PB = d; L->AC = d; d += NL*6;
   L->C = d; d += NL*6;
   L->PA = d; L->XA = d; d += NL*6;
-  L->MS = d; d += NL*4;
+  L->MS = d; d += NL*3;
   {
     const int pool = 36*npool > 6*NL ? 36*npool : 6*NL;
     int stage = 14*NL + pool;
@@ -350,13 +354,14 @@ RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int
   if( vert_rigid ){ L->QL = d; d += M*M; L->QW = d; d += M*M; L->QV = d; d += 5*M + ( vert_rigid == 2 ? 0 : RKFD_WAVE ); L->CR = d; d += 3*M; }
   int *ip = (int *)d;
   L->CIp = ip; ip += NC; L->CFO = ip; ip += NC;
-  L->lrg = ip; ip += maxact; L->lel = ip; ip += maxact; L->tgt = ip; ip += 2*maxact; L->cnt = ip; ip += NC > 0 ? 8 : 4;
+  L->tgt = ip; ip += nside*maxact; L->cnt = ip; ip += NC > 0 ? 8 : 4;
   L->LI = ip; ip += NL;
   L->CRC = ip; if( vert_rigid ) ip += M;
   unsigned short *sp = (unsigned short *)ip;
   L->CHP = sp; sp += NL;
   unsigned char *bp = (unsigned char *)sp;
   L->act = bp; bp += NC; L->typ = bp; bp += NC; L->asl = bp; bp += NC;
+  L->lrg = bp; bp += maxact; L->lel = bp; bp += maxact;
   L->PL = bp;
 }
 

@@ -19,7 +19,7 @@ template<bool prof> RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, c
   const int li = L.LI[i];
   const int jt = on ? RKFD_LI_JT( li ) : RKFD_JOINT_FIXED;
   const int off = RKFD_LI_OFF( li );
-  double R[9], p[3], Rj[9], vJ[6], qd1 = 0, qdf[6] = {0,0,0,0,0,0};
+  double R[9], p[3], Rj[9], vJ[6], q1 = 0, qd1 = 0, qdf[6] = {0,0,0,0,0,0};
   int anc[RKFD_MAX_ROUND];
   {
     const int *ancp = RELOAD( m.anc );
@@ -38,14 +38,15 @@ template<bool prof> RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, c
     for( int k=0; k<9; k++ ) R[k] = o[k];
     p[0]=o[9]; p[1]=o[10]; p[2]=o[11];
     if( jt == RKFD_JOINT_REVOL ){
-      double q = L.q[off], s, c;
-      d_sincos( q, &s, &c );
+      double s, c;
+      q1 = L.q[off];
+      d_sincos( q1, &s, &c );
       double Rz[9] = { c,-s,0, s,c,0, 0,0,1 };
       d_mul33( o, Rz, R );
       qd1 = L.qd[off];
     } else if( jt == RKFD_JOINT_PRISM ){
-      double q = L.q[off];
-      p[0] += q*o[2]; p[1] += q*o[5]; p[2] += q*o[8];
+      q1 = L.q[off];
+      p[0] += q1*o[2]; p[1] += q1*o[5]; p[2] += q1*o[8];
       qd1 = L.qd[off];
     } else if( jt == RKFD_JOINT_FLOAT ){
       double qq[6], t[3];
@@ -222,14 +223,14 @@ template<bool prof> RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, c
         if( mt == RKFD_MOTOR_DC ){
           const double gear = RELOAD( m.mot_gear )[i], admit = RELOAD( m.mot_admit )[i];
           const double gk = gear*RELOAD( m.mot_k )[i];
-          jm = RELOAD( m.mot_inertia )[i]*gear*gear;
+          jm = RELOAD( m.mot_inertia )[i];      /* reflected through the gear on the host */
           tin = admit*gk*d_clamp( in, RELOAD( m.mot_vmin )[i], RELOAD( m.mot_vmax )[i] );
           treg = admit*gk*gk*qd1;
           tf = jm*( -qd1/m.dt ) - tin + treg + ll.pivp;
           double fmax;
           if( ll.pivt == RKFD_SF ) fmax = RELOAD( m.sfric )[i];
           else {
-            const double q = L.q[off];
+            const double q = q1;      /* (L.q shares its storage with PB / C, written above) */
             const double sg = qd1 > 0 ? 1.0 : ( qd1 < 0 ? -1.0 : 0.0 );
             fmax = -RELOAD( m.stiff )[i]*q - RELOAD( m.visc )[i]*qd1 - RELOAD( m.coulomb )[i]*sg;
           }
@@ -238,16 +239,15 @@ template<bool prof> RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, c
           if( fabs( tf ) > fmax ){ tf = tf > 0 ? fmax : -fmax; newt = RKFD_KF; }
           else newt = RKFD_SF;
           /* the pivot type is committed by the caller when doUpRef (stored in MS slot 1 as a flag) */
-          L.MS[4*i+1] = (double)newt;
+          L.MS[3*i+1] = (double)newt;
         } else if( mt == RKFD_MOTOR_TRQ ){
           tin = d_clamp( in, RELOAD( m.mot_vmin )[i], RELOAD( m.mot_vmax )[i] );
         }
         tau = tin - treg + tf;
         /* driving torque without the inertia term + friction, for rkFDUpdateJointPrevDrivingTrq */
-        L.MS[4*i+0] = tin - treg + tf;
+        L.MS[3*i+0] = tin - treg + tf;
       }
-      L.MS[4*i+2] = tau;
-      L.MS[4*i+3] = jm;
+      L.MS[3*i+2] = tau;
     }
   }
   SYNC();

@@ -133,7 +133,7 @@ template<bool prof, bool vqp> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &
   /* sqrt(1/D) of the 1-DoF joints (MS slot 2: the driving torque kept there is dead after sweep 2) */
   if( lane < NL ){
     const int jt = RKFD_LI_JT( L.LI[lane] );
-    if( jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM ) L.MS[4*lane+2] = sqrt( L.MS[4*lane+0] );
+    if( jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM ) L.MS[3*lane+2] = sqrt( L.MS[3*lane+0] );
   }
   SYNC();
   MST(14);
@@ -168,14 +168,14 @@ template<bool prof, bool vqp> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &
         double Sx[6], Ux[6], sdx, dix;
 #pragma unroll
         for( int k=0; k<6; k++ ){ Sx[k] = L.S[6*a+k]; Ux[k] = L.U[6*a+k]; }
-        sdx = L.MS[4*a+2]; dix = L.MS[4*a+0];
+        sdx = L.MS[3*a+2]; dix = L.MS[3*a+0];
         int inext = path[da > 0 ? da-1 : 0];
         for( int d=da; d>=d0; d-- ){
           const int in_ = inext;
           double Sn[6], Un[6];
 #pragma unroll
           for( int k=0; k<6; k++ ){ Sn[k] = L.S[6*in_+k]; Un[k] = L.U[6*in_+k]; }
-          const double sdn = L.MS[4*in_+2], din = L.MS[4*in_+0];
+          const double sdn = L.MS[3*in_+2], din = L.MS[3*in_+0];
           inext = path[d > 1 ? d-2 : 0];
           double du0 = Sx[0]*dp[0], du1 = Sx[1]*dp[1];
           du0 = fma( Sx[2], dp[2], du0 ); du1 = fma( Sx[3], dp[3], du1 );
@@ -387,7 +387,7 @@ template<bool prof, bool vqp> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &
                        : ( RKFD_CS_DEPTH( e ) >= dpt && RKFD_CS_D0( e ) <= dpt && L.PL[RKFD_CS_LINK( e )*NLV+dpt] == link ) );
         sum += onp ? v : 0.0;
       }
-      if( is1 ) L.MS[4*link+1] = sum*L.MS[4*link+2];
+      if( is1 ) L.MS[3*link+1] = sum*L.MS[3*link+2];
       if( isf ) L.U[6*link+fq] = sum;
     }
   }

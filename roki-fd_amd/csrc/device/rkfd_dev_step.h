@@ -21,11 +21,11 @@ template<bool prof, bool vqp> RKFD_DEV int rkfd_evaluate(const rkfdDevModel &m, 
   if( doUpRef && lane < m.nlink ){
     const int jt = RKFD_LI_JT( L.LI[lane] );
     if( ( jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM ) && RKFD_LI_MT( L.LI[lane] ) == RKFD_MOTOR_DC )
-      ll.pivt = (int)L.MS[4*lane+1];
+      ll.pivt = (int)L.MS[3*lane+1];
   }
   /* MS slot 0 carries (driving torque + friction) until sweep 2 overwrites it: keep a copy */
   double drv = 0;
-  if( lane < m.nlink ) drv = L.MS[4*lane+0];
+  if( lane < m.nlink ) drv = L.MS[3*lane+0];
   SYNC();
   if( m.ncand > 0 ){
     rkfd_phase_collision( m, L );
@@ -63,7 +63,7 @@ template<bool prof, bool vqp> RKFD_DEV int rkfd_evaluate(const rkfdDevModel &m, 
   if( doUpRef && lane < m.nlink ){
     const int jt = RKFD_LI_JT( L.LI[lane] );
     if( jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM )
-      ll.pivp = drv - L.MS[4*lane+3]*L.acc[RKFD_LI_OFF( L.LI[lane] )];
+      ll.pivp = drv - m.mot_inertia[lane]*L.acc[RKFD_LI_OFF( L.LI[lane] )];
   }
   SYNC();
   STAMP(5);

@@ -94,13 +94,13 @@ RKFD_DEV void rkfd_row_offsets(int rr, int *ro)
     ro[k] = v;
   }
 }
-RKFD_DEV void rkfd_pre2_load(const rkfdLds &L, int i, int rr, const int *ro, rkfdPre2 &p)
+RKFD_DEV void rkfd_pre2_load(const rkfdDevModel &m, const rkfdLds &L, int i, int rr, const int *ro, rkfdPre2 &p)
 {
 #pragma unroll
   for( int k=0; k<6; k++ ){ p.S[k] = L.S[6*i+k]; p.c[k] = L.C[6*i+k]; }
   p.S_r = L.S[6*i+rr];
   p.pb = L.PB[6*i+rr];
-  p.tau = L.MS[4*i+2]; p.jm = L.MS[4*i+3];
+  p.tau = L.MS[3*i+2]; p.jm = m.mot_inertia[i];
 #pragma unroll
   for( int k=0; k<6; k++ ) p.row[k] = L.IST[14*i+ro[k]];
 }
@@ -130,7 +130,7 @@ template<bool prof> RKFD_DEV void rkfd_phase_sweep2(const rkfdDevModel &m, const
     /* operands of this iteration (with two waves per SIMD the other wave covers the LDS latency;
      * a second, prefetched operand set would cost ~60 VGPRs) */
     rkfdPre2 pre;
-    rkfd_pre2_load( L, rec.i >= 0 ? rec.i : 0, rr, ro, pre );
+    rkfd_pre2_load( m, L, rec.i >= 0 ? rec.i : 0, rr, ro, pre );
     QST(8);
     const bool onl = rec.i >= 0;
     const bool on = onl && r < 6;
@@ -203,8 +203,8 @@ template<bool prof> RKFD_DEV void rkfd_phase_sweep2(const rkfdDevModel &m, const
       L.PA[6*i+rr] = pa;
       if( isf ) L.U[6*i+rr] = pr;   /* float: the U slot keeps the bias pA */
       if( rr == 0 && is1 ){
-        L.MS[4*i+0] = Dinv;
-        L.MS[4*i+1] = u;
+        L.MS[3*i+0] = Dinv;
+        L.MS[3*i+1] = u;
       }
     }
     LDS_FENCE();
@@ -231,7 +231,7 @@ typedef struct { double c_r, U_r, S_r, u, Dinv; } rkfdPre3;
 template<bool delta> RKFD_DEV void rkfd_pre3_load(const rkfdLds &L, int i, int rr, rkfdPre3 &p)
 {
   p.c_r = delta ? 0.0 : L.C[6*i+rr]; p.U_r = L.U[6*i+rr]; p.S_r = L.S[6*i+rr];
-  p.Dinv = L.MS[4*i+0]; p.u = L.MS[4*i+1];
+  p.Dinv = L.MS[3*i+0]; p.u = L.MS[3*i+1];
 }
 template<bool delta> RKFD_DEV void rkfd_phase_sweep3(const rkfdDevModel &m, const rkfdLds &L)
 {

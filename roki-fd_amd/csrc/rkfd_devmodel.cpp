@@ -122,7 +122,9 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
     const int i = orig[r];
     R_stiff[r] = m->stiff[i]; R_visc[r] = m->visc[i]; R_coulomb[r] = m->coulomb[i]; R_sfric[r] = m->sfric[i];
     R_mot_k[r] = m->mot_k[i]; R_mot_admit[r] = m->mot_admit[i]; R_mot_vmax[r] = m->mot_vmax[i]; R_mot_vmin[r] = m->mot_vmin[i];
-    R_mot_gear[r] = m->mot_gear[i]; R_mot_inertia[r] = m->mot_inertia[i];
+    R_mot_gear[r] = m->mot_gear[i];
+    /* the device keeps the inertia reflected through the gear (same product order as the oracle's), 0 without a DC motor */
+    R_mot_inertia[r] = ( ( m->jtype[i] == RKFD_JOINT_REVOL || m->jtype[i] == RKFD_JOINT_PRISM ) && m->mtype[i] == RKFD_MOTOR_DC ) ? m->mot_inertia[i]*m->mot_gear[i]*m->mot_gear[i] : 0.0;
   }
 
   /* depth, levels */
@@ -412,11 +414,11 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
     const size_t pool = (size_t)36*npool > (size_t)6*NL ? (size_t)36*npool : (size_t)6*NL;   /* Ia pool | second half of the world frames */
     size_t stage = (size_t)14*NL + pool;                         /* inertia staging + Ia pool ...   */
     if( (size_t)dm.ma_size > stage ) stage = (size_t)dm.ma_size;   /* ... shared with the contact matrix */
-    const size_t dbl = (size_t)2*ND + (size_t)NL*( 5*6 + 4 ) + stage + (size_t)48*nfloat
+    const size_t dbl = (size_t)NL*( 5*6 + 3 ) + stage + (size_t)48*nfloat
                      + (size_t)maxact*( 24 + ( NC > RKFD_WAVE ? 3 : 0 ) + ( dm.has_slide ? 6 : 0 ) ) + ( dm.vert_rigid ? 2 : 1 )*M + ( dm.pu_alias ? 0 : (size_t)nside*npurow*M )
                      + ( dm.vert_rigid ? 2*M*M + 5*M + ( dm.qscr_alias ? 0 : RKFD_WAVE ) + 3*M : 0 );   /* Vert QP: QL, QW, QV, CR */
-    const size_t ints = (size_t)2*NC + (size_t)4*maxact + ( NC > 0 ? 8 : 4 ) + (size_t)NL + ( dm.vert_rigid ? M : 0 );     /* CIp CFO, lrg lel tgt, cnt, LI, CRC */
-    const size_t bytes = (size_t)2*NL + (size_t)3*NC                                     /* CHP (16 bit), act typ asl (bytes) */
+    const size_t ints = (size_t)2*NC + (size_t)nside*maxact + ( NC > 0 ? 8 : 4 ) + (size_t)NL + ( dm.vert_rigid ? M : 0 );     /* CIp CFO, lrg lel tgt, cnt, LI, CRC */
+    const size_t bytes = (size_t)2*NL + (size_t)3*NC + (size_t)2*maxact                                     /* CHP (16 bit), act typ asl (bytes) */
                        + ( max_rigid > 0 ? (size_t)NL*( nlevel+3 ) : 0 );                /* PL */
     out->lds_bytes = dbl*sizeof(double) + ints*sizeof(int) + bytes;
     out->lds_bytes = ( out->lds_bytes + 15 ) & ~(size_t)15;

@@ -39,7 +39,7 @@ typedef struct {
   const int *orig;       /* [nlink] model link of a device link                                       */
   const double *org, *mass, *com, *inertia;
   const double *stiff, *visc, *coulomb, *sfric;
-  const double *mot_k, *mot_admit, *mot_vmax, *mot_vmin, *mot_gear, *mot_inertia;
+  const double *mot_k, *mot_admit, *mot_vmax, *mot_vmin, *mot_gear, *mot_inertia;   /* mot_inertia: reflected through the gear, 0 without a DC motor */
   const int *anc;        /* [nround][nlink]: ancestor 2^r levels up, -1 if none          */
   const int *level_off;  /* [nlevel+1]                                                   */
   const int *level_link; /* [nlink] links sorted by depth                                */
