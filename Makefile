@@ -30,7 +30,7 @@ $(BUILD)/rkfd_devmodel.o: $(CSRC)/rkfd_devmodel.cpp $(CSRC)/*.h $(CSRC)/device/*
 # kernel spills to scratch and that all of them fit three waves per SIMD (168 VGPRs)
 $(BUILD)/rkfd_capi.o: $(CSRC)/rkfd_capi.hip $(CSRC)/*.h $(CSRC)/device/*.h include/*.h | $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(BUILD)/rkfd_capi.remarks || ( cat $(BUILD)/rkfd_capi.remarks; exit 1 )
-	@grep -E "Function Name|VGPRs:|ScratchSize|Occupancy" $(BUILD)/rkfd_capi.remarks | sed 's/.*remark: *//; s/ \[-Rpass.*//' > $(PKG)/kernel_resources.txt
+	@grep -E "Function Name|VGPRs:|ScratchSize|Occupancy|VGPRs Spill|SGPRs Spill" $(BUILD)/rkfd_capi.remarks | sed 's/.*remark: *//; s/ \[-Rpass.*//' > $(PKG)/kernel_resources.txt
 	@grep -vE "remark:|^ +[0-9]+ \||^ +\||\^" $(BUILD)/rkfd_capi.remarks || true
 
 $(LIB): $(HOST_OBJS) $(BUILD)/rkfd_capi.o

@@ -310,7 +310,8 @@ typedef struct {
   unsigned char *act, *typ;       /* [NC] in contact, stick / slip type                   */
   unsigned char *asl;             /* [NC] active-contact slot of a candidate              */
   int *LI;                        /* [NL] packed link info (RKFD_LI_*)                    */
-  int *CIp, *CFO;                 /* [NC] packed candidate info, first plane              */
+  int *CIp;                       /* [NC] packed candidate info                           */
+  unsigned short *CFO;            /* [NC] first plane of the candidate's partner shape    */
   unsigned short *CHP;            /* [NL] children lists (CSR values; offsets in the schedule): child | ( its pool slot + 1 ) << 8 */
   unsigned char *PL;              /* [NL*nlevel] ancestor at depth d (MLCP only), one byte each */
 } rkfdLds;
@@ -341,8 +342,8 @@ RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int
     if( ma_size > stage ) stage = ma_size;
     d += stage;
   }
-  L->CHOL = d; d += 36*nfloat; L->XF = d; d += 12*nfloat;
-  L->CX = d; d += maxact*3; L->AX = d; d += maxact*9; L->RW = d; d += maxact*3; L->PRO = d; d += maxact*3;
+  L->CHOL = d; d += 21*nfloat; L->XF = d; d += 12*nfloat;
+  L->CX = d; d += maxact*3; L->AX = d; d += maxact*6; L->RW = d; d += maxact*3; L->PRO = d; d += maxact*3;
   L->REF = d; d += maxact*3; L->RTMP = d; if( NC > RKFD_WAVE ) d += maxact*3;
   L->CF = d; d += maxact*3;
   L->SV = d; L->SD = d; if( has_slide ){ L->SV = d; d += maxact*3; L->SD = d; d += maxact*3; }
@@ -353,16 +354,25 @@ RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int
   L->QL = d; L->QW = d; L->QV = d; L->CR = d;
   if( vert_rigid ){ L->QL = d; d += M*M; L->QW = d; d += M*M; L->QV = d; d += 5*M + ( vert_rigid == 2 ? 0 : RKFD_WAVE ); L->CR = d; d += 3*M; }
   int *ip = (int *)d;
-  L->CIp = ip; ip += NC; L->CFO = ip; ip += NC;
+  L->CIp = ip; ip += NC;
   L->tgt = ip; ip += nside*maxact; L->cnt = ip; ip += NC > 0 ? 8 : 4;
   L->LI = ip; ip += NL;
   L->CRC = ip; if( vert_rigid ) ip += M;
   unsigned short *sp = (unsigned short *)ip;
-  L->CHP = sp; sp += NL;
+  L->CHP = sp; sp += NL; L->CFO = sp; sp += NC;
   unsigned char *bp = (unsigned char *)sp;
   L->act = bp; bp += NC; L->typ = bp; bp += NC; L->asl = bp; bp += NC;
   L->lrg = bp; bp += maxact; L->lel = bp; bp += maxact;
   L->PL = bp;
+}
+
+/* the contact frame of a slot: normal and first tangent are stored, the second tangent is their cross product
+ * (exactly how d_ortho_space made it) */
+RKFD_DEV void d_load_axes(const rkfdLds &L, int slot, double *ax)
+{
+#pragma unroll
+  for( int k=0; k<6; k++ ) ax[k] = L.AX[6*slot+k];
+  d_cross( ax, ax+3, ax+6 );
 }
 
 /* per-lane state that only lane = link ever touches: kept in registers for the whole launch */

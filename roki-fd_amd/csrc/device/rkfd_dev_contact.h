@@ -93,7 +93,7 @@ RKFD_DEV void rkfd_phase_collision(const rkfdDevModel &m, const rkfdLds &L)
         L.RW[3*slot] = rw[0]+pB[0]; L.RW[3*slot+1] = rw[1]+pB[1]; L.RW[3*slot+2] = rw[2]+pB[2];
         d_ortho_space( nw, t1, t2 );
 #pragma unroll
-        for( int k=0; k<3; k++ ){ L.AX[9*slot+k] = nw[k]; L.AX[9*slot+3+k] = t1[k]; L.AX[9*slot+6+k] = t2[k]; }
+        for( int k=0; k<3; k++ ){ L.AX[6*slot+k] = nw[k]; L.AX[6*slot+3+k] = t1[k]; }
         if( m.has_slide ){
           /* cells in slide mode (rkFDLinkAddSlideVel, rkFDUpdateRefSlide; reference src/rkfd_util.c:26-40,218-237):
            * the surface runs around its slide axis, tangentially to the contact normal.  The frames are at hand
@@ -199,7 +199,8 @@ RKFD_DEV void rkfd_push_wrenches(const rkfdDevModel &m, const rkfdLds &L, const 
 RKFD_DEV void d_modify_friction(const rkfdDevModel &m, const rkfdLds &L, int j, const double *vr, double *f, bool doUpRef)
 {
   const int ci = RKFD_CI_CI( L.CIp[j] );
-  const double *ax = &L.AX[9*L.asl[j]];
+  double ax[9];
+  d_load_axes( L, L.asl[j], ax );
   const double fn = d_dot( f, ax );
   const double f1 = d_dot( f, ax+3 ), f2 = d_dot( f, ax+6 );
   const double fs = sqrt( f1*f1 + f2*f2 );
@@ -242,7 +243,7 @@ RKFD_DEV void rkfd_phase_penalty(const rkfdDevModel &m, const rkfdLds &L, bool d
       vr[k] = va[k]-vb[k] + ( m.has_slide ? L.SV[3*L.asl[j]+k] : 0.0 );
       f[k] = -E*( x[k]-L.RW[3*L.asl[j]+k] ) + kv*vr[k];
     }
-    if( d_dot( f, &L.AX[9*L.asl[j]] ) < 0.0 ){
+    if( d_dot( f, &L.AX[6*L.asl[j]] ) < 0.0 ){
       f[0] = f[1] = f[2] = 0;
     } else {
       d_modify_friction( m, L, j, vr, f, doUpRef );
@@ -270,9 +271,11 @@ RKFD_DEV void rkfd_phase_bvel(const rkfdDevModel &m, const rkfdLds &L, double *b
     double va[3], vb[3], ca[3], cb[3];
     d_point_vel( &L.V[6*la], x, va ); d_point_vel( &L.V[6*lb], x, vb );
     d_cross( &L.V[6*la], va, ca ); d_cross( &L.V[6*lb], vb, cb );
+    double axl[9];
+    d_load_axes( L, sl, axl );
 #pragma unroll
     for( int i=0; i<3; i++ ){
-      const double *ax = &L.AX[9*sl+3*i];
+      const double *ax = &axl[3*i];
       bv[i]   = ax[0]*( va[0]-vb[0] ) + ax[1]*( va[1]-vb[1] ) + ax[2]*( va[2]-vb[2] );
       if( m.has_slide ) bv[i] += ax[0]*L.SV[3*sl] + ax[1]*L.SV[3*sl+1] + ax[2]*L.SV[3*sl+2];
       bv[3+i] = ax[0]*( ca[0]-cb[0] ) + ax[1]*( ca[1]-cb[1] ) + ax[2]*( ca[2]-cb[2] );

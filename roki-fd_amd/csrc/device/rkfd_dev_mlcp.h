@@ -107,9 +107,11 @@ template<bool prof, bool vqp> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &
     }
     const double mu = L.typ[j] == RKFD_SF ? m.ci_sf[ci] : m.ci_kf[ci];
     const double K = m.ci_k[ci];
+    double axl[9];
+    d_load_axes( L, L.asl[j], axl );
 #pragma unroll
     for( int i=0; i<3; i++ ){
-      const double *ax = &L.AX[9*L.asl[j]+3*i];
+      const double *ax = &axl[3*i];
       double b = ( d_dot( ax, ra ) + bv[3+i] )*dt + bv[i];
       b += ( i == 0 ? K : K*mu )*d_dot( d, ax );
       L.MB[3*lane+i] = b;
@@ -149,7 +151,10 @@ template<bool prof, bool vqp> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &
     double W[6];
     {
       const double x[3] = { L.CX[3*L.asl[j]], L.CX[3*L.asl[j]+1], L.CX[3*L.asl[j]+2] };
-      const double *ax = &L.AX[9*L.asl[j]+3*ia];
+      double axl[9], ax[3];
+      d_load_axes( L, L.asl[j], axl );
+#pragma unroll
+      for( int k=0; k<3; k++ ) ax[k] = ia == 0 ? axl[k] : ( ia == 1 ? axl[3+k] : axl[6+k] );
       d_cross( x, ax, W );
       W[3] = ax[0]; W[4] = ax[1]; W[5] = ax[2];
     }
@@ -194,7 +199,7 @@ template<bool prof, bool vqp> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &
           double rhs[6], y[6];
 #pragma unroll
           for( int k=0; k<6; k++ ) rhs[k] = -dp[k];
-          d_chol6_fwd( &L.CHOL[36*FSL[RKFD_CS_TOP( e )]], rhs, y );
+          d_chol6_fwd( &L.CHOL[21*FSL[RKFD_CS_TOP( e )]], rhs, y );
 #pragma unroll
           for( int k=0; k<6; k++ ) pu[( NLV+k )*M] = y[k];
         }
@@ -265,11 +270,12 @@ template<bool prof, bool vqp> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &
      * a vertex is in kinetic friction when one of its pyramid faces is active at the solution */
     if( lane < nc ){
       const int j = L.lrg[lane];
-      double fw[3] = {0,0,0};
+      double fw[3] = {0,0,0}, axl[9];
+      d_load_axes( L, L.asl[j], axl );
 #pragma unroll
       for( int i=0; i<3; i++ ){
         const double fi = L.MF[3*lane+i];
-        fw[0] += fi*L.AX[9*L.asl[j]+3*i]; fw[1] += fi*L.AX[9*L.asl[j]+3*i+1]; fw[2] += fi*L.AX[9*L.asl[j]+3*i+2];
+        fw[0] += fi*axl[3*i]; fw[1] += fi*axl[3*i+1]; fw[2] += fi*axl[3*i+2];
       }
       { const int sl_ = L.asl[j]; L.CF[3*sl_] = fw[0]; L.CF[3*sl_+1] = fw[1]; L.CF[3*sl_+2] = fw[2]; }
       if( doUpRef ){
@@ -341,11 +347,12 @@ template<bool prof, bool vqp> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &
   /* _rkFDSolverSetForce (reference src/rkfd_mlcp.c:252-284) incl. quirks Q1 / Q2 */
   if( lane < nc ){
     const int j = L.lrg[lane], ci = RKFD_CI_CI( L.CIp[j] );
-    double fw[3] = {0,0,0};
+    double fw[3] = {0,0,0}, axl[9];
+    d_load_axes( L, L.asl[j], axl );
 #pragma unroll
     for( int i=0; i<3; i++ ){
       const double fi = L.MF[3*lane+i];
-      fw[0] += fi*L.AX[9*L.asl[j]+3*i]; fw[1] += fi*L.AX[9*L.asl[j]+3*i+1]; fw[2] += fi*L.AX[9*L.asl[j]+3*i+2];
+      fw[0] += fi*axl[3*i]; fw[1] += fi*axl[3*i+1]; fw[2] += fi*axl[3*i+2];
     }
     { const int sl_ = L.asl[j]; L.CF[3*sl_] = fw[0]; L.CF[3*sl_+1] = fw[1]; L.CF[3*sl_+2] = fw[2]; }
     const double fn = fw[0], fs = sqrt( fw[1]*fw[1] + fw[2]*fw[2] );

@@ -7,6 +7,8 @@
 /* ------------------------------------------------------------------------ */
 /* in-place Cholesky of the 6x6 at A (row-major, lower part used), one lane.  The diagonal
  * stores 1/L_jj so that the factorisation and the solves multiply instead of dividing. */
+/* the factor of a float joint's articulated inertia: lower triangle, packed by rows (21 doubles) */
+#define RKFD_TRI(i,k) ( (i)*( (i)+1 )/2 + (k) )
 RKFD_DEV void d_chol6_inplace(double *A)
 {
   /* the lower triangle is pulled into registers in one batch of loads, factored there and written back */
@@ -14,7 +16,7 @@ RKFD_DEV void d_chol6_inplace(double *A)
 #pragma unroll
   for( int i=0; i<6; i++ )
 #pragma unroll
-    for( int k=0; k<6; k++ ) if( k <= i ) a[i][k] = A[6*i+k];
+    for( int k=0; k<6; k++ ) if( k <= i ) a[i][k] = A[RKFD_TRI( i, k )];
 #pragma unroll
   for( int j=0; j<6; j++ ){
     double s = a[j][j];
@@ -33,7 +35,7 @@ RKFD_DEV void d_chol6_inplace(double *A)
 #pragma unroll
   for( int i=0; i<6; i++ )
 #pragma unroll
-    for( int k=0; k<6; k++ ) if( k <= i ) A[6*i+k] = a[i][k];
+    for( int k=0; k<6; k++ ) if( k <= i ) A[RKFD_TRI( i, k )] = a[i][k];
 }
 /* forward substitution y = L^-1 b and back substitution x = L^-T y with that factor */
 RKFD_DEV void d_chol6_fwd(const double *Lm, const double *b, double *y)
@@ -42,8 +44,8 @@ RKFD_DEV void d_chol6_fwd(const double *Lm, const double *b, double *y)
   for( int i=0; i<6; i++ ){
     double s = b[i];
 #pragma unroll
-    for( int k=0; k<6; k++ ) if( k < i ) s -= Lm[6*i+k]*y[k];
-    y[i] = s*Lm[6*i+i];
+    for( int k=0; k<6; k++ ) if( k < i ) s -= Lm[RKFD_TRI( i, k )]*y[k];
+    y[i] = s*Lm[RKFD_TRI( i, i )];
   }
 }
 RKFD_DEV void d_chol6_back(const double *Lm, const double *y, double *x)
@@ -52,8 +54,8 @@ RKFD_DEV void d_chol6_back(const double *Lm, const double *y, double *x)
   for( int i=5; i>=0; i-- ){
     double s = y[i];
 #pragma unroll
-    for( int k=0; k<6; k++ ) if( k > i ) s -= Lm[6*k+i]*x[k];
-    x[i] = s*Lm[6*i+i];
+    for( int k=0; k<6; k++ ) if( k > i ) s -= Lm[RKFD_TRI( k, i )]*x[k];
+    x[i] = s*Lm[RKFD_TRI( i, i )];
   }
 }
 
@@ -197,7 +199,7 @@ template<bool prof> RKFD_DEV void rkfd_phase_sweep2(const rkfdDevModel &m, const
       }
       if( isf ){
 #pragma unroll
-        for( int k=0; k<6; k++ ) L.CHOL[36*REC_FSLOT( rec )+6*rr+k] = row[k];
+        for( int k=0; k<6; k++ ) if( k <= rr ) L.CHOL[21*REC_FSLOT( rec )+RKFD_TRI( rr, k )] = row[k];
       }
       if( is1 ) L.U[6*i+rr] = U_r;
       L.PA[6*i+rr] = pa;
@@ -209,7 +211,7 @@ template<bool prof> RKFD_DEV void rkfd_phase_sweep2(const rkfdDevModel &m, const
     }
     LDS_FENCE();
     QST(12);
-    if( isf && onl && r == 0 ) d_chol6_inplace( &L.CHOL[36*REC_FSLOT( rec )] );
+    if( isf && onl && r == 0 ) d_chol6_inplace( &L.CHOL[21*REC_FSLOT( rec )] );
     QST(13);
 #undef QST
 #pragma unroll
@@ -274,13 +276,13 @@ template<bool delta> RKFD_DEV void rkfd_phase_sweep3(const rkfdDevModel &m, cons
         if( delta ){
 #pragma unroll
           for( int k=0; k<6; k++ ) rhs[k] = L.U[6*i+k];
-          d_chol6_back( &L.CHOL[36*REC_FSLOT( rec )], rhs, x );
+          d_chol6_back( &L.CHOL[21*REC_FSLOT( rec )], rhs, x );
         } else {
           double yv[6];
 #pragma unroll
           for( int k=0; k<6; k++ ) rhs[k] = -L.U[6*i+k];
-          d_chol6_fwd( &L.CHOL[36*REC_FSLOT( rec )], rhs, yv );
-          d_chol6_back( &L.CHOL[36*REC_FSLOT( rec )], yv, x );
+          d_chol6_fwd( &L.CHOL[21*REC_FSLOT( rec )], rhs, yv );
+          d_chol6_back( &L.CHOL[21*REC_FSLOT( rec )], yv, x );
         }
 #pragma unroll
         for( int k=0; k<6; k++ ){

@@ -195,6 +195,7 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
     const int shA = m->pair_shape[2*pr+sd], shB = m->pair_shape[2*pr+1-sd];
     cA[j] = rep[m->shape_link[shA]]; cB[j] = rep[m->shape_link[shB]];
     cfo[j] = m->shape_foff[shB]; cnf[j] = m->shape_foff[shB+1] - m->shape_foff[shB];
+    if( cfo[j] > 65535 ) FAIL( "more than 65535 shape faces (the device keeps a candidate's first plane in 16 bits)" );
     cci[j] = m->pair_ci[pr];
     const double *T = &Trep[12*m->shape_link[shA]], *v = &m->verts[3*m->cand_vert[j]];
     for( int a=0; a<3; a++ ) cv[3*j+a] = T[9+a] + T[3*a]*v[0] + T[3*a+1]*v[1] + T[3*a+2]*v[2];
@@ -414,11 +415,11 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
     const size_t pool = (size_t)36*npool > (size_t)6*NL ? (size_t)36*npool : (size_t)6*NL;   /* Ia pool | second half of the world frames */
     size_t stage = (size_t)14*NL + pool;                         /* inertia staging + Ia pool ...   */
     if( (size_t)dm.ma_size > stage ) stage = (size_t)dm.ma_size;   /* ... shared with the contact matrix */
-    const size_t dbl = (size_t)NL*( 5*6 + 3 ) + stage + (size_t)48*nfloat
-                     + (size_t)maxact*( 24 + ( NC > RKFD_WAVE ? 3 : 0 ) + ( dm.has_slide ? 6 : 0 ) ) + ( dm.vert_rigid ? 2 : 1 )*M + ( dm.pu_alias ? 0 : (size_t)nside*npurow*M )
+    const size_t dbl = (size_t)NL*( 5*6 + 3 ) + stage + (size_t)33*nfloat
+                     + (size_t)maxact*( 21 + ( NC > RKFD_WAVE ? 3 : 0 ) + ( dm.has_slide ? 6 : 0 ) ) + ( dm.vert_rigid ? 2 : 1 )*M + ( dm.pu_alias ? 0 : (size_t)nside*npurow*M )
                      + ( dm.vert_rigid ? 2*M*M + 5*M + ( dm.qscr_alias ? 0 : RKFD_WAVE ) + 3*M : 0 );   /* Vert QP: QL, QW, QV, CR */
-    const size_t ints = (size_t)2*NC + (size_t)nside*maxact + ( NC > 0 ? 8 : 4 ) + (size_t)NL + ( dm.vert_rigid ? M : 0 );     /* CIp CFO, lrg lel tgt, cnt, LI, CRC */
-    const size_t bytes = (size_t)2*NL + (size_t)3*NC + (size_t)2*maxact                                     /* CHP (16 bit), act typ asl (bytes) */
+    const size_t ints = (size_t)NC + (size_t)nside*maxact + ( NC > 0 ? 8 : 4 ) + (size_t)NL + ( dm.vert_rigid ? M : 0 );     /* CIp CFO, lrg lel tgt, cnt, LI, CRC */
+    const size_t bytes = (size_t)2*NL + (size_t)5*NC + (size_t)2*maxact                                     /* CHP (16 bit), act typ asl (bytes) */
                        + ( max_rigid > 0 ? (size_t)NL*( nlevel+3 ) : 0 );                /* PL */
     out->lds_bytes = dbl*sizeof(double) + ints*sizeof(int) + bytes;
     out->lds_bytes = ( out->lds_bytes + 15 ) & ~(size_t)15;
