@@ -60,8 +60,8 @@ int rkfdBatchSetPivot(rkfdBatch *b, const int *type, const double *prev_trq);
 /* rkFDUpdateInit's committing evaluation _rkFDUpdateRef (reference src/rkfd_sim.c:542-549,556).
  * stream: hipStream_t (NULL = default stream).  Asynchronous. */
 int rkfdBatchUpdateInit(rkfdBatch *b, void *stream);
-/* nsteps x rkFDUpdate (reference src/rkfd_sim.c:560-566) for every instance, fused in one launch.
- * Asynchronous. */
+/* nsteps x rkFDUpdate (reference src/rkfd_sim.c:560-566) for every instance: one launch with the steps fused, or -
+ * under split launches - nsteps rounds of one-step launches on the internal streams (same results).  Asynchronous. */
 int rkfdBatchUpdate(rkfdBatch *b, int nsteps, void *stream);
 /* one evaluation _rkFDUpdate (doUpRef=0) or _rkFDUpdateRef (doUpRef=1) at the current state
  * (reference src/rkfd_sim.c:533-549): fills acc and the contact forces.  Asynchronous. */
