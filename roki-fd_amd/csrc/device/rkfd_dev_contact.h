@@ -47,18 +47,24 @@ RKFD_DEV void rkfd_phase_collision(const rkfdDevModel &m, const rkfdLds &L)
     pB[0] = pB[1] = pB[2] = 0;
     if( on ){
       const int la = RKFD_CI_A( cinf ), lb = RKFD_CI_B( cinf );
-      double vl[3], rr[3];
+      double vl[3], rr[3], bs[4];
 #pragma unroll
       for( int k=0; k<6; k++ ){ RA[k] = L.XA[6*la+k]; RB[k] = L.XA[6*lb+k]; }
 #pragma unroll
       for( int k=0; k<3; k++ ){ RA[6+k] = L.XB[6*la+k]; RB[6+k] = L.XB[6*lb+k]; }
 #pragma unroll
       for( int k=0; k<3; k++ ){ pA[k] = L.XB[6*la+3+k]; pB[k] = L.XB[6*lb+3+k]; vl[k] = RELOAD( m.cand_vert )[3*j+k]; }
+#pragma unroll
+      for( int k=0; k<4; k++ ) bs[k] = RELOAD( m.cand_bs )[4*j+k];
       d_mulv( RA, vl, x );
       x[0] += pA[0]; x[1] += pA[1]; x[2] += pA[2];
       rr[0] = x[0]-pB[0]; rr[1] = x[1]-pB[1]; rr[2] = x[2]-pB[2];
       d_tmulv( RB, rr, y );
-      const int f0 = L.CFO[j], nf = RKFD_CI_NF( cinf );
+      /* broad phase: a vertex outside the sphere around the other shape cannot touch it (no plane is read for it;
+       * the face loop of a chunk runs as long as its nearest candidate needs) */
+      const double e0 = y[0]-bs[0], e1 = y[1]-bs[1], e2 = y[2]-bs[2];
+      const bool nearb = e0*e0 + e1*e1 + e2*e2 <= bs[3];
+      const int f0 = L.CFO[j], nf = nearb ? RKFD_CI_NF( cinf ) : 0;
       for( int f=f0; f<f0+nf; f++ ){
         const double sd = m.planes[4*f]*y[0] + m.planes[4*f+1]*y[1] + m.planes[4*f+2]*y[2] - m.planes[4*f+3];
         if( sd > smax ){ smax = sd; fbest = f; }

@@ -3,6 +3,7 @@
  * and by the lane emulator under tests/emu.
  */
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 #include <stdio.h>
 #include <vector>
@@ -200,6 +201,33 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
     const double *T = &Trep[12*m->shape_link[shA]], *v = &m->verts[3*m->cand_vert[j]];
     for( int a=0; a<3; a++ ) cv[3*j+a] = T[9+a] + T[3*a]*v[0] + T[3*a+1]*v[1] + T[3*a+2]*v[2];
   }
+  /* broad phase: a sphere around the other shape (its vertices, in its device link's frame) that a candidate vertex
+   * must enter before it is tested against the shape's planes.  The margin (0.1 % + 1 mm) is far above the contact
+   * tolerance, so the cull never changes a result */
+  std::vector<double> cbs( (size_t)4*( NC ? NC : 1 ), 0.0 );
+  for( int j=0; j<NC; j++ ){
+    const int pr = m->cand_pair[j], sd = m->cand_side[j];
+    const int shB = m->pair_shape[2*pr+1-sd];
+    const double *T = &Trep[12*m->shape_link[shB]];
+    double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
+    std::vector<double> w;
+    for( int v=m->shape_voff[shB]; v<m->shape_voff[shB+1]; v++ ){
+      const double *p = &m->verts[3*v];
+      for( int a=0; a<3; a++ ){
+        const double x = T[9+a] + T[3*a]*p[0] + T[3*a+1]*p[1] + T[3*a+2]*p[2];
+        w.push_back( x ); if( x < lo[a] ) lo[a] = x; if( x > hi[a] ) hi[a] = x;
+      }
+    }
+    double r2 = 0;
+    for( int a=0; a<3; a++ ) cbs[4*j+a] = w.empty() ? 0.0 : 0.5*( lo[a]+hi[a] );
+    for( size_t v=0; v+2<w.size(); v+=3 ){
+      double d2 = 0;
+      for( int a=0; a<3; a++ ){ const double d = w[v+a]-cbs[4*j+a]; d2 += d*d; }
+      if( d2 > r2 ) r2 = d2;
+    }
+    const double r = sqrt( r2 )*1.001 + 1e-3;
+    cbs[4*j+3] = w.empty() ? 1e300 : r*r;
+  }
   std::vector<double> refT( (size_t)12*( NC ? NC : 1 ), 0.0 );
   for( int j=0; j<NC; j++ ){
     const int pr = m->cand_pair[j], sd = m->cand_side[j];
@@ -387,7 +415,7 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   PUT( pslot, pslot.data(), sizeof(int)*NL );
   PUT( cand_linkA, cA.data(), sizeof(int)*NC ); PUT( cand_linkB, cB.data(), sizeof(int)*NC );
   PUT( cand_foff, cfo.data(), sizeof(int)*NC ); PUT( cand_nf, cnf.data(), sizeof(int)*NC );
-  PUT( cand_ci, cci.data(), sizeof(int)*NC ); PUT( cand_vert, cv.data(), sizeof(double)*3*NC );
+  PUT( cand_ci, cci.data(), sizeof(int)*NC ); PUT( cand_vert, cv.data(), sizeof(double)*3*NC ); PUT( cand_bs, cbs.data(), sizeof(double)*4*( NC ? NC : 1 ) );
   dm.has_slide = has_slide;
   PUT( cs_mode, csm.data(), sizeof(int)*csm.size() ); PUT( cs_par, csp.data(), sizeof(double)*csp.size() );
   PUT( planes, planes_d.data(), sizeof(double)*4*nplane );
@@ -444,7 +472,7 @@ extern "C" void rkfd_devmodel_rebase(rkfdDevModel *dm, const void *from, const v
   RB(org); RB(mass); RB(com); RB(inertia); RB(stiff); RB(visc); RB(coulomb); RB(sfric);
   RB(mot_k); RB(mot_admit); RB(mot_vmax); RB(mot_vmin); RB(mot_gear); RB(mot_inertia);
   RB(anc); RB(level_off); RB(level_link); RB(child_off); RB(child_idx); RB(pathlink); RB(linfo); RB(sched); RB(cinfo); RB(pslot); RB(orig); RB(dofkind);
-  RB(cand_linkA); RB(cand_linkB); RB(cand_foff); RB(cand_nf); RB(cand_ci); RB(cand_vert); RB(cs_mode); RB(cs_par); RB(planes);
+  RB(cand_linkA); RB(cand_linkB); RB(cand_foff); RB(cand_nf); RB(cand_ci); RB(cand_vert); RB(cand_bs); RB(cs_mode); RB(cs_par); RB(planes);
   RB(ci_type); RB(ci_sf); RB(ci_kf); RB(ci_k); RB(ci_l); RB(ci_e); RB(ci_v);
 #undef RB
 }

@@ -58,6 +58,7 @@ typedef struct {
   /* per candidate contact vertex */
   const int *cand_linkA, *cand_linkB, *cand_foff, *cand_nf, *cand_ci;
   const double *cand_vert; /* [ncand*3] vertex in link A's frame                         */
+  const double *cand_bs;   /* [ncand*4] bounding sphere of the other shape in link B's frame: centre, squared radius (with a margin) */
   /* slide mode (fake crawler), only when has_slide: per candidate the two cells, owner first:
    * cs_mode [ncand*2] 0/1 | 2 when the anchor drift is expressed in the OWNER link's frame (reference index quirk,
    * src/rkfd_util.c:232), cs_par [ncand*14]: slide_vel, axis(3), origin of the shape's model link (3), both in the
