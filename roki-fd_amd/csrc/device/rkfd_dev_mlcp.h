@@ -9,14 +9,23 @@
  * statically, the broadcasts read fixed lanes and the dependent path of an update is ALU only.
  * Same arithmetic and update order as the general loop in rkfd_phase_mlcp. */
 #define RKFD_PGS_NC 4
-RKFD_DEV void rkfd_pgs_registers(const double *Arow, int ld, int nc, int max_iter, bool on, int lane, double mu,
+/* where entry (R, K) of the contact matrix lives: full rows (stride ld), or - kernel variants pk, chosen by the host
+ * where it buys residency - the lower triangle packed by rows (A is exactly symmetric), which halves the largest
+ * object in LDS (72 rows: 41 KB -> 21 KB, a third instance per CU for config 5).  The packed form costs index
+ * arithmetic in the PGS (+12 % of that phase), so small matrices that fit anyway stay full. */
+template<bool pk> RKFD_DEV int rkfd_ma_idx(int Rr, int K, int ld)
+{
+  if( !pk ) return Rr*ld + K;
+  return K <= Rr ? ( Rr*( Rr+1 ) >> 1 ) + K : ( K*( K+1 ) >> 1 ) + Rr;
+}
+template<bool pk> RKFD_DEV void rkfd_pgs_registers(const double *MA, int r0, int ld, int nc, int max_iter, bool on, int lane, double mu,
                                  double in_, double i1, double i2, double &rn, double &r1, double &r2, double &fn, double &f1, double &f2)
 {
   double A0[3*RKFD_PGS_NC], A1[3*RKFD_PGS_NC], A2[3*RKFD_PGS_NC];
 #pragma unroll
   for( int k=0; k<3*RKFD_PGS_NC; k++ ){
     const bool in = on && k < 3*nc;
-    A0[k] = in ? Arow[k] : 0.0; A1[k] = in ? Arow[ld+k] : 0.0; A2[k] = in ? Arow[2*ld+k] : 0.0;
+    A0[k] = in ? MA[rkfd_ma_idx<pk>( r0, k, ld )] : 0.0; A1[k] = in ? MA[rkfd_ma_idx<pk>( r0+1, k, ld )] : 0.0; A2[k] = in ? MA[rkfd_ma_idx<pk>( r0+2, k, ld )] : 0.0;
   }
   for( int it=0; it<max_iter; it++ ){
 #pragma unroll
@@ -70,7 +79,7 @@ RKFD_DEV void rkfd_pgs_registers(const double *Arow, int ld, int nc, int max_ite
  * i.e. no per-column response walks and no second backward sweep; A comes out exactly
  * symmetric.  Output: contact forces CF, committed contact state, and the inputs of the delta
  * sweep (MS slot 1, U slot of float joints). */
-template<bool prof, bool vqp> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L, const double *bv, bool doUpRef, unsigned long long *pc)
+template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L, const double *bv, bool doUpRef, unsigned long long *pc)
 {
   /* the Vert plugin's rigid branch (reference src/rkfd_vert.c:325-336) shares the contact system (A, b) and
    * the way the forces are applied; it differs in the solver (QP instead of PGS), in where the
@@ -217,7 +226,7 @@ template<bool prof, bool vqp> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &
       for( int sr=0; sr<NSD; sr++ ) for( int sk=0; sk<NSD; sk++ ){
         const unsigned er = (unsigned)L.tgt[cr*NSD+sr], ek = (unsigned)L.tgt[ck*NSD+sk];
         if( !RKFD_CS_VALID( er ) || !RKFD_CS_VALID( ek ) || RKFD_CS_TOP( er ) != RKFD_CS_TOP( ek ) ) continue;   /* no joint in common */
-        const double *pr = &L.PU[sr*PUS + 3*cr], *pk = &L.PU[sk*PUS + 3*ck];
+        const double *pr = &L.PU[sr*PUS + 3*cr], *pkk = &L.PU[sk*PUS + 3*ck];
         const int a = RKFD_CS_LINK( er ), b = RKFD_CS_LINK( ek );
         const int d0 = RKFD_CS_D0( er );
         int dc = RKFD_CS_DEPTH( er ) < RKFD_CS_DEPTH( ek ) ? RKFD_CS_DEPTH( er ) : RKFD_CS_DEPTH( ek );
@@ -230,7 +239,7 @@ template<bool prof, bool vqp> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &
 #pragma unroll 2
         for( int d=d0; d<=dc; d++ ){
           const double r0 = pr[d*M], r1 = pr[d*M+1], r2 = pr[d*M+2];
-          const double k0 = pk[d*M], k1 = pk[d*M+1], k2 = pk[d*M+2];
+          const double k0 = pkk[d*M], k1 = pkk[d*M+1], k2 = pkk[d*M+2];
           blk[0] = fma( r0, k0, blk[0] ); blk[1] = fma( r0, k1, blk[1] ); blk[2] = fma( r0, k2, blk[2] );
           blk[3] = fma( r1, k0, blk[3] ); blk[4] = fma( r1, k1, blk[4] ); blk[5] = fma( r1, k2, blk[5] );
           blk[6] = fma( r2, k0, blk[6] ); blk[7] = fma( r2, k1, blk[7] ); blk[8] = fma( r2, k2, blk[8] );
@@ -240,7 +249,7 @@ template<bool prof, bool vqp> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &
           for( int q=0; q<6; q++ ){
             const int d = NLV + q;
             const double r0 = pr[d*M], r1 = pr[d*M+1], r2 = pr[d*M+2];
-            const double k0 = pk[d*M], k1 = pk[d*M+1], k2 = pk[d*M+2];
+            const double k0 = pkk[d*M], k1 = pkk[d*M+1], k2 = pkk[d*M+2];
             blk[0] = fma( r0, k0, blk[0] ); blk[1] = fma( r0, k1, blk[1] ); blk[2] = fma( r0, k2, blk[2] );
             blk[3] = fma( r1, k0, blk[3] ); blk[4] = fma( r1, k1, blk[4] ); blk[5] = fma( r1, k2, blk[5] );
             blk[6] = fma( r2, k0, blk[6] ); blk[7] = fma( r2, k1, blk[7] ); blk[8] = fma( r2, k2, blk[8] );
@@ -256,8 +265,12 @@ template<bool prof, bool vqp> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &
       for( int i=0; i<3; i++ )
 #pragma unroll
         for( int q=0; q<3; q++ ){
-          L.MA[( 3*cr+i )*ld + 3*ck+q] = blk[3*i+q];
-          if( cr != ck ) L.MA[( 3*ck+q )*ld + 3*cr+i] = blk[3*i+q];
+          if( !pk ){
+            L.MA[( 3*cr+i )*ld + 3*ck+q] = blk[3*i+q];
+            if( cr != ck ) L.MA[( 3*ck+q )*ld + 3*cr+i] = blk[3*i+q];
+          } else if( cr != ck || q <= i ){
+            L.MA[rkfd_ma_idx<true>( 3*cr+i, 3*ck+q, 0 )] = blk[3*i+q];
+          }
         }
     }
   }
@@ -301,7 +314,7 @@ template<bool prof, bool vqp> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &
     double rn = 0, r1 = 0, r2 = 0, fn = 0, f1 = 0, f2 = 0, in_ = 0, i1 = 0, i2 = 0, mu = 0;
     if( on ){
       rn = L.MB[r0]; r1 = L.MB[r0+1]; r2 = L.MB[r0+2];
-      const double dn = L.MA[r0*ld+r0], d1 = L.MA[(r0+1)*ld+r0+1], d2 = L.MA[(r0+2)*ld+r0+2];
+      const double dn = L.MA[rkfd_ma_idx<pk>( r0, r0, ld )], d1 = L.MA[rkfd_ma_idx<pk>( r0+1, r0+1, ld )], d2 = L.MA[rkfd_ma_idx<pk>( r0+2, r0+2, ld )];
       in_ = 1.0/dn;
       /* tangential rows with |a_kk| < zTOL are frozen at 0 (reference :220-221) */
       i1 = fabs( d1 ) < RKFD_DEV_TOL ? 0.0 : 1.0/d1;
@@ -309,12 +322,11 @@ template<bool prof, bool vqp> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &
       const int jr_ = L.lrg[lane], cir_ = RKFD_CI_CI( L.CIp[jr_] );
       mu = L.typ[jr_] == RKFD_SF ? m.ci_sf[cir_] : m.ci_kf[cir_];
     }
-    const double *Arow = &L.MA[r0*ld];
-    if( nc <= RKFD_PGS_NC ) rkfd_pgs_registers( Arow, ld, nc, m.max_iter, on, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
+    if( nc <= RKFD_PGS_NC ) rkfd_pgs_registers<pk>( L.MA, r0, ld, nc, m.max_iter, on, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
     else for( int it=0; it<m.max_iter; it++ ){
       for( int c=0; c<nc; c++ ){
         /* normal force of contact c: f_n <- max( 0, -( b + a.f - a_nn f_n ) / a_nn ) */
-        const double a0 = Arow[3*c], a1 = Arow[ld+3*c], a2 = Arow[2*ld+3*c];
+        const double a0 = L.MA[rkfd_ma_idx<pk>( r0, 3*c, ld )], a1 = L.MA[rkfd_ma_idx<pk>( r0+1, 3*c, ld )], a2 = L.MA[rkfd_ma_idx<pk>( r0+2, 3*c, ld )];
         double ff = fn - rn*in_;
         if( ff < RKFD_DEV_TOL ) ff = 0.0;
         const double dl = BCAST( ff - fn, c );
@@ -324,8 +336,8 @@ template<bool prof, bool vqp> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &
       for( int c=0; c<nc; c++ ){
         /* tangential forces of contact c: Gauss-Seidel value for both, then scaled onto the
          * friction disc of radius mu f_n */
-        const double a0 = Arow[3*c+1], a1 = Arow[ld+3*c+1], a2 = Arow[2*ld+3*c+1];
-        const double b0 = Arow[3*c+2], b1 = Arow[ld+3*c+2], b2 = Arow[2*ld+3*c+2];
+        const double a0 = L.MA[rkfd_ma_idx<pk>( r0, 3*c+1, ld )], a1 = L.MA[rkfd_ma_idx<pk>( r0+1, 3*c+1, ld )], a2 = L.MA[rkfd_ma_idx<pk>( r0+2, 3*c+1, ld )];
+        const double b0 = L.MA[rkfd_ma_idx<pk>( r0, 3*c+2, ld )], b1 = L.MA[rkfd_ma_idx<pk>( r0+1, 3*c+2, ld )], b2 = L.MA[rkfd_ma_idx<pk>( r0+2, 3*c+2, ld )];
         const double ff0 = f1 - r1*i1, ff1 = f2 - r2*i2;
         const double fnorm = ff0*ff0 + ff1*ff1;
         double fs = mu*fn; fs = fs*fs;

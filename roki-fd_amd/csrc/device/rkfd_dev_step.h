@@ -8,7 +8,7 @@
 /* one dynamics evaluation: _rkFDUpdate / _rkFDUpdateRef (reference src/rkfd_sim.c:533-549).
  * Input L.q, L.qd; output L.acc (and contact / pivot state).  Returns nonzero when the model
  * needs a rigid solver that is not available on the device (wave-uniform). */
-template<bool prof, bool vqp> RKFD_DEV int rkfd_evaluate(const rkfdDevModel &m, const rkfdLds &L, rkfdLaneLink &ll, bool doUpRef, unsigned long long *pc)
+template<bool prof, bool vqp, bool pk> RKFD_DEV int rkfd_evaluate(const rkfdDevModel &m, const rkfdLds &L, rkfdLaneLink &ll, bool doUpRef, unsigned long long *pc)
 {
   const int lane = LANE();
   int err = 0;
@@ -48,7 +48,7 @@ template<bool prof, bool vqp> RKFD_DEV int rkfd_evaluate(const rkfdDevModel &m, 
       SYNC();
       const double afree = lane < m.ndof ? L.acc[lane] : 0.0;
       /* contact forces, then their effect on the accelerations (rkChainUpdateCachedABI in the reference) */
-      rkfd_phase_mlcp<prof, vqp>( m, L, bv, doUpRef, pc );
+      rkfd_phase_mlcp<prof, vqp, pk>( m, L, bv, doUpRef, pc );
       STAMP(4);
       rkfd_phase_sweep3<true>( m, L );
       SYNC();
@@ -100,7 +100,7 @@ RKFD_DEV void rkfd_cat_dis(const rkfdDevModel &m, const rkfdLds &L, int dofkind,
 /* the whole step for one instance: load state, nsteps x rkFDUpdate (or a single evaluation),
  * store state.  mode 0: rkFDUpdate x nsteps; mode 1: rkFDUpdateInit (committing evaluation);
  * mode 2: evaluation without commit. */
-template<bool prof, bool vqp> RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkfdDevState &st, int b, void *ldsbase,
+template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkfdDevState &st, int b, void *ldsbase,
                             int mode, int nsteps, int *errflag)
 {
   const int lane = LANE();
@@ -188,7 +188,7 @@ template<bool prof, bool vqp> RKFD_DEV void rkfd_instance(const rkfdDevModel &m,
       if( stage == 4 ){ q = on ? L.q[lane] : 0.0; qd = xv; }
       SYNC();
       const bool doUp = mode == 0 ? stage == 4 : mode == 1;
-      err |= rkfd_evaluate<prof, vqp>( m, L, ll, doUp, pc );
+      err |= rkfd_evaluate<prof, vqp, pk>( m, L, ll, doUp, pc );
       const double a = on ? L.acc[lane] : 0.0;
       if( stage == 0 ){ Fv = xv; Fa = a; Tv = xv; Ta = a; Pv = c21*xv; Pa = c21*a; }
       else if( stage == 1 ){ Fv = fma( w2, xv, Fv ); Fa = fma( w2, a, Fa ); Tv = fma( c22, xv, Pv ); Ta = fma( c22, a, Pa ); Pv = c31*xv; Pa = c31*a; }

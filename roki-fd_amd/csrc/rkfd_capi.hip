@@ -18,22 +18,25 @@ static thread_local char g_err[512] = "";
  * three waves per SIMD, i.e. up to twelve instances per CU where the LDS allows (10 for the humanoid worlds).
  * With machine LICM on, the backend hoists ~35 registers of literals (sincos polynomial coefficients, fp64
  * constants) and addresses out of the step loop and the kernels need 184-193. */
-#define RKFD_KERNEL(name, prof, vqp) \
+#define RKFD_KERNEL(name, prof, vqp, pk) \
 extern "C" __global__ void __launch_bounds__(RKFD_WAVE, 3) \
 name(rkfdDevModel m, rkfdDevState st, int first, int mode, int nsteps, int *errflag) \
 { \
   extern __shared__ __attribute__((aligned(16))) char lds[]; \
   const int b = first + (int)blockIdx.x; \
   if( b >= st.batch ) return; \
-  rkfd_instance<prof, vqp>( m, st, b, lds, mode, nsteps, errflag ); \
+  rkfd_instance<prof, vqp, pk>( m, st, b, lds, mode, nsteps, errflag ); \
 }
-RKFD_KERNEL( rkfd_step_kernel, false, false )
+RKFD_KERNEL( rkfd_step_kernel, false, false, false )
+/* the contact matrix as a packed lower triangle (worlds where that lets one more instance share a CU) */
+RKFD_KERNEL( rkfd_step_kernel_pk, false, false, true )
 /* the variant that also carries the Vert plugin's QP (worlds with rigid pairs under the Vert plugin);
  * kept apart so that its code and registers do not weigh on the MLCP / penalty kernel */
-RKFD_KERNEL( rkfd_step_kernel_vqp, false, true )
+RKFD_KERNEL( rkfd_step_kernel_vqp, false, true, false )
 /* diagnostic instantiations with in-kernel phase stamps (rkfdBatchProfile) */
-RKFD_KERNEL( rkfd_step_kernel_prof, true, false )
-RKFD_KERNEL( rkfd_step_kernel_prof_vqp, true, true )
+RKFD_KERNEL( rkfd_step_kernel_prof, true, false, false )
+RKFD_KERNEL( rkfd_step_kernel_prof_pk, true, false, true )
+RKFD_KERNEL( rkfd_step_kernel_prof_vqp, true, true, false )
 
 typedef void (*rkfdKernel)(rkfdDevModel, rkfdDevState, int, int, int, int *);
 #define RKFD_MAX_SPLIT 8
@@ -124,8 +127,8 @@ extern "C" rkfdBatch *rkfdBatchCreate(const rkfdModel *m, int batch, int device,
   bad |= dalloc( &b->d_err, 1 );
   b->st.dbg = NULL; b->st.dbg_stride = 0; b->st.batch = batch; b->st.prof = NULL;
   if( bad ){ rkfdBatchDestroy( b ); return NULL; }
-  b->kern = b->dm.vert_rigid ? rkfd_step_kernel_vqp : rkfd_step_kernel;
-  b->kern_prof = b->dm.vert_rigid ? rkfd_step_kernel_prof_vqp : rkfd_step_kernel_prof;
+  b->kern = b->dm.vert_rigid ? rkfd_step_kernel_vqp : ( b->dm.ma_packed ? rkfd_step_kernel_pk : rkfd_step_kernel );
+  b->kern_prof = b->dm.vert_rigid ? rkfd_step_kernel_prof_vqp : ( b->dm.ma_packed ? rkfd_step_kernel_prof_pk : rkfd_step_kernel_prof );
   if( b->lds_bytes > 64*1024 ){
     hipError_t e = hipFuncSetAttribute( (const void *)b->kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes );
     if( e == hipSuccess ) e = hipFuncSetAttribute( (const void *)b->kern_prof, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes );

@@ -370,7 +370,8 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   dm.vert_rigid = ( m->solver == RKFD_SOLVER_VERT && has_rigid && max_rigid > 0 ) ? 1 : 0;
   dm.qscr_alias = ( dm.vert_rigid && 6*NL >= RKFD_WAVE ) ? 1 : 0;
   if( dm.qscr_alias ) dm.vert_rigid = 2;
-  dm.ma_size = dm.vert_rigid ? 3*max_rigid*( 3*max_rigid+1 ) : 9*max_rigid*max_rigid;
+  dm.ma_packed = 0;
+  dm.ma_size = dm.vert_rigid ? 3*max_rigid*( 3*max_rigid+1 ) : 9*max_rigid*max_rigid;   /* full rows (odd stride while a slot is free / for the Vert QP); see ma_packed below */
   if( dm.vert_rigid && (size_t)dm.pyramid*max_rigid > RKFD_WAVE )
     FAIL( "Vert plugin: pyramid faces x rigid contact capacity exceeds 64 (one constraint per lane)" );
   int maxact = has_elastic ? ( NC < 16 ? NC : 16 ) : 0;
@@ -437,8 +438,16 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
     memcpy( rf, refT.data(), sizeof(double)*refT.size() );
     out->ref_frame = rf; out->ncand = NC;
   }
-  /* LDS bytes one instance needs (must match rkfd_lds_carve in rkfd_device.h) */
-  {
+  /* LDS bytes one instance needs (must match rkfd_lds_carve in rkfd_device.h).  Two passes: with the contact matrix
+   * as full rows, and - PGS worlds only - as a packed lower triangle, which is taken when it lets one more instance
+   * share a CU (LDS is handed out in 1280-byte pieces, 128 per CU) */
+  size_t lds_full = 0;
+  for( int pass=0; pass<2; pass++ ){
+    if( pass == 1 ){
+      const size_t Mr = 3*(size_t)max_rigid;
+      if( dm.vert_rigid || max_rigid <= 0 ) break;
+      dm.ma_packed = 1; dm.ma_size = (int)( Mr*( Mr+1 )/2 );
+    }
     const size_t M = 3*(size_t)max_rigid;
     const size_t pool = (size_t)36*npool > (size_t)6*NL ? (size_t)36*npool : (size_t)6*NL;   /* Ia pool | second half of the world frames */
     size_t stage = (size_t)14*NL + pool;                         /* inertia staging + Ia pool ...   */
@@ -451,10 +460,16 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
                        + ( max_rigid > 0 ? (size_t)NL*( nlevel+3 ) : 0 );                /* PL */
     out->lds_bytes = dbl*sizeof(double) + ints*sizeof(int) + bytes;
     out->lds_bytes = ( out->lds_bytes + 15 ) & ~(size_t)15;
+    if( pass == 0 ) lds_full = out->lds_bytes;
+    else if( 128/( ( out->lds_bytes+1279 )/1280 ) <= 128/( ( lds_full+1279 )/1280 ) ){
+      /* no instance gained: stay with full rows */
+      dm.ma_packed = 0; dm.ma_size = 9*max_rigid*max_rigid; out->lds_bytes = lds_full;
+    }
     if( getenv( "RKFD_DEVMODEL_DUMP" ) )
       fprintf( stderr, "rkfd devmodel: NL %d ND %d NC %d nlevel %d npool %d nfloat %d maxact %d nside %d npurow %d pu_alias %d M %d stage %zu (staging %zu) vert %d -> %zu B of LDS\n",
                NL, ND, NC, nlevel, npool, nfloat, maxact, nside, npurow, dm.pu_alias, (int)M, stage, (size_t)14*NL + pool, dm.vert_rigid, out->lds_bytes );
   }
+  out->dm.ma_packed = dm.ma_packed; out->dm.ma_size = dm.ma_size;
   return 0;
 #undef FAIL
 }

@@ -27,7 +27,8 @@ typedef struct {
   int vert_rigid;        /* > 0: Vert plugin and rigid pairs exist -> the QP path and its LDS are set up;
                             2: the QP's reduction scratch overlays the link accelerations (qscr_alias)      */
   int qscr_alias;
-  int ma_size;           /* doubles the contact matrix may take: rows have an odd stride while a slot is free (and always for the Vert QP) */
+  int ma_packed;         /* 1: the contact matrix is kept as a packed lower triangle (PGS kernels only), chosen where it lets one more instance share a CU */
+  int ma_size;           /* doubles the contact matrix may take: full rows with an odd stride for the Vert QP, else the packed lower triangle */
   int pyramid;           /* faces of the Vert plugin's friction pyramid                                  */
   int npurow;            /* rows of PU per side: nlevel (+6 with a float joint)                         */
   int nside;             /* 1 when every rigid-capable pair has a static cell (probe walks one-sided) else 2 */

@@ -31,10 +31,10 @@ def _kernels():
 
 def test_every_kernel_variant_is_reported():
     k = _kernels()
-    assert set(k) == {"rkfd_step_kernel", "rkfd_step_kernel_vqp", "rkfd_step_kernel_prof", "rkfd_step_kernel_prof_vqp"}
+    assert set(k) == {"rkfd_step_kernel", "rkfd_step_kernel_pk", "rkfd_step_kernel_vqp", "rkfd_step_kernel_prof", "rkfd_step_kernel_prof_pk", "rkfd_step_kernel_prof_vqp"}
 
 
-@pytest.mark.parametrize("name", ["rkfd_step_kernel", "rkfd_step_kernel_vqp", "rkfd_step_kernel_prof", "rkfd_step_kernel_prof_vqp"])
+@pytest.mark.parametrize("name", ["rkfd_step_kernel", "rkfd_step_kernel_pk", "rkfd_step_kernel_vqp", "rkfd_step_kernel_prof", "rkfd_step_kernel_prof_pk", "rkfd_step_kernel_prof_vqp"])
 def test_kernel_fits_three_waves_per_simd_without_scratch(name):
     k = _kernels()[name]
     assert k["VGPRs Spill"] == 0, k
