@@ -19,6 +19,7 @@
 #  define G8BCAST(x,k)  rkfd_emu_g8bcast(x,k)
 #  define RKFD_RCP(x)   ( 1.0/(x) )
 #  define LDS_FENCE()   rkfd_emu_sync()
+#  define RKFD_SCHED_BARRIER() do{}while(0)
 #  define BCAST(x,l)    rkfd_emu_bcast(x,l)
 #  define BALLOT(p)     rkfd_emu_ballot(p)
 #else
@@ -101,6 +102,8 @@ RKFD_DEV double rkfd_rcp(double x)
 #  define RKFD_RCP(x)   rkfd_rcp(x)
 /* compiler-only fence: LDS operations of one wavefront execute in program order */
 #  define LDS_FENCE()   asm volatile( "" ::: "memory" )
+/* the instruction scheduler does not move anything across this point */
+#  define RKFD_SCHED_BARRIER() __builtin_amdgcn_sched_barrier( 0 )
 #  define BCAST(x,l)    rkfd_bcast(x,l)
 #  define BALLOT(p)     __ballot(p)
 #endif

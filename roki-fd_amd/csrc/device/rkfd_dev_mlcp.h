@@ -208,7 +208,9 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
           double rhs[6], y[6];
 #pragma unroll
           for( int k=0; k<6; k++ ) rhs[k] = -dp[k];
-          d_chol6_fwd( &L.CHOL[21*FSL[RKFD_CS_TOP( e )]], rhs, y );
+          double Lr[21];
+          d_chol6_load( &L.CHOL[21*FSL[RKFD_CS_TOP( e )]], Lr );
+          d_chol6_fwd( Lr, rhs, y );
 #pragma unroll
           for( int k=0; k<6; k++ ) pu[( NLV+k )*M] = y[k];
         }

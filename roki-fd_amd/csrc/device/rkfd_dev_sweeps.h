@@ -37,7 +37,15 @@ RKFD_DEV void d_chol6_inplace(double *A)
 #pragma unroll
     for( int k=0; k<6; k++ ) if( k <= i ) A[RKFD_TRI( i, k )] = a[i][k];
 }
-/* forward substitution y = L^-1 b and back substitution x = L^-T y with that factor */
+/* the factor is pulled into registers in one batch of loads before a substitution starts: left to itself the compiler
+ * sinks each load to its first use, and a 6x6 solve becomes eleven LDS round trips in a row */
+RKFD_DEV void d_chol6_load(const double *Lm, double *Lr)
+{
+#pragma unroll
+  for( int k=0; k<21; k++ ) Lr[k] = Lm[k];
+  RKFD_SCHED_BARRIER();
+}
+/* forward substitution y = L^-1 b and back substitution x = L^-T y with that factor (in registers) */
 RKFD_DEV void d_chol6_fwd(const double *Lm, const double *b, double *y)
 {
 #pragma unroll
@@ -276,13 +284,17 @@ template<bool delta> RKFD_DEV void rkfd_phase_sweep3(const rkfdDevModel &m, cons
         if( delta ){
 #pragma unroll
           for( int k=0; k<6; k++ ) rhs[k] = L.U[6*i+k];
-          d_chol6_back( &L.CHOL[21*REC_FSLOT( rec )], rhs, x );
+          double Lr[21];
+          d_chol6_load( &L.CHOL[21*REC_FSLOT( rec )], Lr );
+          d_chol6_back( Lr, rhs, x );
         } else {
           double yv[6];
 #pragma unroll
           for( int k=0; k<6; k++ ) rhs[k] = -L.U[6*i+k];
-          d_chol6_fwd( &L.CHOL[21*REC_FSLOT( rec )], rhs, yv );
-          d_chol6_back( &L.CHOL[21*REC_FSLOT( rec )], yv, x );
+          double Lr[21];
+          d_chol6_load( &L.CHOL[21*REC_FSLOT( rec )], Lr );
+          d_chol6_fwd( Lr, rhs, yv );
+          d_chol6_back( Lr, yv, x );
         }
 #pragma unroll
         for( int k=0; k<6; k++ ){
