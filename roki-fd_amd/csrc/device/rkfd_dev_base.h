@@ -306,7 +306,7 @@ typedef struct {
   double *QL, *QW, *QV, *CR;      /* Vert QP (only when the world can have rigid contacts under the Vert plugin):
                                      [M*M] Q / its Cholesky factor, [M*M] W = L^-1 C', [5M (+64)] vectors (+ reduction scratch
                                      unless it overlays the link accelerations), [3M] reduced rows */
-  int *CRC;                       /* [M] contact of a reduced constraint row */
+  unsigned char *CRC;             /* [M] contact of a reduced constraint row */
   double *MA, *MB, *MF, *PU;      /* MLCP: [M*(M+1)] (ALIASES IST|POOL), [M], [M], [nside*npurow*M] (ALIASES C|PA when it fits) */
   int *tgt, *cnt;
   unsigned char *lrg, *lel;       /* [maxact] candidates in rigid / elastic contact, in candidate order */
@@ -355,17 +355,17 @@ RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int
   /* probe scratch: lives while the contact problem is set up and solved, when C and PA are dead */
   if( pu_alias ) L->PU = L->C; else { L->PU = d; d += nside*npurow*M; }
   L->QL = d; L->QW = d; L->QV = d; L->CR = d;
-  if( vert_rigid ){ L->QL = d; d += M*M; L->QW = d; d += M*M; L->QV = d; d += 5*M + ( vert_rigid == 2 ? 0 : RKFD_WAVE ); L->CR = d; d += 3*M; }
+  if( vert_rigid ){ L->QL = d; d += M*( M+1 )/2; L->QW = d; d += M*M; L->QV = d; d += 5*M + ( vert_rigid == 2 ? 0 : RKFD_WAVE ); L->CR = d; d += 3*M; }
   int *ip = (int *)d;
   L->CIp = ip; ip += NC;
   L->tgt = ip; ip += nside*maxact; L->cnt = ip; ip += NC > 0 ? 8 : 4;
   L->LI = ip; ip += NL;
-  L->CRC = ip; if( vert_rigid ) ip += M;
   unsigned short *sp = (unsigned short *)ip;
   L->CHP = sp; sp += NL; L->CFO = sp; sp += NC;
   unsigned char *bp = (unsigned char *)sp;
   L->act = bp; bp += NC; L->typ = bp; bp += NC; L->asl = bp; bp += NC;
   L->lrg = bp; bp += maxact; L->lel = bp; bp += maxact;
+  L->CRC = bp; if( vert_rigid ) bp += M;
   L->PL = bp;
 }
 

@@ -9,47 +9,53 @@
 /* wave-cooperative dense kernels on small SPD systems held in LDS (n <= 64, row-major, leading
  * dimension ld).  All lanes call them (uniform control flow); lane i owns row / entry i. */
 
+/* These routines only touch the lower triangle; pk = true: it is stored packed by rows (entry (r,c) at r(r+1)/2 + c,
+ * ld unused), which is how the factor of Q is kept - half the LDS of a full square. */
+#define RKFD_WI(r,c) ( pk ? ( ( (r)*( (r)+1 ) ) >> 1 ) + (c) : (r)*ld + (c) )
 /* in-place Cholesky: lower triangle <- factor, diagonal <- 1/L_ii (left-looking; the pivot of
  * column k travels by v_readlane) */
-RKFD_DEV void rkfd_w_chol(double *Mx, int ld, int n)
+template<bool pk> RKFD_DEV void rkfd_w_chol(double *Mx, int ld, int n)
 {
   const int lane = LANE();
   for( int k=0; k<n; k++ ){
     double s = 0;
     if( lane >= k && lane < n ){
-      s = Mx[lane*ld+k];
-      for( int j=0; j<k; j++ ) s -= Mx[lane*ld+j]*Mx[k*ld+j];
+      s = Mx[RKFD_WI( lane, k )];
+      for( int j=0; j<k; j++ ) s -= Mx[RKFD_WI( lane, j )]*Mx[RKFD_WI( k, j )];
     }
     const double rinv = RKFD_RCP( sqrt( BCAST( s, k ) ) );
-    if( lane == k ) Mx[k*ld+k] = rinv;
-    else if( lane > k && lane < n ) Mx[lane*ld+k] = s*rinv;
+    if( lane == k ) Mx[RKFD_WI( k, k )] = rinv;
+    else if( lane > k && lane < n ) Mx[RKFD_WI( lane, k )] = s*rinv;
     LDS_FENCE();
   }
 }
 /* y = L^-1 b : lane i passes b_i and receives y_i */
-RKFD_DEV double rkfd_w_fwd(const double *Mx, int ld, int n, double bi)
+template<bool pk> RKFD_DEV double rkfd_w_fwd(const double *Mx, int ld, int n, double bi)
 {
   const int lane = LANE();
   double s = bi, yi = 0;
   for( int j=0; j<n; j++ ){
-    const double yj = BCAST( s, j )*Mx[j*ld+j];
+    const double yj = BCAST( s, j )*Mx[RKFD_WI( j, j )];
     if( lane == j ) yi = yj;
-    if( lane > j && lane < n ) s -= Mx[lane*ld+j]*yj;
+    if( lane > j && lane < n ) s -= Mx[RKFD_WI( lane, j )]*yj;
   }
   return yi;
 }
 /* x = L^-T y */
-RKFD_DEV double rkfd_w_back(const double *Mx, int ld, int n, double yi)
+template<bool pk> RKFD_DEV double rkfd_w_back(const double *Mx, int ld, int n, double yi)
 {
   const int lane = LANE();
   double s = yi, xi = 0;
   for( int j=n-1; j>=0; j-- ){
-    const double xj = BCAST( s, j )*Mx[j*ld+j];
+    const double xj = BCAST( s, j )*Mx[RKFD_WI( j, j )];
     if( lane == j ) xi = xj;
-    if( lane < j ) s -= Mx[j*ld+lane]*xj;
+    if( lane < j ) s -= Mx[RKFD_WI( j, lane )]*xj;
   }
   return xi;
 }
+#undef RKFD_WI
+/* entry (r, c <= r) of the packed factor of Q */
+#define RKFD_QI(r,c) ( ( ( (r)*( (r)+1 ) ) >> 1 ) + (c) )
 /* minimum / sum over the wave through a 64-entry LDS scratch (log-depth tree) */
 RKFD_DEV double rkfd_w_min(double v, double *scr)
 {
@@ -134,14 +140,14 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
     d_sincos( 0.0 + ( -PI/P ), &s0, &c0 );
     if( onc ){ g0 = mu*c0; g1 = s1; g2 = c1; }
   }
-  /* q = A'A + L (lower triangle and mirror), c = A'c */
+  /* q = A'A + L (lower triangle, packed by rows), c = A'c */
   for( int t0=0; t0<n*n; t0+=RKFD_WAVE ){
     const int t = t0 + lane, i = t/n, k = t - i*n;
     if( t < n*n && k <= i ){
       double s = 0;
       for( int r=0; r<n; r++ ) s = fma( L.MA[r*ld+i], L.MA[r*ld+k], s );
       if( i == k ) s += m.ci_l[RKFD_CI_CI( L.CIp[L.lrg[i/3]] )];
-      Q[i*ldq+k] = s; Q[k*ldq+i] = s;
+      Q[RKFD_QI( i, k )] = s;
     }
   }
   if( lane < n ){
@@ -151,10 +157,10 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
     ans[lane] = ( lane%3 == 0 ) ? 1.0 : 0.0;           /* _rkFDSolverQPASMInit */
   }
   SYNC();
-  rkfd_w_chol( Q, ldq, n );
+  rkfd_w_chol<true>( Q, 0, n );
   /* z = L^-1 c */
   {
-    const double zi = rkfd_w_fwd( Q, ldq, n, lane < n ? cv[lane] : 0.0 );
+    const double zi = rkfd_w_fwd<true>( Q, 0, n, lane < n ? cv[lane] : 0.0 );
     if( lane < n ) zv[lane] = zi;
   }
   SYNC();
@@ -198,8 +204,8 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
       const double h0 = L.CR[3*lane], h1 = L.CR[3*lane+1], h2 = L.CR[3*lane+2];
       for( int i=0; i<n; i++ ){
         double sacc = i == c3 ? h0 : ( i == c3+1 ? h1 : ( i == c3+2 ? h2 : 0.0 ) );
-        for( int j=c3; j<i; j++ ) sacc -= Q[i*ldq+j]*W[j*ldq+lane];
-        W[i*ldq+lane] = i < c3 ? 0.0 : sacc*Q[i*ldq+i];
+        for( int j=c3; j<i; j++ ) sacc -= Q[RKFD_QI( i, j )]*W[j*ldq+lane];
+        W[i*ldq+lane] = i < c3 ? 0.0 : sacc*Q[RKFD_QI( i, i )];
       }
     }
     SYNC();
@@ -216,10 +222,10 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
     if( lane < r ) for( int i=0; i<n; i++ ) rl = fma( W[i*ldq+lane], zv[i], rl );
     SYNC();
     VST(26);
-    rkfd_w_chol( S, ld, r );
+    rkfd_w_chol<false>( S, ld, r );
     {
-      const double y = rkfd_w_fwd( S, ld, r, rl );
-      const double l = rkfd_w_back( S, ld, r, y );
+      const double y = rkfd_w_fwd<false>( S, ld, r, rl );
+      const double l = rkfd_w_back<false>( S, ld, r, y );
       if( lane < r ) lam[lane] = l;
     }
     SYNC();
@@ -231,7 +237,7 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
         for( int a=0; a<r; a++ ) ti = fma( W[lane*ldq+a], lam[a], ti );
         ti -= zv[lane];
       }
-      const double xi = rkfd_w_back( Q, ldq, n, ti );
+      const double xi = rkfd_w_back<true>( Q, 0, n, ti );
       if( lane < n ) xv[lane] = xi;
     }
     SYNC();
@@ -292,8 +298,8 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
      * f'Qf/2 = |L'f|^2/2 with the stored factor (diagonal kept as 1/L_ii) */
     double part = 0;
     if( lane < n ){
-      double u = ans[lane]/Q[lane*ldq+lane];
-      for( int j=lane+1; j<n; j++ ) u = fma( Q[j*ldq+lane], ans[j], u );
+      double u = ans[lane]/Q[RKFD_QI( lane, lane )];
+      for( int j=lane+1; j<n; j++ ) u = fma( Q[RKFD_QI( j, lane )], ans[j], u );
       part = 0.5*u*u + cv[lane]*ans[lane];
     }
     const double objv = rkfd_w_sum( part, scr );

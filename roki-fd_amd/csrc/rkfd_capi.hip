@@ -318,7 +318,9 @@ static int launch(rkfdBatch *b, int mode, int nsteps, void *stream)
   /* several steps go out as that many rounds of one-step launches, not as fused kernels: a fused launch holds its
    * slots for all its steps, so with more instances than slots the rest of the batch waits that long and the tail
    * of the last round runs thin (4096 instances, 200 steps: 9.2 M steps/s fused, 12.7 M in rounds; tools/fused_vs_stepwise.py) */
-  const int rounds = ( mode == 0 && nsteps > 1 ) ? nsteps : 1, per = rounds > 1 ? 1 : nsteps;
+  /* (not for worlds under the Vert plugin: the QP makes the step times of the instances vary widely, and there the
+   * per-step barrier of a round costs more than the slots a fused launch holds: 2.1 M against 3.6 M steps/s) */
+  const int rounds = ( mode == 0 && nsteps > 1 && !b->dm.vert_rigid ) ? nsteps : 1, per = rounds > 1 ? 1 : nsteps;
   for( int r=0; r<rounds; r++ )
     for( int k=0; k<b->nsplit; k++ ){
       const int lo = (int)( (long long)b->batch*k/b->nsplit ), hi = (int)( (long long)b->batch*( k+1 )/b->nsplit );

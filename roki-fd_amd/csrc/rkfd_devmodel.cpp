@@ -454,9 +454,9 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
     if( (size_t)dm.ma_size > stage ) stage = (size_t)dm.ma_size;   /* ... shared with the contact matrix */
     const size_t dbl = (size_t)NL*( 5*6 + 3 ) + stage + (size_t)33*nfloat
                      + (size_t)maxact*( 21 + ( NC > RKFD_WAVE ? 3 : 0 ) + ( dm.has_slide ? 6 : 0 ) ) + ( dm.vert_rigid ? 2 : 1 )*M + ( dm.pu_alias ? 0 : (size_t)nside*npurow*M )
-                     + ( dm.vert_rigid ? 2*M*M + 5*M + ( dm.qscr_alias ? 0 : RKFD_WAVE ) + 3*M : 0 );   /* Vert QP: QL, QW, QV, CR */
-    const size_t ints = (size_t)NC + (size_t)nside*maxact + ( NC > 0 ? 8 : 4 ) + (size_t)NL + ( dm.vert_rigid ? M : 0 );     /* CIp CFO, lrg lel tgt, cnt, LI, CRC */
-    const size_t bytes = (size_t)2*NL + (size_t)5*NC + (size_t)2*maxact                                     /* CHP (16 bit), act typ asl (bytes) */
+                     + ( dm.vert_rigid ? M*M + M*( M+1 )/2 + 5*M + ( dm.qscr_alias ? 0 : RKFD_WAVE ) + 3*M : 0 );   /* Vert QP: QL, QW, QV, CR */
+    const size_t ints = (size_t)NC + (size_t)nside*maxact + ( NC > 0 ? 8 : 4 ) + (size_t)NL;     /* CIp, tgt, cnt, LI */
+    const size_t bytes = (size_t)2*NL + (size_t)5*NC + (size_t)2*maxact + ( dm.vert_rigid ? M : 0 )                                     /* CHP (16 bit), act typ asl (bytes) */
                        + ( max_rigid > 0 ? (size_t)NL*( nlevel+3 ) : 0 );                /* PL */
     out->lds_bytes = dbl*sizeof(double) + ints*sizeof(int) + bytes;
     out->lds_bytes = ( out->lds_bytes + 15 ) & ~(size_t)15;

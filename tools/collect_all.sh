@@ -10,7 +10,7 @@ WARM=100 python3 tools/prof_phases.py config2 config3 config4 config4v config5 >
 echo "phases done"
 python3 bench.py --workload config5 --steps 100 --warmup 20 > gpurun_out/bench_config5.json 2> gpurun_out/bench_config5.log
 echo "bench config5 done"
-python3 bench.py --workload config4v > gpurun_out/bench_config4v.json 2> gpurun_out/bench_config4v.log
+python3 bench.py --workload config4v --fuse 40 > gpurun_out/bench_config4v.json 2> gpurun_out/bench_config4v.log
 echo "bench config4v done"
 python3 tools/parity_report.py 1000 16 > gpurun_out/parity_report.txt 2>&1
 echo "parity report done"
