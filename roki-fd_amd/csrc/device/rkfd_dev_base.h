@@ -280,7 +280,10 @@ RKFD_DEV double d_clamp(double x, double lo, double hi){ return x < lo ? lo : ( 
 /* ------------------------------------------------------------------------ */
 /* LDS carve-up for one instance */
 typedef struct {
-  double *q, *qd, *acc;           /* [ndof] each                                         */
+  double *q, *qd;                 /* [ndof] each; live from the integrator's update to the first look of the next evaluation:
+                                     ALIAS the head of PB|AC|C */
+  double *acc;                    /* [ndof] joint accelerations: ALIASES the head of IST (dead after sweep 2) and so MA - the
+                                     free accelerations wait in a lane register while the contact problem is solved */
   double *tmp;                    /* [ndof] scratch of rkfd_cat_dis: ALIASES V (dead between evaluations) */
   double *S;                      /* [NL*6]  joint axis (ang, lin)                        */
   double *V;                      /* [NL*6]  spatial velocity (kinematics .. rkfd_phase_bvel)               */
@@ -295,19 +298,20 @@ typedef struct {
   double *IST;                    /* [NL*14] inertia staging: A = Iw + m(|r|^2 1 - r r') (xx,xy,xz,yy,yz,zz),
                                      +m r (3), -m r (3), m, 0: every entry of the 6x6 is one of these */
   double *POOL;                   /* [npool*36] Ia of links whose parent gathers through LDS */
-  double *CHOL;                   /* [nfloat*36] articulated inertia / Cholesky factor of float joints */
+  double *CHOL;                   /* [nfloat*21] articulated inertia / Cholesky factor of float joints: lower triangle, packed by rows */
   double *XF;                     /* [nfloat*12] float joints: world orientation of the joint-origin frame (9), link position (3) */
-  double *CX, *AX, *RW, *PRO;     /* per ACTIVE contact slot (capacity maxact): 3, 9, 3, 3 */
+  double *CX, *AX, *RW, *PRO;     /* per ACTIVE contact slot (capacity maxact): 3, 6 (normal, first tangent; d_load_axes), 3, 3 */
   double *REF;                    /* stick anchors (state): per active slot              */
   double *RTMP;                   /* [maxact*3] copy of REF while the slots are re-assigned; only when ncand > 64 */
   double *CF;                     /* contact forces (output): per active slot              */
   double *SV, *SD;                /* slide mode only: relative slide velocity of the two cells (world), anchor drift of one
                                      committing evaluation (anchor frame); per active slot, 3 each */
   double *QL, *QW, *QV, *CR;      /* Vert QP (only when the world can have rigid contacts under the Vert plugin):
-                                     [M*M] Q / its Cholesky factor, [M*M] W = L^-1 C', [5M (+64)] vectors (+ reduction scratch
+                                     [M(M+1)/2] Q / its Cholesky factor (packed lower triangle), [M*M] W = L^-1 C', [5M (+64)] vectors (+ reduction scratch
                                      unless it overlays the link accelerations), [3M] reduced rows */
   unsigned char *CRC;             /* [M] contact of a reduced constraint row */
-  double *MA, *MB, *MF, *PU;      /* MLCP: [M*(M+1)] (ALIASES IST|POOL), [M], [M], [nside*npurow*M] (ALIASES C|PA when it fits) */
+  double *MA, *MB, *MF, *PU;      /* contact problem: [ma_size] the matrix (ALIASES IST|POOL; full rows or a packed lower triangle, rkfd_ma_idx),
+                                     [M] bias vector, [M] forces (ALIAS the bias vector in the PGS kernels), [nside*npurow*M] (ALIASES C|PA when it fits) */
   int *tgt, *cnt;
   unsigned char *lrg, *lel;       /* [maxact] candidates in rigid / elastic contact, in candidate order */
   unsigned char *act, *typ;       /* [NC] in contact, stick / slip type                   */

@@ -137,7 +137,7 @@ template<bool prof> RKFD_DEV void rkfd_phase_sweep2(const rkfdDevModel &m, const
     const rkfdRec rec = rec1;
     rec1 = rec2;
     rec2 = rkfd_rec_load( m, t-2, g );
-    /* operands of this iteration (with two waves per SIMD the other wave covers the LDS latency;
+    /* operands of this iteration (the other waves of the SIMD cover the LDS latency;
      * a second, prefetched operand set would cost ~60 VGPRs) */
     rkfdPre2 pre;
     rkfd_pre2_load( m, L, rec.i >= 0 ? rec.i : 0, rr, ro, pre );
