@@ -34,7 +34,7 @@ $(BUILD)/rkfd_capi.o: $(CSRC)/rkfd_capi.hip $(CSRC)/*.h $(CSRC)/device/*.h inclu
 	@grep -vE "remark:|^ +[0-9]+ \||^ +\||\^" $(BUILD)/rkfd_capi.remarks || true
 
 $(LIB): $(HOST_OBJS) $(BUILD)/rkfd_capi.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm -lhiprtc -ldl
 
 oracle:
 	$(MAKE) -C oracle

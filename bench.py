@@ -123,10 +123,18 @@ def main():
     ap.add_argument("--fuse", type=int, default=1, help="steps per rkfdBatchUpdate call (must divide --steps).  1: a launch round per step.  "
                     "Worlds under the Vert plugin run the steps of a call fused in one kernel per part: the QP makes step times "
                     "vary widely between instances, and without a per-step barrier the variation averages out (config4v: 2.4 M -> 3.6 M steps/s)")
+    ap.add_argument("--no-specialize", action="store_true", help="keep the generic step kernel instead of compiling it for the "
+                    "workload's world (rkfdBatchSpecialize, hipRTC: same results, the world's dimensions as literals)")
     ap.add_argument("--split", type=int, default=3, help="launch each step as this many kernels over parts of the batch on internal HIP streams (1..8): the instances are independent, so the tail of one part's step overlaps the next step of another")
     args = ap.parse_args()
 
     import numpy as np
+    if not args.no_specialize and os.path.exists("/opt/rocm/lib/libamd_comgr.so.3") and not os.environ.get("RKFD_BENCH_NO_COMGR_PRELOAD"):
+        # rkfdBatchSpecialize compiles through hipRTC -> comgr.  PyTorch bundles an older comgr under the same soname, and
+        # whichever is loaded first serves the whole process: with the bundled one the specialised kernel spills (437
+        # VGPR spills, 3.9 M steps/s instead of 13.9 M).  Load the image's ROCm 7.2 compiler library before torch.
+        import ctypes
+        ctypes.CDLL("/opt/rocm/lib/libamd_comgr.so.3", mode=ctypes.RTLD_GLOBAL)
     import torch
     import rkfd_pkg
     R = rkfd_pkg.load()
@@ -147,6 +155,13 @@ def main():
     lo, hi = R.sharding.shard_range(rank, world, total)
     sl = slice(lo, hi)
     b = R.Batch(sc["world"], Bn, device=local, max_rigid=sc["max_rigid"])
+    specialized = False
+    if not args.no_specialize and b.lds_bytes <= 64 * 1024:
+        try:
+            b.specialize()
+            specialized = True
+        except R.RkfdError as e:              # an optimisation, not a correctness path: say so and keep the generic kernel
+            print("bench.py: %s" % e, file=sys.stderr)
     b.set_state(sc["dis"][sl], sc["vel"][sl])
     b.set_split(args.split)
     stream = torch.cuda.current_stream().cuda_stream
@@ -205,7 +220,7 @@ def main():
                        "parallelism": f"instances sharded over {world} GPU(s), no data-path collective; {args.split} launches per step on internal streams"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload, per_launch),
-                         "kernel": "rkfd_step_kernel", "kernel_ms": kernel_ms, "alg_bytes_per_instance_step": alg,
+                         "kernel": "rkfd_step_kernel_spec" if specialized else "rkfd_step_kernel", "kernel_ms": kernel_ms, "alg_bytes_per_instance_step": alg,
                          "instances_per_launch": per_launch, "launches_per_step": nlaunch / args.steps, "steps_per_launch": args.steps * args.split // nlaunch, "step_ms_hip_events": step_ms,
                          "lds_bytes_per_instance": b.lds_bytes, "resident_instances_per_cu": b.residency(),
                          "achieved_all_launches_of_a_step": alg * Bn / (step_ms * 1e-3) / 1e9},

@@ -73,6 +73,14 @@ int rkfdBatchEval(rkfdBatch *b, int doUpRef, void *stream);
  * rkfdBatchJoin( b, stream ) or rkfdBatchStatus( b, stream ); the host-side accessors (Get / Set) wait.
  * nsplit = 1 (default): one launch on the caller's stream, plain stream order. */
 int rkfdBatchSetSplit(rkfdBatch *b, int nsplit);
+/* Compile the step kernel for THIS world (hipRTC, a few seconds): the same device code with the world's dimensions
+ * as literals, so that the LDS layout, loop bounds and table strides fold into immediates (+7 % steps/s on the
+ * 30-DoF humanoid).  Results are bit-identical to the generic kernels, which stay in use for the profiling entry
+ * point.  Needs the package's csrc/ and include/ directories beside the library at run time; 0, or -1 with a message
+ * (the generic kernels remain in use then).  rkfdSpecializeCompile: the compile step alone, without a GPU - bytes
+ * of code object, or -1. */
+int rkfdBatchSpecialize(rkfdBatch *b);
+int rkfdSpecializeCompile(const rkfdModel *m, int max_rigid);
 int rkfdBatchJoin(rkfdBatch *b, void *stream);
 /* measurement aid: with on = 1 every launch is bracketed by HIP events on the stream it runs on;
  * rkfdBatchLaunchTiming synchronises the device and returns their number and summed duration */

@@ -80,7 +80,8 @@ def lib():
     L.rkfdBatchCreate.argtypes = [C.POINTER(RkfdModel), C.c_int, C.c_int, C.c_int]
     L.rkfdBatchCreate.restype = vp
     L.rkfdBatchDestroy.argtypes = [vp]
-    for f in ("rkfdBatchSize", "rkfdBatchDof", "rkfdBatchLdsBytes", "rkfdBatchResidency"):
+    L.rkfdSpecializeCompile.argtypes = [C.POINTER(RkfdModel), C.c_int]
+    for f in ("rkfdBatchSize", "rkfdBatchDof", "rkfdBatchLdsBytes", "rkfdBatchResidency", "rkfdBatchSpecialize"):
         getattr(L, f).argtypes = [vp]
     L.rkfdBatchSetState.argtypes = [vp, vp, vp]
     L.rkfdBatchGetState.argtypes = [vp, vp, vp, vp]
@@ -281,6 +282,10 @@ class Batch:
     @property
     def lds_bytes(self):
         return self._L.rkfdBatchLdsBytes(self._b)
+
+    def specialize(self):
+        """compile the step kernel for this world (hipRTC): same results, its dimensions as literals"""
+        self._chk(self._L.rkfdBatchSpecialize(self._b))
 
     def residency(self):
         """instances per compute unit the HIP runtime can keep resident (registers + LDS)"""

@@ -100,9 +100,24 @@ RKFD_DEV void rkfd_cat_dis(const rkfdDevModel &m, const rkfdLds &L, int dofkind,
 /* the whole step for one instance: load state, nsteps x rkFDUpdate (or a single evaluation),
  * store state.  mode 0: rkFDUpdate x nsteps; mode 1: rkFDUpdateInit (committing evaluation);
  * mode 2: evaluation without commit. */
-template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDevModel &m, const rkfdDevState &st, int b, void *ldsbase,
+template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDevModel &m_, const rkfdDevState &st, int b, void *ldsbase,
                             int mode, int nsteps, int *errflag)
 {
+#ifdef RKFD_SPEC
+  /* kernel compiled for ONE world (rkfdBatchSpecialize, hipRTC): its dimensions are literals, so the LDS layout,
+   * loop bounds and table strides fold into immediates (config 4: 190 -> 84 SGPR spills, 54 -> 45 KB of code).  The length
+   * of the sweep schedule stays a run-time value: as a literal it gets the sweeps unrolled, and 62 KB of code no longer
+   * sit in the 64 KB instruction cache two CUs share (config 4 fell from 13 M to 3.9 M steps/s) */
+  rkfdDevModel m = m_;
+  m.nlink = RKFD_SPEC_NLINK; m.ndof = RKFD_SPEC_NDOF; m.ncand = RKFD_SPEC_NCAND; m.nlink_model = RKFD_SPEC_NLINK_MODEL;
+  m.nlevel = RKFD_SPEC_NLEVEL; m.nround = RKFD_SPEC_NROUND; m.maxrg = RKFD_SPEC_MAXRG;
+  m.npool = RKFD_SPEC_NPOOL; m.nfloat = RKFD_SPEC_NFLOAT; m.maxact = RKFD_SPEC_MAXACT; m.nside = RKFD_SPEC_NSIDE;
+  m.npurow = RKFD_SPEC_NPUROW; m.pu_alias = RKFD_SPEC_PU_ALIAS; m.vert_rigid = RKFD_SPEC_VERT_RIGID; m.qscr_alias = RKFD_SPEC_QSCR_ALIAS;
+  m.has_slide = RKFD_SPEC_HAS_SLIDE; m.ma_size = RKFD_SPEC_MA_SIZE; m.ma_packed = RKFD_SPEC_MA_PACKED;
+  m.max_iter = RKFD_SPEC_MAX_ITER; m.solver = RKFD_SPEC_SOLVER; m.pyramid = RKFD_SPEC_PYRAMID; m.anchor = RKFD_SPEC_ANCHOR;
+#else
+  const rkfdDevModel &m = m_;
+#endif
   const int lane = LANE();
   const int ND = m.ndof, NL = m.nlink, NC = m.ncand;
   rkfdLds L;

@@ -1,5 +1,8 @@
 /* rkfd_capi.hip - C ABI (include/rkfd_hip.h) over the gfx950 kernel in rkfd_device.h. */
 #include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+#include <dlfcn.h>
+#include <string>
 #include <vector>
 #include <stdio.h>
 #include <stdlib.h>
@@ -50,6 +53,9 @@ struct rkfdBatch {
   int *d_err;
   size_t lds_bytes;
   rkfdKernel kern, kern_prof;
+  /* rkfdBatchSpecialize: the step kernel compiled for this world (hipRTC); NULL = the generic kernels above */
+  hipModule_t spec_mod;
+  hipFunction_t spec_fn;
   /* split launches (rkfdBatchSetSplit): the batch goes out as nsplit kernels on internal streams, so that the
    * tail of one step of one part overlaps the next step of another (the instances are independent) */
   int nsplit;
@@ -148,6 +154,7 @@ extern "C" void rkfdBatchDestroy(rkfdBatch *b)
     for( int k=0; k<RKFD_MAX_SPLIT; k++ ){ (void)hipStreamSynchronize( b->sub[k] ); (void)hipStreamDestroy( b->sub[k] ); (void)hipEventDestroy( b->done[k] ); }
   }
   if( b->tev ){ for( size_t i=0; i<b->tev->size(); i++ ) (void)hipEventDestroy( (*b->tev)[i] ); delete b->tev; }
+  if( b->spec_mod ) (void)hipModuleUnload( b->spec_mod );
   (void)hipFree( b->d_err ); (void)hipFree( b->dblob );
   rkfd_devmodel_free( &b->host );
   free( b );
@@ -296,6 +303,19 @@ static int sync_streams(rkfdBatch *b)
   b->pending = 0;
   return 0;
 }
+/* one kernel launch over `count` instances starting at `first`: the kernel compiled for this world when there is one */
+static int launch_one(rkfdBatch *b, rkfdKernel kern, int count, int first, int mode, int nsteps, hipStream_t stream)
+{
+  if( b->spec_fn && !b->st.prof ){
+    void *args[] = { &b->dm, &b->st, &first, &mode, &nsteps, &b->d_err };
+    HIPCHK( hipModuleLaunchKernel( b->spec_fn, count, 1, 1, RKFD_WAVE, 1, 1, (unsigned)b->lds_bytes, stream, args, NULL ), -1 );
+    return 0;
+  }
+  hipLaunchKernelGGL( kern, dim3( count ), dim3( RKFD_WAVE ), b->lds_bytes, stream, b->dm, b->st, first, mode, nsteps, b->d_err );
+  HIPCHK( hipGetLastError(), -1 );
+  return 0;
+}
+
 static int launch(rkfdBatch *b, int mode, int nsteps, void *stream)
 {
   if( !b ){ SETERR( "null batch" ); return -1; }
@@ -305,9 +325,7 @@ static int launch(rkfdBatch *b, int mode, int nsteps, void *stream)
     if( b->st.prof && sync_streams( b ) < 0 ) return -1;
     hipEvent_t e0 = NULL, e1 = NULL;
     if( b->timing && !b->st.prof && ( e0 = timing_event( b ) ) && ( e1 = timing_event( b ) ) ) HIPCHK( hipEventRecord( e0, (hipStream_t)stream ), -1 );
-    hipLaunchKernelGGL( kern, dim3( b->batch ), dim3( RKFD_WAVE ), b->lds_bytes, (hipStream_t)stream,
-                        b->dm, b->st, 0, mode, nsteps, b->d_err );
-    HIPCHK( hipGetLastError(), -1 );
+    if( launch_one( b, kern, b->batch, 0, mode, nsteps, (hipStream_t)stream ) < 0 ) return -1;
     if( e0 && e1 ) HIPCHK( hipEventRecord( e1, (hipStream_t)stream ), -1 );
     return 0;
   }
@@ -327,15 +345,109 @@ static int launch(rkfdBatch *b, int mode, int nsteps, void *stream)
       if( hi <= lo ) continue;
       hipEvent_t e0 = NULL, e1 = NULL;
       if( b->timing && ( e0 = timing_event( b ) ) && ( e1 = timing_event( b ) ) ) HIPCHK( hipEventRecord( e0, b->sub[k] ), -1 );
-      hipLaunchKernelGGL( kern, dim3( hi-lo ), dim3( RKFD_WAVE ), b->lds_bytes, b->sub[k],
-                          b->dm, b->st, lo, mode, per, b->d_err );
-      HIPCHK( hipGetLastError(), -1 );
+      if( launch_one( b, kern, hi-lo, lo, mode, per, b->sub[k] ) < 0 ) return -1;
       if( e0 && e1 ) HIPCHK( hipEventRecord( e1, b->sub[k] ), -1 );
     }
   for( int k=0; k<b->nsplit; k++ ) HIPCHK( hipEventRecord( b->done[k], b->sub[k] ), -1 );
   b->pending = 1;
   return 0;
 }
+/* ---- the step kernel compiled for one world (hipRTC) ---------------------------------------------------- */
+static std::string lib_dir(void)
+{
+  Dl_info di;
+  if( !dladdr( (const void *)&lib_dir, &di ) || !di.dli_fname ) return ".";
+  std::string p( di.dli_fname );
+  const size_t k = p.rfind( '/' );
+  return k == std::string::npos ? std::string( "." ) : p.substr( 0, k );
+}
+/* source of the specialised kernel: the dimensions of the world as literals in front of the same device code */
+static std::string spec_source(const rkfdDevModel &d)
+{
+  char buf[2048];
+  snprintf( buf, sizeof(buf),
+    "#define RKFD_SPEC 1\n"
+    "#define RKFD_SPEC_NLINK %d\n#define RKFD_SPEC_NDOF %d\n#define RKFD_SPEC_NCAND %d\n#define RKFD_SPEC_NLINK_MODEL %d\n"
+    "#define RKFD_SPEC_NLEVEL %d\n#define RKFD_SPEC_NROUND %d\n#define RKFD_SPEC_NSCHED %d\n#define RKFD_SPEC_MAXRG %d\n"
+    "#define RKFD_SPEC_NPOOL %d\n#define RKFD_SPEC_NFLOAT %d\n#define RKFD_SPEC_MAXACT %d\n#define RKFD_SPEC_NSIDE %d\n"
+    "#define RKFD_SPEC_NPUROW %d\n#define RKFD_SPEC_PU_ALIAS %d\n#define RKFD_SPEC_VERT_RIGID %d\n#define RKFD_SPEC_QSCR_ALIAS %d\n"
+    "#define RKFD_SPEC_HAS_SLIDE %d\n#define RKFD_SPEC_MA_SIZE %d\n#define RKFD_SPEC_MA_PACKED %d\n"
+    "#define RKFD_SPEC_MAX_ITER %d\n#define RKFD_SPEC_SOLVER %d\n#define RKFD_SPEC_PYRAMID %d\n#define RKFD_SPEC_ANCHOR %d\n"
+    "#include \"rkfd_device.h\"\n"
+    "extern \"C\" __global__ void __launch_bounds__(64, 3)\n"
+    "rkfd_step_kernel_spec(rkfdDevModel m, rkfdDevState st, int first, int mode, int nsteps, int *errflag)\n"
+    "{\n"
+    "  extern __shared__ __attribute__((aligned(16))) char lds[];\n"
+    "  const int b = first + (int)blockIdx.x;\n"
+    "  if( b >= st.batch ) return;\n"
+    "  rkfd_instance<false, %s, %s>( m, st, b, lds, mode, nsteps, errflag );\n"
+    "}\n",
+    d.nlink, d.ndof, d.ncand, d.nlink_model, d.nlevel, d.nround, d.nsched, d.maxrg, d.npool, d.nfloat, d.maxact, d.nside,
+    d.npurow, d.pu_alias, d.vert_rigid, d.qscr_alias, d.has_slide, d.ma_size, d.ma_packed, d.max_iter, d.solver, d.pyramid, d.anchor,
+    d.vert_rigid ? "true" : "false", d.ma_packed ? "true" : "false" );
+  return std::string( buf );
+}
+/* compile for gfx950; needs the device headers beside the library (csrc/) and include/ beside the package */
+static int spec_compile(const rkfdDevModel &d, std::vector<char> &code)
+{
+  const std::string src = spec_source( d ), dir = lib_dir();
+  if( const char *dump = getenv( "RKFD_SPEC_DUMP" ) ){ FILE *f = fopen( dump, "w" ); if( f ){ fputs( src.c_str(), f ); fclose( f ); } }   /* diagnostic */
+  const std::string i1 = "-I" + dir + "/csrc", i2 = "-I" + dir + "/../include";
+  const char *opts[] = { "--offload-arch=gfx950", "-O3", "-Wno-unused-value", "-mllvm", "-disable-machine-licm", i1.c_str(), i2.c_str() };
+  hiprtcProgram prog;
+  if( hiprtcCreateProgram( &prog, src.c_str(), "rkfd_step_kernel_spec.hip", 0, NULL, NULL ) != HIPRTC_SUCCESS ){ SETERR( "hiprtcCreateProgram failed" ); return -1; }
+  const hiprtcResult r = hiprtcCompileProgram( prog, (int)( sizeof(opts)/sizeof(opts[0]) ), opts );
+  if( r != HIPRTC_SUCCESS ){
+    size_t n = 0; hiprtcGetProgramLogSize( prog, &n );
+    std::string log( n ? n : 1, ' ' ); if( n ) hiprtcGetProgramLog( prog, &log[0] );
+    SETERR( "hipRTC: %s: %.400s", hiprtcGetErrorString( r ), log.c_str() );
+    hiprtcDestroyProgram( &prog );
+    return -1;
+  }
+  size_t n = 0;
+  hiprtcGetCodeSize( prog, &n ); code.resize( n ); hiprtcGetCode( prog, code.data() );
+  if( const char *dump = getenv( "RKFD_SPEC_DUMP_CODE" ) ){ FILE *f = fopen( dump, "wb" ); if( f ){ fwrite( code.data(), 1, n, f ); fclose( f ); } }   /* diagnostic */
+  hiprtcDestroyProgram( &prog );
+  return 0;
+}
+extern "C" int rkfdSpecializeCompile(const rkfdModel *m, int max_rigid)
+{
+  rkfdDevModelHost h;
+  char err[256];
+  if( !m || rkfd_devmodel_build( m, max_rigid, &h, err, sizeof(err) ) < 0 ){ SETERR( "rkfdSpecializeCompile: %s", m ? err : "null model" ); return -1; }
+  std::vector<char> code;
+  const int r = spec_compile( h.dm, code );
+  rkfd_devmodel_free( &h );
+  return r < 0 ? -1 : (int)code.size();
+}
+extern "C" int rkfdBatchSpecialize(rkfdBatch *b)
+{
+  if( !b ){ SETERR( "null batch" ); return -1; }
+  if( b->spec_fn ) return 0;
+  if( b->lds_bytes > 64*1024 ){ SETERR( "rkfdBatchSpecialize: worlds above 64 KiB of LDS per instance keep the generic kernel" ); return -1; }
+  HIPCHK( hipSetDevice( b->device ), -1 );
+  if( sync_streams( b ) < 0 ) return -1;
+  std::vector<char> code;
+  if( spec_compile( b->dm, code ) < 0 ) return -1;
+  HIPCHK( hipModuleLoadData( &b->spec_mod, code.data() ), -1 );
+  HIPCHK( hipModuleGetFunction( &b->spec_fn, b->spec_mod, "rkfd_step_kernel_spec" ), -1 );
+  {
+    /* the compiler behind hipRTC is whichever libamd_comgr the process loaded first; a framework that bundles an older
+     * one (PyTorch does) gives a kernel that spills (437 VGPR spills, 3.9 M instead of 14 M steps/s on config 4): refuse it */
+    int regs = -1, scratch = -1;
+    hipFuncGetAttribute( &regs, HIP_FUNC_ATTRIBUTE_NUM_REGS, b->spec_fn );
+    hipFuncGetAttribute( &scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, b->spec_fn );
+    if( getenv( "RKFD_SPEC_DEBUG" ) ) fprintf( stderr, "rkfdBatchSpecialize: %d VGPRs, %d bytes of scratch per lane, %zu bytes of LDS\n", regs, scratch, b->lds_bytes );
+    if( scratch > 64 ){
+      (void)hipModuleUnload( b->spec_mod ); b->spec_mod = NULL; b->spec_fn = NULL;
+      SETERR( "rkfdBatchSpecialize: the compiler hipRTC resolved to in this process produced a spilling kernel (%d VGPRs, %d bytes of scratch per lane); "
+              "load /opt/rocm/lib/libamd_comgr.so.3 before libraries that bundle their own (see bench.py); the generic kernel stays in use", regs, scratch );
+      return -1;
+    }
+  }
+  return 0;
+}
+
 extern "C" int rkfdBatchSetSplit(rkfdBatch *b, int nsplit)
 {
   if( !b || nsplit < 1 || nsplit > RKFD_MAX_SPLIT ){ SETERR( "rkfdBatchSetSplit: 1 <= nsplit <= %d", RKFD_MAX_SPLIT ); return -1; }

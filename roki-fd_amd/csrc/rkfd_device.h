@@ -22,7 +22,12 @@
 #ifndef RKFD_DEVICE_H
 #define RKFD_DEVICE_H
 
+#ifndef __HIPCC_RTC__
 #include <math.h>
+#endif
+#ifndef HUGE_VAL            /* (hipRTC has no system headers) */
+#define HUGE_VAL __builtin_huge_val()
+#endif
 #include "rkfd_model.h"
 #include "rkfd_devmodel.h"
 

@@ -426,3 +426,22 @@ def test_residency_report_follows_the_lds_allocation_pieces(R):
         b = R.Batch(sc["world"], 8, max_rigid=sc["max_rigid"])
         pieces = -(-b.lds_bytes // 1280)
         assert b.residency() == min(12, 128 // pieces) == expect, (name, b.lds_bytes, b.residency())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["config2", "config3", "config4", "config4v", "config5"])
+def test_specialized_kernel_gives_the_same_results(R, cfg):
+    """rkfdBatchSpecialize: the step kernel compiled for the world (hipRTC, its dimensions as literals) against the
+    generic kernel - states, contact state and pivots bit for bit, every kernel variant (PGS full / packed, Vert QP)"""
+    sc = R.scenarios.CONFIGS[cfg](batch=64)
+    out = []
+    for spec in (False, True):
+        b = R.Batch(sc["world"], 64, max_rigid=sc["max_rigid"])
+        if spec:
+            b.specialize()
+        b.set_state(sc["dis"], sc["vel"]); b.update_init()
+        b.update(20); b.set_split(3); b.update(10)
+        assert b.status() == 0
+        out.append(b.get_state() + b.get_contact() + b.get_pivot())
+    for x, y in zip(out[0], out[1]):
+        assert np.array_equal(x, y)

@@ -90,3 +90,11 @@ def test_reader_loads_the_reference_shipped_models(R):
     for f in ("arm.ztk", "dualarm.ztk", "wall.ztk"):
         with pytest.raises(R.RkfdError):
             R.World().reg_file(os.path.join(REF_MODELS, f))
+
+
+def test_specialized_step_kernel_compiles_without_a_gpu(R):
+    """rkfdSpecializeCompile: the hipRTC source of the world-specific step kernel (the world's dimensions as literals
+    in front of csrc/rkfd_device.h) compiles for gfx950 - no device needed for the compile step"""
+    sc = R.scenarios.config4(batch=2)
+    n = R.lib().rkfdSpecializeCompile(sc["world"].model, sc["max_rigid"])
+    assert n > 10000, R.lib().rkfdHipLastError().decode()
