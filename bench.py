@@ -217,7 +217,8 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": sc["name"], "instances_per_gpu": Bn, "ndof": m.ndof, "nlink": m.nlink,
-                       "parallelism": f"instances sharded over {world} GPU(s), no data-path collective; {args.split} launches per step on internal streams"},
+                       "parallelism": f"instances sharded over {world} GPU(s), no data-path collective; {args.split} launches per step on internal streams",
+                       "step_kernel": "compiled for this world (rkfdBatchSpecialize)" if specialized else "generic"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload, per_launch),
                          "kernel": "rkfd_step_kernel_spec" if specialized else "rkfd_step_kernel", "kernel_ms": kernel_ms, "alg_bytes_per_instance_step": alg,
