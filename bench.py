@@ -13,6 +13,8 @@ part's step overlaps the next step of another part (+25 % at 4096 instances per 
 `roofline.kernel_ms` is the average duration of ONE launch (HIP events on the stream it runs on),
 `roofline.achieved` the algorithmic bytes of one launch over that duration; the launches of a step
 overlap, `achieved_all_launches_of_a_step` relates the whole step's bytes to the step's duration.
+The step kernel is compiled for the workload's world before the timing starts (rkfdBatchSpecialize, hipRTC, about 2 s;
+--no-specialize keeps the library's generic kernel; same results either way).  --fuse N sends N steps per call.
 Prints ONE JSON line on rank 0.
 """
 import argparse
