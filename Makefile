@@ -10,7 +10,8 @@ BUILD    = $(PKG)/build
 INC      = -Iinclude -I$(CSRC) -I$(CSRC)/host
 CFLAGS   = -O2 -Wall -fPIC $(INC)
 # machine LICM off: hoisted literals / addresses held across the step loop cost ~35 VGPRs and the third wave per SIMD
-HIPFLAGS = --offload-arch=$(ARCH) -O3 -fPIC $(INC) -Wno-unused-value -mllvm -disable-machine-licm
+ROCM_LIBDIR ?= $(abspath $(dir $(realpath $(HIPCC)))/../lib)
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -fPIC $(INC) -Wno-unused-value -mllvm -disable-machine-licm -DRKFD_ROCM_LIBDIR='"$(ROCM_LIBDIR)"'
 
 HOST_OBJS = $(BUILD)/rkfd_ztk.o $(BUILD)/rkfd_world.o $(BUILD)/rkfd_sim.o $(BUILD)/rkfd_devmodel.o
 LIB = $(PKG)/librkfd_amd.so
@@ -34,7 +35,7 @@ $(BUILD)/rkfd_capi.o: $(CSRC)/rkfd_capi.hip $(CSRC)/*.h $(CSRC)/device/*.h inclu
 	@grep -vE "remark:|^ +[0-9]+ \||^ +\||\^" $(BUILD)/rkfd_capi.remarks || true
 
 $(LIB): $(HOST_OBJS) $(BUILD)/rkfd_capi.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm -lhiprtc -ldl
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm -ldl -lpthread
 
 oracle:
 	$(MAKE) -C oracle

@@ -1,89 +1,128 @@
 #!/usr/bin/env python3
 """bench.py - sim-steps/sec of the batched rkFDUpdate hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W [--workload config4|config3|config2] [--batch B]
+  python bench.py --gpus N --steps K --warmup W [--workload config4|config3|config2|config5|config4v] [--batch B]
 
-A "step" is one rkFDUpdate (4 RKG stage evaluations + the committing evaluation) of every
-instance of the batch; state stays resident in HBM between steps.  One process per GPU; for
-N>1 the driver launches this file under torch.distributed.run and every rank simulates its
-own shard of instances (no data-path collective; one RCCL all-gather of the final states).
-A step goes out as --split (default 3) launches of the step kernel over contiguous parts of the
-batch on internal HIP streams: the instances are independent, so the thinly occupied tail of one
-part's step overlaps the next step of another part (+25 % at 4096 instances per GPU).
+A "step" is one rkFDUpdate (4 RKG stage evaluations + the committing evaluation) of every instance of the
+batch; state stays resident in HBM between steps.
+
+The workload is MPC-style rollouts (BASELINE.json north_star): every instance starts from its own standing
+state (flat soles seated in the floor, all 8 sole vertices in rigid contact), is simulated for --horizon
+steps (default 25), is put back to its start state by a device-side copy (rkfdBatchRestore, inside the timed
+region) and simulated again.  Why a horizon: under the reference's algorithm (PGS with 10 sweeps and no warm
+start + the K = 1000 deadbeat penetration compensation) a stiff body resting on more than three coplanar
+vertices does not stay there - a 4-step chatter builds up and after 30-40 steps the robot rocks on 3-4
+vertices (DESIGN.md "Scenario note", measured with the CPU oracle).  The horizon keeps the timed steps on
+the contact problem the configuration names (Nc ~ 8 => a 24x24 MLCP); the JSON line reports what was really
+solved: config.mean_rigid_contacts is read back from the device for exactly the timed steps, and the
+algorithmic bytes are computed from it.  --horizon 0 runs one continuous trajectory instead (the rocking
+regime, ~3.5 contacts; reported in DESIGN.md beside the headline).
+
+--steps K is the block that is timed; the block is repeated until the timed region lasts --min-seconds
+(default 1 s) so that the figure does not depend on a 4 ms measurement; ms_per_step and value are averages
+over all timed steps (config.timed_steps), the rollout boundaries continue across blocks.
+
+One process per GPU; for N>1 the driver launches this file under torch.distributed.run and every rank
+simulates its own shard of instances (no data-path collective; one RCCL all-gather of the final states).
+Started by hand with --gpus N > 1 and no WORLD_SIZE, it spawns torch.distributed.run itself (as a child
+process, before anything touches the GPU) and relays rank 0's line.
+A step goes out as --split (default 3) launches of the step kernel over contiguous parts of the batch on
+internal HIP streams: the instances are independent, so the thinly occupied tail of one part's step overlaps
+the next step of another (+25 % at 4096 instances per GPU).
 `roofline.kernel_ms` is the average duration of ONE launch (HIP events on the stream it runs on),
-`roofline.achieved` the algorithmic bytes of one launch over that duration; the launches of a step
-overlap, `achieved_all_launches_of_a_step` relates the whole step's bytes to the step's duration.
-The step kernel is compiled for the workload's world before the timing starts (rkfdBatchSpecialize, hipRTC, about 2 s;
---no-specialize keeps the library's generic kernel; same results either way).  --fuse N sends N steps per call.
+`roofline.achieved` the algorithmic bytes of one launch over that duration; the launches of a step overlap,
+`achieved_all_launches_of_a_step` relates the whole step's bytes to the step's duration.
+The step kernel is compiled for the workload's world before the timing starts (rkfdBatchSpecialize, about
+2 s; --no-specialize keeps the library's generic kernel; same results either way).
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALG_BYTES = {  # algorithmic HBM bytes per instance-step (SURVEY.md 8d / DESIGN.md)
-    "config2": lambda m: 8 * 6 * m.ndof,
-    "config3": lambda m: 8 * 6 * m.ndof + 8 * 80 + 24 * 24,
-    "config4": lambda m: 8 * 6 * m.ndof + 8 * 80 + 24 * 24,
-    "config4v": lambda m: 8 * 6 * m.ndof + 8 * 80 + 24 * 24,
-    "config5": lambda m: 8 * 6 * m.ndof + 24 * 80 + 24 * 24,
-    "config3_26": lambda m: 8 * 6 * m.ndof + 8 * 80 + 20 * 24,
-    "config4_26": lambda m: 8 * 6 * m.ndof + 8 * 80 + 20 * 24,
-}
 HBM_PEAK_GBS = 8000.0
+PROFILE_TAG = "r02"
 
 
-def measured_traffic(workload, batch):
-    """HBM bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in
-    separate runs by tools/collect_traffic.sh and corrected as MI355X_MICROARCH.md prescribes);
-    None when no measurement for this workload/batch is on file."""
-    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+def alg_bytes(m, mean_contacts, R):
+    """algorithmic HBM bytes per instance-step: read dis, vel, u and write dis, vel, acc (8*6n);
+    per contact vertex in contact r/w {type, _ref} and write f (80); per friction-pivot DoF r/w {type, prev_trq} (24).
+    The contact count is the MEASURED mean over the timed steps."""
+    jt = m.arr("jtype", m.nlink); mt = m.arr("mtype", m.nlink)
+    n_fric = int(((jt == R.binding.JOINT_REVOL) | (jt == R.binding.JOINT_PRISM))[mt == 2].sum())
+    return 8 * 6 * m.ndof + 80.0 * mean_contacts + 24 * n_fric, n_fric
+
+
+def measured_traffic(workload, per_launch):
+    """HBM bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in separate runs by
+    tools/collect_traffic.sh and corrected as MI355X_MICROARCH.md prescribes); None when no measurement for
+    this workload / launch size is on file."""
     try:
-        with open(path) as fp:
+        with open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_hbm_traffic.json")) as fp:
             rec = json.load(fp).get(workload)
-        if rec and rec.get("batch") == batch:
+        if rec and rec.get("batch") == per_launch:
             return rec["hbm_bytes_per_launch"]
     except (OSError, ValueError):
         pass
     return None
 
 
-def counted_flops(workload):
-    """algorithmic flops per instance-step from the flop-counting build of the oracle
-    (tools/count_flops.py -> profiles/r01_flops.json); None when not on file"""
+def counted_flops(workload, horizon):
+    """algorithmic flops per instance-step from the flop-counting build of the oracle, counted over the same
+    rollout window (tools/count_flops.py -> profiles/r02_flops.json); None when not on file"""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_flops.json")) as fp:
-            return json.load(fp)[workload]["flops_per_instance_step"]
+        with open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_flops.json")) as fp:
+            rec = json.load(fp)[workload]
+        return rec["flops_per_instance_step"] if rec.get("horizon") == horizon else None
     except (OSError, ValueError, KeyError):
         return None
 
 
-def cpu_baseline(R, name, seconds=10.0):
-    """the oracle (CPU restatement, 'port') timed on one host core on a bounded sample"""
-    import numpy as np
+def _oracle_rollouts(Oracle, sc, inst, horizon, deadline, block=None):
+    """one oracle instance doing the bench's workload: rollouts of `horizon` steps from its start state
+    (horizon 0: one trajectory in blocks of 200 steps) until the deadline; returns the steps done"""
+    o = Oracle(sc["world"].model)
+    n = 0
+    if horizon > 0:
+        while time.perf_counter() < deadline:
+            o.set_state(sc["dis"][inst], sc["vel"][inst])
+            o.reset_contact()
+            o.update_init()
+            o.update_n(horizon)
+            n += horizon
+    else:
+        o.set_state(sc["dis"][inst], sc["vel"][inst])
+        o.update_init()
+        while time.perf_counter() < deadline and n < 1000:
+            o.update_n(200); n += 200
+    o.close()
+    return n
+
+
+def cpu_baseline(R, name, horizon, seconds=10.0):
+    """the oracle (CPU restatement, 'port') timed on one host core on a bounded sample of the SAME workload:
+    rollouts of `horizon` steps from the same standing states"""
     from oracle.pyoracle import Oracle
     sc = R.scenarios.CONFIGS[name](batch=4)
-    nsteps = 0
+    nsteps = 0; inst = 0
     t0 = time.perf_counter()
-    inst = 0
     while time.perf_counter() - t0 < seconds:
-        o = Oracle(sc["world"].model)
-        o.set_state(sc["dis"][inst % 4], sc["vel"][inst % 4])
-        o.update_init()
-        o.update_n(200)
-        nsteps += 200
+        nsteps += _oracle_rollouts(Oracle, sc, inst % 4, horizon, min(t0 + seconds, time.perf_counter() + 2.0))
         inst += 1
     dt = time.perf_counter() - t0
+    what = f"rollouts of {horizon} steps from the standing states" if horizon > 0 else "trajectories of up to 1000 steps"
     return dict(value=nsteps / dt, unit="sim-steps/sec", cores=1, kind="port",
-                sample=f"{inst} instances x 200 steps of {name}, sequential on 1 core (oracle/rkfd_oracle.c, gcc -O3 -funroll-loops)")
+                sample=f"{nsteps} steps of {name} ({what}, 4 distinct instances), sequential on 1 core "
+                       f"(oracle/rkfd_oracle.c, gcc -O3 -funroll-loops)")
 
 
-def cpu_baseline_all_cores(R, name, seconds=8.0):
+def cpu_baseline_all_cores(R, name, horizon, seconds=8.0):
     """the same oracle on every host core this process may use: one OS thread per core over disjoint
     instances (the reference itself is single-threaded; this is the generous baseline).
     ctypes releases the GIL inside the C calls and the oracle keeps no global state."""
@@ -97,11 +136,7 @@ def cpu_baseline_all_cores(R, name, seconds=8.0):
     def work(k):
         inst = k
         while time.perf_counter() - t0 < seconds:
-            o = Oracle(sc["world"].model)
-            o.set_state(sc["dis"][inst % 4], sc["vel"][inst % 4])
-            o.update_init()
-            o.update_n(200)
-            done[k] += 200
+            done[k] += _oracle_rollouts(Oracle, sc, inst % 4, horizon, min(t0 + seconds, time.perf_counter() + 2.0))
             inst += cores
 
     th = [threading.Thread(target=work, args=(k,)) for k in range(cores)]
@@ -111,7 +146,20 @@ def cpu_baseline_all_cores(R, name, seconds=8.0):
         t.join()
     dt = time.perf_counter() - t0
     return dict(value=sum(done) / dt, unit="sim-steps/sec", cores=cores, kind="port",
-                sample=f"{sum(done) // 200} instances x 200 steps of {name}, one thread per core on {cores} cores")
+                sample=f"{sum(done)} steps of {name}, same rollouts, one thread per core on {cores} cores")
+
+
+def spawn_ranks(args):
+    """python bench.py --gpus N (N > 1) by hand: start torch.distributed.run as a CHILD process - this process has not
+    touched the GPU - and relay its output; exit with its code"""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    env = dict(os.environ, RKFD_BENCH_SPAWNED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -121,22 +169,23 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="config4")
     ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
+    ap.add_argument("--horizon", type=int, default=25, help="steps per rollout before the instances are put back to their start states "
+                    "(device-side copy, timed); 0: one continuous trajectory")
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the --steps block until the timed region lasts this long")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--fuse", type=int, default=1, help="steps per rkfdBatchUpdate call (must divide --steps).  1: a launch round per step.  "
-                    "Worlds under the Vert plugin run the steps of a call fused in one kernel per part: the QP makes step times "
-                    "vary widely between instances, and without a per-step barrier the variation averages out (config4v: 2.4 M -> 3.6 M steps/s)")
+    ap.add_argument("--fuse", type=int, default=0, help="steps per rkfdBatchUpdate call (0: up to the end of the rollout / block).  Under split "
+                    "launches a call of n steps goes out as n rounds of one-step launches, except for worlds under the Vert plugin, whose steps "
+                    "run fused in one kernel per part: the QP makes step times vary widely between instances, and without a per-step barrier "
+                    "the variation averages out")
     ap.add_argument("--no-specialize", action="store_true", help="keep the generic step kernel instead of compiling it for the "
-                    "workload's world (rkfdBatchSpecialize, hipRTC: same results, the world's dimensions as literals)")
-    ap.add_argument("--split", type=int, default=3, help="launch each step as this many kernels over parts of the batch on internal HIP streams (1..8): the instances are independent, so the tail of one part's step overlaps the next step of another")
+                    "workload's world (rkfdBatchSpecialize: same results, the world's dimensions as literals)")
+    ap.add_argument("--split", type=int, default=3, help="launch each step as this many kernels over parts of the batch on internal HIP streams (1..8)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
+
     import numpy as np
-    if not args.no_specialize and os.path.exists("/opt/rocm/lib/libamd_comgr.so.3") and not os.environ.get("RKFD_BENCH_NO_COMGR_PRELOAD"):
-        # rkfdBatchSpecialize compiles through hipRTC -> comgr.  PyTorch bundles an older comgr under the same soname, and
-        # whichever is loaded first serves the whole process: with the bundled one the specialised kernel spills (437
-        # VGPR spills, 3.9 M steps/s instead of 13.9 M).  Load the image's ROCm 7.2 compiler library before torch.
-        import ctypes
-        ctypes.CDLL("/opt/rocm/lib/libamd_comgr.so.3", mode=ctypes.RTLD_GLOBAL)
     import torch
     import rkfd_pkg
     R = rkfd_pkg.load()
@@ -144,6 +193,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: measuring {world} GPU(s)", file=sys.stderr)
     dist = None
     if world > 1 or "RANK" in os.environ:     # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
@@ -153,9 +204,9 @@ def main():
 
     Bn = args.batch
     total = Bn * world                       # weak scaling: per-GPU work is fixed
-    sc = R.scenarios.CONFIGS[args.workload](batch=total)
     lo, hi = R.sharding.shard_range(rank, world, total)
-    sl = slice(lo, hi)
+    assert hi - lo == Bn
+    sc = R.scenarios.CONFIGS[args.workload](batch=Bn, first=lo)      # this rank's shard only (the seeded stream is index-addressable)
     b = R.Batch(sc["world"], Bn, device=local, max_rigid=sc["max_rigid"])
     specialized = False
     if not args.no_specialize and b.lds_bytes <= 64 * 1024:
@@ -164,14 +215,27 @@ def main():
             specialized = True
         except R.RkfdError as e:              # an optimisation, not a correctness path: say so and keep the generic kernel
             print("bench.py: %s" % e, file=sys.stderr)
-    b.set_state(sc["dis"][sl], sc["vel"][sl])
+    b.set_state(sc["dis"], sc["vel"])
     b.set_split(args.split)
     stream = torch.cuda.current_stream().cuda_stream
     b.update_init(stream)
-    for _ in range(args.warmup):
-        b.update(1, stream)
     assert b.status(stream) == 0
-    b.time_launches(True)                     # HIP events around every kernel launch, on the stream it runs on
+    H = args.horizon
+    if H > 0:
+        b.snapshot()                          # the rollouts' start: standing state + rkFDUpdateInit's committing evaluation
+
+    pos = [0]                                 # steps since the last restore
+
+    def run_steps(n):
+        """n steps of the workload: rollouts of H steps, the state put back in between (device-side, stream-ordered)"""
+        while n > 0:
+            if H > 0 and pos[0] == H:
+                b.restore(stream); pos[0] = 0
+            k = n if H <= 0 else min(n, H - pos[0])
+            if args.fuse > 0:
+                k = min(k, args.fuse)
+            b.update(k, stream)
+            pos[0] += k; n -= k
 
     def barrier():
         torch.cuda.synchronize()
@@ -179,23 +243,45 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    run_steps(args.warmup)
+    assert b.status(stream) == 0
+    # how many blocks make --min-seconds: one untimed block, the slowest rank decides
+    barrier()
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    b.join(stream)
+    barrier()
+    t_block = time.perf_counter() - t0
+    reps = max(1, int(np.ceil(args.min_seconds / max(t_block, 1e-6))))
+    if dist is not None:
+        t = torch.tensor([reps], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        reps = int(t.item())
+    timed_steps = reps * args.steps
+    # the timed steps must see the same mix of rollout phases whatever --steps is: start them at a rollout boundary
+    if H > 0:
+        run_steps(H - pos[0])
+    b.contact_stats(reset=True)
+    b.time_launches(True)                     # HIP events around every kernel launch, on the stream it runs on
+
     ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
     barrier()
     t0 = time.perf_counter()
     ev0.record()
-    assert args.steps % args.fuse == 0, "--fuse must divide --steps"
-    for _ in range(args.steps // args.fuse):
-        b.update(args.fuse, stream)
+    for _ in range(reps):
+        run_steps(args.steps)
     b.join(stream)                            # the current stream waits for the parts (no host sync)
     ev1.record()
     barrier()
     t1 = time.perf_counter()
     st = b.status(stream)
     elapsed = t1 - t0
-    step_ms = ev0.elapsed_time(ev1) / args.steps
+    step_ms = ev0.elapsed_time(ev1) / timed_steps
     nlaunch, launch_ms = b.launch_timing()
-    assert nlaunch > 0 and ( args.steps * args.split ) % nlaunch == 0, (nlaunch, args.steps, args.split)
+    assert nlaunch > 0
     kernel_ms = launch_ms / nlaunch           # average duration of one launch of the step kernel
+    mean_rg, mean_el, counted = b.contact_stats()
+    assert counted == Bn * timed_steps, (counted, Bn, timed_steps)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -209,35 +295,46 @@ def main():
 
     if rank == 0:
         m = sc["world"].model.contents
-        alg = ALG_BYTES.get(args.workload, ALG_BYTES["config4"])(m)
+        has_contacts = m.ncand > 0
+        if args.workload in ("config4", "config5", "config4v", "config4_26"):
+            assert mean_rg > 0, "the timed region solved no rigid contact: the workload is not the one it names"
+        alg, n_fric = alg_bytes(m, mean_rg + mean_el, R)
+        steps_per_launch = 1 if (args.split > 1 and not (args.workload == "config4v")) else None
         per_launch = Bn // args.split          # instances one launch processes
-        achieved = alg * per_launch / (kernel_ms * 1e-3) / 1e9
+        launches_per_step = nlaunch / timed_steps
+        spl = args.split / launches_per_step   # steps one launch carries
+        achieved = alg * per_launch * spl / (kernel_ms * 1e-3) / 1e9
         res = {
             "metric": "sim-steps/sec (node), 30-DoF humanoid + ground contact, batch=4096",
-            "value": Bn * world * args.steps / elapsed, "unit": "sim-steps/sec",
+            "value": Bn * world * timed_steps / elapsed, "unit": "sim-steps/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / timed_steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": sc["name"], "instances_per_gpu": Bn, "ndof": m.ndof, "nlink": m.nlink,
+            "config": {"workload": sc["name"] + (f", MPC-style rollouts of {H} steps from the standing states" if H > 0 else ", one continuous trajectory"),
+                       "instances_per_gpu": Bn, "ndof": m.ndof, "nlink": m.nlink,
+                       "rollout_horizon": H, "timed_steps": timed_steps, "blocks": reps,
+                       "mean_rigid_contacts": mean_rg if has_contacts else 0.0, "mean_elastic_contacts": mean_el if has_contacts else 0.0,
                        "parallelism": f"instances sharded over {world} GPU(s), no data-path collective; {args.split} launches per step on internal streams",
                        "step_kernel": "compiled for this world (rkfdBatchSpecialize)" if specialized else "generic"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload, per_launch),
-                         "kernel": "rkfd_step_kernel_spec" if specialized else "rkfd_step_kernel", "kernel_ms": kernel_ms, "alg_bytes_per_instance_step": alg,
-                         "instances_per_launch": per_launch, "launches_per_step": nlaunch / args.steps, "steps_per_launch": args.steps * args.split // nlaunch, "step_ms_hip_events": step_ms,
+                         "kernel": "rkfd_step_kernel_spec" if specialized else "rkfd_step_kernel", "kernel_ms": kernel_ms,
+                         "alg_bytes_per_instance_step": alg, "friction_pivot_dofs": n_fric,
+                         "instances_per_launch": per_launch, "launches_per_step": launches_per_step, "steps_per_launch": spl, "step_ms_hip_events": step_ms,
                          "lds_bytes_per_instance": b.lds_bytes, "resident_instances_per_cu": b.residency(),
                          "achieved_all_launches_of_a_step": alg * Bn / (step_ms * 1e-3) / 1e9},
             "device_status": st,
         }
-        fl = counted_flops(args.workload)
+        del steps_per_launch
+        fl = counted_flops(args.workload, H)
         if fl is not None:
             # second axis SURVEY 8d asks for: fp64 vector throughput (dense peak 78.6 TFLOP/s, MI355X_MICROARCH.md)
             tf = fl * Bn / (step_ms * 1e-3) / 1e12      # whole step: the launches of one step overlap
             res["roofline_valu"] = {"bound": "valu_fp64", "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6,
                                     "alg_flops_per_instance_step": fl}
         if world == 1 and not args.no_cpu_baseline:      # the CPU baseline is a single-GPU-run figure (rank 0, N = 1)
-            res["cpu_baseline"] = cpu_baseline(R, args.workload)
-            res["cpu_baseline_all_cores"] = cpu_baseline_all_cores(R, args.workload)
+            res["cpu_baseline"] = cpu_baseline(R, args.workload, H)
+            res["cpu_baseline_all_cores"] = cpu_baseline_all_cores(R, args.workload, H)
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

@@ -89,9 +89,27 @@ int rkfdBatchLaunchTiming(rkfdBatch *b, int *launches, double *total_ms);
 
 /* waits for the stream-ordered work, then reports device-side conditions:
  * 0 ok, 1 rigid contact met without a rigid solver set up (Volume plugin, or max_rigid = 0),
- * 2 rigid-contact capacity exceeded, 3 the Vert plugin's QP ran out of iterations (256) or of
- * basis history (64); negative: HIP error */
+ * 2 contact capacity exceeded - more rigid contact vertices than max_rigid, or more rigid + elastic contact
+ * vertices than the active-contact slots (max_rigid when the world has no elastic pairs, else max(max_rigid, 16)
+ * capped by the candidate count); the vertices beyond the capacity were dropped -, 3 the Vert plugin's QP ran
+ * out of iterations (256) or of basis history (64); negative: HIP error.  rkfdHipLastError() describes a
+ * non-zero status.  A condition is reported ONCE: the call clears the device-side flag, so the next status tells
+ * what happened after this one (when several conditions occurred since the last call, the last one written wins). */
 int rkfdBatchStatus(rkfdBatch *b, void *stream);
+
+/* Mean number of rigid / elastic contact vertices per instance at the committing evaluation of the rkFDUpdate
+ * steps run since the last reset (the length of the plugin's vertex lists, reference src/rkfd_mlcp.c:327-345,
+ * src/rkfd_vert.c:380-392), and the number of instance-steps counted.  Measurement aid: tells what contact
+ * problem a timed region really solved.  Synchronises the device.  Any output may be NULL. */
+int rkfdBatchContactStats(rkfdBatch *b, int reset, double *mean_rigid, double *mean_elastic, long long *instance_steps);
+
+/* MPC-style rollouts: rkfdBatchSnapshot keeps a device-resident copy of the whole per-instance state (joint
+ * state, accelerations, friction pivots, contact-vertex state and forces; synchronous), rkfdBatchRestore puts it
+ * back in stream order (one small copy kernel per part, no host traffic) - the start of the next rollout from the
+ * same states.  The reference has no counterpart: a caller would re-run rkFDChainSetDis / SetVel per instance
+ * (reference src/rkfd_sim.c:277-287) and rkFDUpdateInit. */
+int rkfdBatchSnapshot(rkfdBatch *b);
+int rkfdBatchRestore(rkfdBatch *b, void *stream);
 
 /* diagnostic launch: nsteps x rkFDUpdate with in-kernel phase stamps.  out is [batch][32]
   * (RKFD_NPROF = 32 per instance) shader-clock cycles: kinematics, collision+penalty, sweep 2, sweep 3 (both

@@ -97,6 +97,11 @@ class Oracle:
         ref = np.ascontiguousarray(ref, dtype=np.float64)
         self._L.rkfdOracleSetContact(self._o, _p(act), _p(typ), _p(ref))
 
+    def reset_contact(self):
+        """forget all contact-vertex and friction-pivot state (a fresh world at the state set next)"""
+        self.set_contact(np.zeros(self.ncand, dtype=np.int32), np.zeros(self.ncand, dtype=np.int32), np.zeros((self.ncand, 3)))
+        self.set_pivot(np.zeros(self.nlink, dtype=np.int32), np.zeros(self.nlink))
+
     def get_pivot(self):
         typ = np.empty(self.nlink, dtype=np.int32); prev = np.empty(self.nlink)
         self._L.rkfdOracleGetPivot(self._o, _p(typ), _p(prev))

@@ -95,6 +95,8 @@ def lib():
     L.rkfdBatchEval.argtypes = [vp, C.c_int, vp]
     L.rkfdLdsBytesFor.argtypes = [C.POINTER(RkfdModel), C.c_int]
     L.rkfdBatchStatus.argtypes = [vp, vp]
+    L.rkfdBatchContactStats.argtypes = [vp, C.c_int, _pd, _pd, C.POINTER(C.c_longlong)]
+    L.rkfdBatchSnapshot.argtypes = [vp]; L.rkfdBatchRestore.argtypes = [vp, vp]
     L.rkfdBatchProfile.argtypes = [vp, C.c_int, vp]
     L.rkfdBatchSetSplit.argtypes = [vp, C.c_int]; L.rkfdBatchJoin.argtypes = [vp, vp]
     L.rkfdBatchTimeLaunches.argtypes = [vp, C.c_int]; L.rkfdBatchLaunchTiming.argtypes = [vp, vp, vp]
@@ -255,6 +257,20 @@ class Batch:
         if r < 0:
             raise RkfdError(self._L.rkfdHipLastError().decode())
         return r
+
+    def contact_stats(self, reset=False):
+        """(mean rigid, mean elastic contact vertices per instance-step, instance-steps counted) since the last reset"""
+        rg = C.c_double(); el = C.c_double(); n = C.c_longlong()
+        self._chk(self._L.rkfdBatchContactStats(self._b, int(bool(reset)), C.byref(rg), C.byref(el), C.byref(n)))
+        return rg.value, el.value, n.value
+
+    def snapshot(self):
+        """keep a device-resident copy of the whole state (start of MPC-style rollouts)"""
+        self._chk(self._L.rkfdBatchSnapshot(self._b))
+
+    def restore(self, stream=None):
+        """put the snapshot back, in stream order (no host traffic)"""
+        self._chk(self._L.rkfdBatchRestore(self._b, C.c_void_p(stream or 0)))
 
     def set_split(self, nsplit):
         """rkfdBatchSetSplit: launch the batch as nsplit kernels on internal streams (tails overlap)"""

@@ -403,5 +403,8 @@ typedef struct { double min, pivp; int pivt; } rkfdLaneLink;
 #define CNT_OVF 2
 #define CNT_QPF 3
 #define CNT_NTGT 4      /* (worlds with contact candidates only: four counters otherwise) */
+#define CNT_SRG 5       /* running sums over the committing evaluations of this launch's steps: rigid contacts, */
+#define CNT_SEL 6       /* elastic contacts, */
+#define CNT_SN  7       /* steps (rkfdBatchContactStats) */
 
 #endif /* RKFD_DEV_BASE_H */

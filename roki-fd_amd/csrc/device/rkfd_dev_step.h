@@ -122,7 +122,10 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDev
   const int ND = m.ndof, NL = m.nlink, NC = m.ncand;
   rkfdLds L;
   rkfd_lds_carve( &L, ldsbase, NL, ND, NC, 3*m.maxrg, m.nlevel, m.npool, m.nfloat, m.maxact, m.nside, m.pu_alias, m.npurow, m.vert_rigid, m.has_slide, m.ma_size );
-  if( lane == 0 ){ L.cnt[CNT_OVF] = 0; L.cnt[CNT_QPF] = 0; }
+  if( lane == 0 ){
+    L.cnt[CNT_OVF] = 0; L.cnt[CNT_QPF] = 0;
+    if( NC > 0 ){ L.cnt[CNT_SRG] = 0; L.cnt[CNT_SEL] = 0; L.cnt[CNT_SN] = 0; }
+  }
 
   /* load persistent state */
   double q = 0, qd = 0;
@@ -204,6 +207,9 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDev
       SYNC();
       const bool doUp = mode == 0 ? stage == 4 : mode == 1;
       err |= rkfd_evaluate<prof, vqp, pk>( m, L, ll, doUp, pc );
+      if( NC > 0 && mode == 0 && stage == 4 && lane == 0 ){     /* contact statistics of the step just committed */
+        L.cnt[CNT_SRG] += L.cnt[CNT_NRG]; L.cnt[CNT_SEL] += L.cnt[CNT_NEL]; L.cnt[CNT_SN] += 1;
+      }
       const double a = on ? L.acc[lane] : 0.0;
       if( stage == 0 ){ Fv = xv; Fa = a; Tv = xv; Ta = a; Pv = c21*xv; Pa = c21*a; }
       else if( stage == 1 ){ Fv = fma( w2, xv, Fv ); Fa = fma( w2, a, Fa ); Tv = fma( c22, xv, Pv ); Ta = fma( c22, a, Pa ); Pv = c31*xv; Pa = c31*a; }
@@ -250,6 +256,8 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDev
       for( int k=0; k<6; k++ ) o[6*lane+k] = L.AC[6*lane+k];
     }
   }
+  if( NC > 0 && mode == 0 && st.stat && lane < 3 )
+    st.stat[(size_t)b*4+lane] += (unsigned int)L.cnt[CNT_SRG+lane];
   if( lane == 0 && errflag ){
     if( err ) *errflag = 1;              /* rigid contact with a solver that has no device path */
     if( L.cnt[CNT_OVF] ) *errflag = 2;   /* more rigid contacts than the configured capacity   */

@@ -1,7 +1,13 @@
 /* rkfd_capi.hip - C ABI (include/rkfd_hip.h) over the gfx950 kernel in rkfd_device.h. */
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE
+#endif
 #include <dlfcn.h>
+#include <link.h>
+#include <pthread.h>
+#include <unistd.h>
 #include <string>
 #include <vector>
 #include <stdio.h>
@@ -41,6 +47,26 @@ RKFD_KERNEL( rkfd_step_kernel_prof, true, false, false )
 RKFD_KERNEL( rkfd_step_kernel_prof_pk, true, false, true )
 RKFD_KERNEL( rkfd_step_kernel_prof_vqp, true, true, false )
 
+/* rkfdBatchRestore: one workgroup copies one instance's state rows back from the snapshot */
+extern "C" __global__ void __launch_bounds__(RKFD_WAVE)
+rkfd_restore_kernel(rkfdDevState st, rkfdDevState sn, int first, int ND, int NLM, int NC)
+{
+  const size_t b = (size_t)first + blockIdx.x;
+  if( b >= (size_t)st.batch ) return;
+  for( int j=threadIdx.x; j<ND; j+=RKFD_WAVE ){
+    st.dis[b*ND+j] = sn.dis[b*ND+j]; st.vel[b*ND+j] = sn.vel[b*ND+j]; st.acc[b*ND+j] = sn.acc[b*ND+j];
+  }
+  for( int j=threadIdx.x; j<NLM; j+=RKFD_WAVE ){
+    st.piv_type[b*NLM+j] = sn.piv_type[b*NLM+j]; st.piv_prev[b*NLM+j] = sn.piv_prev[b*NLM+j];
+  }
+  for( int j=threadIdx.x; j<NC; j+=RKFD_WAVE ){
+    st.cv_active[b*NC+j] = sn.cv_active[b*NC+j]; st.cv_type[b*NC+j] = sn.cv_type[b*NC+j];
+  }
+  for( int j=threadIdx.x; j<3*NC; j+=RKFD_WAVE ){
+    st.cv_ref[b*3*NC+j] = sn.cv_ref[b*3*NC+j]; st.cv_f[b*3*NC+j] = sn.cv_f[b*3*NC+j];
+  }
+}
+
 typedef void (*rkfdKernel)(rkfdDevModel, rkfdDevState, int, int, int, int *);
 #define RKFD_MAX_SPLIT 8
 
@@ -50,6 +76,8 @@ struct rkfdBatch {
   rkfdDevModel dm;        /* device-pointer version */
   void *dblob;
   rkfdDevState st;
+  rkfdDevState snap;      /* rkfdBatchSnapshot: device-resident copy of the state (allocated on first use) */
+  int has_snap;
   int *d_err;
   size_t lds_bytes;
   rkfdKernel kern, kern_prof;
@@ -103,7 +131,7 @@ extern "C" rkfdBatch *rkfdBatchCreate(const rkfdModel *m, int batch, int device,
   char err[256];
   if( rkfd_devmodel_build( m, max_rigid, &b->host, err, sizeof(err) ) < 0 ){
     SETERR( "rkfdBatchCreate: %s", err );
-    free( b );
+    rkfdBatchDestroy( b );
     return NULL;
   }
   b->device = device; b->batch = batch; b->nlink = m->nlink; b->ndof = m->ndof; b->ncand = m->ncand;
@@ -112,13 +140,13 @@ extern "C" rkfdBatch *rkfdBatchCreate(const rkfdModel *m, int batch, int device,
   if( const char *pad = getenv( "RKFD_LDS_PAD_BYTES" ) ) b->lds_bytes += (size_t)( atoi( pad ) > 0 ? atoi( pad ) : 0 );
   if( b->lds_bytes > 160*1024 ){
     SETERR( "rkfdBatchCreate: one instance needs %zu bytes of LDS (> 160 KiB)", b->lds_bytes );
-    rkfd_devmodel_free( &b->host ); free( b );
+    rkfdBatchDestroy( b );
     return NULL;
   }
   if( hipMalloc( &b->dblob, b->host.bytes ) != hipSuccess ||
       hipMemcpy( b->dblob, b->host.blob, b->host.bytes, hipMemcpyHostToDevice ) != hipSuccess ){
     SETERR( "rkfdBatchCreate: cannot copy the model to the device" );
-    rkfd_devmodel_free( &b->host ); free( b );
+    rkfdBatchDestroy( b );
     return NULL;
   }
   b->dm = b->host.dm;
@@ -130,6 +158,7 @@ extern "C" rkfdBatch *rkfdBatchCreate(const rkfdModel *m, int batch, int device,
   bad |= dalloc( &b->st.motor_in, B*NL ); bad |= dalloc( &b->st.piv_type, B*NL ); bad |= dalloc( &b->st.piv_prev, B*NL );
   bad |= dalloc( &b->st.cv_active, B*NC ); bad |= dalloc( &b->st.cv_type, B*NC );
   bad |= dalloc( &b->st.cv_ref, B*NC*3 ); bad |= dalloc( &b->st.cv_f, B*NC*3 );
+  bad |= dalloc( &b->st.stat, B*4 );
   bad |= dalloc( &b->d_err, 1 );
   b->st.dbg = NULL; b->st.dbg_stride = 0; b->st.batch = batch; b->st.prof = NULL;
   if( bad ){ rkfdBatchDestroy( b ); return NULL; }
@@ -149,6 +178,10 @@ extern "C" void rkfdBatchDestroy(rkfdBatch *b)
   (void)hipFree( b->st.dis ); (void)hipFree( b->st.vel ); (void)hipFree( b->st.acc );
   (void)hipFree( b->st.motor_in ); (void)hipFree( b->st.piv_type ); (void)hipFree( b->st.piv_prev );
   (void)hipFree( b->st.cv_active ); (void)hipFree( b->st.cv_type ); (void)hipFree( b->st.cv_ref ); (void)hipFree( b->st.cv_f );
+  (void)hipFree( b->st.stat );
+  (void)hipFree( b->snap.dis ); (void)hipFree( b->snap.vel ); (void)hipFree( b->snap.acc );
+  (void)hipFree( b->snap.piv_type ); (void)hipFree( b->snap.piv_prev );
+  (void)hipFree( b->snap.cv_active ); (void)hipFree( b->snap.cv_type ); (void)hipFree( b->snap.cv_ref ); (void)hipFree( b->snap.cv_f );
   if( b->fork ){
     (void)hipEventDestroy( b->fork );
     for( int k=0; k<RKFD_MAX_SPLIT; k++ ){ (void)hipStreamSynchronize( b->sub[k] ); (void)hipStreamDestroy( b->sub[k] ); (void)hipEventDestroy( b->done[k] ); }
@@ -275,17 +308,23 @@ extern "C" int rkfdBatchSetPivot(rkfdBatch *b, const int *type, const double *pr
   return 0;
 }
 
-/* next event of the timing pool (grown in blocks: creating events inside the launch path is expensive) */
-static hipEvent_t timing_event(rkfdBatch *b)
+/* next start / stop pair of the timing pool (grown in blocks: creating events inside the launch path is expensive);
+ * pairs are handed out whole, so a failed creation never leaves the pool misaligned */
+static int timing_pair(rkfdBatch *b, hipEvent_t *e0, hipEvent_t *e1)
 {
-  if( b->tused == b->tev->size() ){
+  *e0 = *e1 = NULL;
+  if( b->tused + 2 > b->tev->size() ){
     for( int i=0; i<1024; i++ ){
-      hipEvent_t e = NULL;
-      if( hipEventCreate( &e ) != hipSuccess ) return NULL;
-      b->tev->push_back( e );
+      hipEvent_t a = NULL, c = NULL;
+      if( hipEventCreate( &a ) != hipSuccess ) break;
+      if( hipEventCreate( &c ) != hipSuccess ){ (void)hipEventDestroy( a ); break; }
+      b->tev->push_back( a ); b->tev->push_back( c );
     }
+    if( b->tused + 2 > b->tev->size() ) return 0;
   }
-  return (*b->tev)[b->tused++];
+  *e0 = (*b->tev)[b->tused]; *e1 = (*b->tev)[b->tused+1];
+  b->tused += 2;
+  return 1;
 }
 /* make `stream` wait for everything the internal streams hold (no host synchronisation) */
 static int join_streams(rkfdBatch *b, hipStream_t stream)
@@ -324,7 +363,7 @@ static int launch(rkfdBatch *b, int mode, int nsteps, void *stream)
   if( b->nsplit <= 1 || b->st.prof ){
     if( b->st.prof && sync_streams( b ) < 0 ) return -1;
     hipEvent_t e0 = NULL, e1 = NULL;
-    if( b->timing && !b->st.prof && ( e0 = timing_event( b ) ) && ( e1 = timing_event( b ) ) ) HIPCHK( hipEventRecord( e0, (hipStream_t)stream ), -1 );
+    if( b->timing && !b->st.prof && timing_pair( b, &e0, &e1 ) ) HIPCHK( hipEventRecord( e0, (hipStream_t)stream ), -1 );
     if( launch_one( b, kern, b->batch, 0, mode, nsteps, (hipStream_t)stream ) < 0 ) return -1;
     if( e0 && e1 ) HIPCHK( hipEventRecord( e1, (hipStream_t)stream ), -1 );
     return 0;
@@ -344,7 +383,7 @@ static int launch(rkfdBatch *b, int mode, int nsteps, void *stream)
       const int lo = (int)( (long long)b->batch*k/b->nsplit ), hi = (int)( (long long)b->batch*( k+1 )/b->nsplit );
       if( hi <= lo ) continue;
       hipEvent_t e0 = NULL, e1 = NULL;
-      if( b->timing && ( e0 = timing_event( b ) ) && ( e1 = timing_event( b ) ) ) HIPCHK( hipEventRecord( e0, b->sub[k] ), -1 );
+      if( b->timing && timing_pair( b, &e0, &e1 ) ) HIPCHK( hipEventRecord( e0, b->sub[k] ), -1 );
       if( launch_one( b, kern, hi-lo, lo, mode, per, b->sub[k] ) < 0 ) return -1;
       if( e0 && e1 ) HIPCHK( hipEventRecord( e1, b->sub[k] ), -1 );
     }
@@ -387,27 +426,87 @@ static std::string spec_source(const rkfdDevModel &d)
     d.vert_rigid ? "true" : "false", d.ma_packed ? "true" : "false" );
   return std::string( buf );
 }
+/* hipRTC, bound at run time in a PRIVATE link namespace.  hipRTC finds its compiler (libamd_comgr) by soname, and
+ * a process serves every request for a soname with the first library it loaded under it: a host program that has
+ * loaded a framework bundling an older comgr (PyTorch does) would silently get that compiler - with it this kernel
+ * spills (437 VGPR spills, 3.9 M instead of 14 M steps/s on the humanoid).  dlmopen( LM_ID_NEWLM ) gives hipRTC and
+ * the comgr next to it (RUNPATH $ORIGIN) a namespace of their own, whatever the host program loaded before or
+ * after - no preload needed from a C, Python or any other caller.  The ROCm library directory is the one this
+ * library was built against (RKFD_ROCM_LIBDIR, from the Makefile) unless RKFD_ROCM_LIBDIR / ROCM_PATH say otherwise;
+ * RKFD_RTC_NAMESPACE=shared skips the private namespace (diagnostic). */
+#ifndef RKFD_ROCM_LIBDIR
+#define RKFD_ROCM_LIBDIR "/opt/rocm/lib"
+#endif
+struct rkfdRtc {
+  void *h;
+  int priv;     /* 1: loaded in a private namespace */
+  hiprtcResult (*create)(hiprtcProgram *, const char *, const char *, int, const char **, const char **);
+  hiprtcResult (*compile)(hiprtcProgram, int, const char **);
+  hiprtcResult (*logsize)(hiprtcProgram, size_t *);
+  hiprtcResult (*log)(hiprtcProgram, char *);
+  hiprtcResult (*codesize)(hiprtcProgram, size_t *);
+  hiprtcResult (*code)(hiprtcProgram, char *);
+  hiprtcResult (*destroy)(hiprtcProgram *);
+  const char *(*errstr)(hiprtcResult);
+};
+static const rkfdRtc *rtc_api(void)
+{
+  static rkfdRtc api;
+  static int state = 0;          /* 0 not tried, 1 ready, -1 failed */
+  static pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+  pthread_mutex_lock( &mu );
+  if( state == 0 ){
+    std::string dir = RKFD_ROCM_LIBDIR;
+    if( const char *e = getenv( "RKFD_ROCM_LIBDIR" ) ) dir = e;
+    else if( const char *r = getenv( "ROCM_PATH" ) ){ std::string d = std::string( r ) + "/lib"; if( access( ( d + "/libhiprtc.so" ).c_str(), R_OK ) == 0 ) dir = d; }
+    const char *mode = getenv( "RKFD_RTC_NAMESPACE" );
+    const char *names[] = { "/libhiprtc.so.7", "/libhiprtc.so" };
+    void *h = NULL; int priv = 0;
+    if( !mode || strcmp( mode, "shared" ) != 0 )
+      for( int k=0; k<2 && !h; k++ ) h = dlmopen( LM_ID_NEWLM, ( dir + names[k] ).c_str(), RTLD_NOW | RTLD_LOCAL );
+    if( h ) priv = 1;
+    for( int k=0; k<2 && !h; k++ ) h = dlopen( ( dir + names[k] ).c_str(), RTLD_NOW | RTLD_LOCAL );
+    if( !h ) h = dlopen( "libhiprtc.so", RTLD_NOW | RTLD_LOCAL );
+    if( !h ){ SETERR( "hipRTC: cannot load libhiprtc from %s: %s", dir.c_str(), dlerror() ); state = -1; }
+    else {
+      api.h = h; api.priv = priv;
+#define RTCSYM(field, name) *(void **)&api.field = dlsym( h, name )
+      RTCSYM( create, "hiprtcCreateProgram" ); RTCSYM( compile, "hiprtcCompileProgram" ); RTCSYM( logsize, "hiprtcGetProgramLogSize" );
+      RTCSYM( log, "hiprtcGetProgramLog" ); RTCSYM( codesize, "hiprtcGetCodeSize" ); RTCSYM( code, "hiprtcGetCode" );
+      RTCSYM( destroy, "hiprtcDestroyProgram" ); RTCSYM( errstr, "hiprtcGetErrorString" );
+#undef RTCSYM
+      if( !api.create || !api.compile || !api.logsize || !api.log || !api.codesize || !api.code || !api.destroy || !api.errstr ){
+        SETERR( "hipRTC: %s lacks an entry point", dir.c_str() ); state = -1;
+      } else state = 1;
+    }
+  }
+  const int s = state;
+  pthread_mutex_unlock( &mu );
+  return s == 1 ? &api : NULL;
+}
 /* compile for gfx950; needs the device headers beside the library (csrc/) and include/ beside the package */
 static int spec_compile(const rkfdDevModel &d, std::vector<char> &code)
 {
+  const rkfdRtc *rtc = rtc_api();
+  if( !rtc ) return -1;
   const std::string src = spec_source( d ), dir = lib_dir();
   if( const char *dump = getenv( "RKFD_SPEC_DUMP" ) ){ FILE *f = fopen( dump, "w" ); if( f ){ fputs( src.c_str(), f ); fclose( f ); } }   /* diagnostic */
   const std::string i1 = "-I" + dir + "/csrc", i2 = "-I" + dir + "/../include";
   const char *opts[] = { "--offload-arch=gfx950", "-O3", "-Wno-unused-value", "-mllvm", "-disable-machine-licm", i1.c_str(), i2.c_str() };
   hiprtcProgram prog;
-  if( hiprtcCreateProgram( &prog, src.c_str(), "rkfd_step_kernel_spec.hip", 0, NULL, NULL ) != HIPRTC_SUCCESS ){ SETERR( "hiprtcCreateProgram failed" ); return -1; }
-  const hiprtcResult r = hiprtcCompileProgram( prog, (int)( sizeof(opts)/sizeof(opts[0]) ), opts );
+  if( rtc->create( &prog, src.c_str(), "rkfd_step_kernel_spec.hip", 0, NULL, NULL ) != HIPRTC_SUCCESS ){ SETERR( "hiprtcCreateProgram failed" ); return -1; }
+  const hiprtcResult r = rtc->compile( prog, (int)( sizeof(opts)/sizeof(opts[0]) ), opts );
   if( r != HIPRTC_SUCCESS ){
-    size_t n = 0; hiprtcGetProgramLogSize( prog, &n );
-    std::string log( n ? n : 1, ' ' ); if( n ) hiprtcGetProgramLog( prog, &log[0] );
-    SETERR( "hipRTC: %s: %.400s", hiprtcGetErrorString( r ), log.c_str() );
-    hiprtcDestroyProgram( &prog );
+    size_t n = 0; rtc->logsize( prog, &n );
+    std::string log( n ? n : 1, ' ' ); if( n ) rtc->log( prog, &log[0] );
+    SETERR( "hipRTC: %s: %.400s", rtc->errstr( r ), log.c_str() );
+    rtc->destroy( &prog );
     return -1;
   }
   size_t n = 0;
-  hiprtcGetCodeSize( prog, &n ); code.resize( n ); hiprtcGetCode( prog, code.data() );
+  rtc->codesize( prog, &n ); code.resize( n ); rtc->code( prog, code.data() );
   if( const char *dump = getenv( "RKFD_SPEC_DUMP_CODE" ) ){ FILE *f = fopen( dump, "wb" ); if( f ){ fwrite( code.data(), 1, n, f ); fclose( f ); } }   /* diagnostic */
-  hiprtcDestroyProgram( &prog );
+  rtc->destroy( &prog );
   return 0;
 }
 extern "C" int rkfdSpecializeCompile(const rkfdModel *m, int max_rigid)
@@ -441,7 +540,7 @@ extern "C" int rkfdBatchSpecialize(rkfdBatch *b)
     if( scratch > 64 ){
       (void)hipModuleUnload( b->spec_mod ); b->spec_mod = NULL; b->spec_fn = NULL;
       SETERR( "rkfdBatchSpecialize: the compiler hipRTC resolved to in this process produced a spilling kernel (%d VGPRs, %d bytes of scratch per lane); "
-              "load /opt/rocm/lib/libamd_comgr.so.3 before libraries that bundle their own (see bench.py); the generic kernel stays in use", regs, scratch );
+              "point RKFD_ROCM_LIBDIR at the ROCm libraries this library was built with; the generic kernel stays in use", regs, scratch );
       return -1;
     }
   }
@@ -474,7 +573,7 @@ extern "C" int rkfdBatchTimeLaunches(rkfdBatch *b, int on)
   if( !b ){ SETERR( "null batch" ); return -1; }
   b->tused = 0;
   b->timing = on ? 1 : 0;
-  if( on && b->tev->empty() ){ b->tused = 0; (void)timing_event( b ); b->tused = 0; }     /* pre-create the first block */
+  if( on && b->tev->empty() ){ hipEvent_t e0, e1; (void)timing_pair( b, &e0, &e1 ); b->tused = 0; }     /* pre-create the first block */
   return 0;
 }
 extern "C" int rkfdBatchLaunchTiming(rkfdBatch *b, int *launches, double *total_ms)
@@ -527,7 +626,83 @@ extern "C" int rkfdBatchStatus(rkfdBatch *b, void *stream)
   HIPCHK( hipStreamSynchronize( (hipStream_t)stream ), -1 );
   int e = 0;
   HIPCHK( hipMemcpy( &e, b->d_err, sizeof(int), hipMemcpyDeviceToHost ), -1 );
-  if( e == 1 ) SETERR( "a rigid contact occurred but the selected solver has no device path (use MLCP)" );
-  if( e == 2 ) SETERR( "rigid-contact capacity (max_rigid) exceeded in at least one instance" );
+  if( e == 1 ) SETERR( "a rigid contact occurred but no rigid solver is set up on the device for this world (Volume plugin, or max_rigid = 0)" );
+  if( e == 2 ) SETERR( "contact capacity exceeded in at least one instance: more rigid contact vertices than max_rigid (%d), or more "
+                       "rigid + elastic contact vertices than the %d active-contact slots; contacts beyond the capacity were dropped", b->dm.maxrg, b->dm.maxact );
+  if( e == 3 ) SETERR( "the Vert plugin's QP ran out of iterations (256) or of basis history (64) in at least one instance" );
+  if( e != 0 ){
+    /* the condition is reported once: the flag is cleared, so a later status describes what happened after this call */
+    const int zero = 0;
+    HIPCHK( hipMemcpy( b->d_err, &zero, sizeof(int), hipMemcpyHostToDevice ), -1 );
+  }
   return e;
+}
+
+/* ---- contact statistics, snapshot / restore ---------------------------------------------------------------- */
+extern "C" int rkfdBatchContactStats(rkfdBatch *b, int reset, double *mean_rigid, double *mean_elastic, long long *instance_steps)
+{
+  if( !b ){ SETERR( "null batch" ); return -1; }
+  HIPCHK( hipSetDevice( b->device ), -1 );
+  if( sync_streams( b ) < 0 ) return -1;
+  HIPCHK( hipDeviceSynchronize(), -1 );
+  std::vector<unsigned int> h( (size_t)b->batch*4 );
+  HIPCHK( hipMemcpy( h.data(), b->st.stat, sizeof(unsigned int)*h.size(), hipMemcpyDeviceToHost ), -1 );
+  unsigned long long rg = 0, el = 0, n = 0;
+  for( int i=0; i<b->batch; i++ ){ rg += h[4*(size_t)i]; el += h[4*(size_t)i+1]; n += h[4*(size_t)i+2]; }
+  if( mean_rigid ) *mean_rigid = n ? (double)rg/(double)n : 0.0;
+  if( mean_elastic ) *mean_elastic = n ? (double)el/(double)n : 0.0;
+  if( instance_steps ) *instance_steps = (long long)n;
+  if( reset ) HIPCHK( hipMemset( b->st.stat, 0, sizeof(unsigned int)*h.size() ), -1 );
+  return 0;
+}
+
+extern "C" int rkfdBatchSnapshot(rkfdBatch *b)
+{
+  if( !b ){ SETERR( "null batch" ); return -1; }
+  HIPCHK( hipSetDevice( b->device ), -1 );
+  if( sync_streams( b ) < 0 ) return -1;
+  HIPCHK( hipDeviceSynchronize(), -1 );
+  const size_t B = b->batch, ND = b->ndof, NL = b->nlink, NC = b->ncand;
+  if( !b->has_snap ){
+    int bad = 0;
+    bad |= dalloc( &b->snap.dis, B*ND ); bad |= dalloc( &b->snap.vel, B*ND ); bad |= dalloc( &b->snap.acc, B*ND );
+    bad |= dalloc( &b->snap.piv_type, B*NL ); bad |= dalloc( &b->snap.piv_prev, B*NL );
+    bad |= dalloc( &b->snap.cv_active, B*NC ); bad |= dalloc( &b->snap.cv_type, B*NC );
+    bad |= dalloc( &b->snap.cv_ref, B*NC*3 ); bad |= dalloc( &b->snap.cv_f, B*NC*3 );
+    if( bad ) return -1;
+    b->snap.batch = b->batch;
+    b->has_snap = 1;
+  }
+#define SNAPCP(f, n) HIPCHK( hipMemcpy( b->snap.f, b->st.f, (n), hipMemcpyDeviceToDevice ), -1 )
+  SNAPCP( dis, sizeof(double)*B*ND ); SNAPCP( vel, sizeof(double)*B*ND ); SNAPCP( acc, sizeof(double)*B*ND );
+  SNAPCP( piv_type, sizeof(int)*B*NL ); SNAPCP( piv_prev, sizeof(double)*B*NL );
+  SNAPCP( cv_active, sizeof(int)*B*NC ); SNAPCP( cv_type, sizeof(int)*B*NC );
+  SNAPCP( cv_ref, sizeof(double)*B*NC*3 ); SNAPCP( cv_f, sizeof(double)*B*NC*3 );
+#undef SNAPCP
+  return 0;
+}
+
+extern "C" int rkfdBatchRestore(rkfdBatch *b, void *stream)
+{
+  if( !b ){ SETERR( "null batch" ); return -1; }
+  if( !b->has_snap ){ SETERR( "rkfdBatchRestore: no snapshot has been taken (rkfdBatchSnapshot)" ); return -1; }
+  HIPCHK( hipSetDevice( b->device ), -1 );
+  if( b->nsplit <= 1 ){
+    hipLaunchKernelGGL( rkfd_restore_kernel, dim3( b->batch ), dim3( RKFD_WAVE ), 0, (hipStream_t)stream, b->st, b->snap, 0, b->ndof, b->nlink, b->ncand );
+    HIPCHK( hipGetLastError(), -1 );
+    return 0;
+  }
+  /* split launches: every part restores itself on its own stream, in order with its steps */
+  HIPCHK( hipEventRecord( b->fork, (hipStream_t)stream ), -1 );
+  for( int k=0; k<b->nsplit; k++ ){
+    HIPCHK( hipStreamWaitEvent( b->sub[k], b->fork, 0 ), -1 );
+    const int lo = (int)( (long long)b->batch*k/b->nsplit ), hi = (int)( (long long)b->batch*( k+1 )/b->nsplit );
+    if( hi > lo ){
+      hipLaunchKernelGGL( rkfd_restore_kernel, dim3( hi-lo ), dim3( RKFD_WAVE ), 0, b->sub[k], b->st, b->snap, lo, b->ndof, b->nlink, b->ncand );
+      HIPCHK( hipGetLastError(), -1 );
+    }
+    HIPCHK( hipEventRecord( b->done[k], b->sub[k] ), -1 );
+  }
+  b->pending = 1;
+  return 0;
 }

@@ -96,6 +96,8 @@ typedef struct {
   double *piv_prev;              /* [B][nlink]  */
   int    *cv_active, *cv_type;   /* [B][ncand]  */
   double *cv_ref, *cv_f;         /* [B][ncand*3]*/
+  unsigned int *stat;            /* optional [B][4] running sums over the committing evaluations of rkFDUpdate steps:
+                                    rigid contact vertices, elastic contact vertices, steps, unused; may be NULL */
   unsigned long long *prof;      /* optional [B][8] phase cycle counters, may be NULL */
   double *dbg;                   /* optional debug dump, may be NULL */
   int dbg_stride;

@@ -10,10 +10,11 @@ from . import binding as B
 MODELS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "models")
 
 
-def splitmix64_uniform(seed, n):
-    """n doubles in [0,1) from the splitmix64 stream seeded with `seed` (instance-major draws)."""
+def splitmix64_uniform(seed, n, start=0):
+    """draws start .. start+n-1 (doubles in [0,1)) of the splitmix64 stream seeded with `seed`.  The stream is
+    index-addressable, so a rank generates only the draws of its own shard of instances (instance-major draws)."""
     with np.errstate(over="ignore"):
-        idx = np.arange(1, n + 1, dtype=np.uint64)
+        idx = np.arange(start + 1, start + n + 1, dtype=np.uint64)
         z = np.uint64(seed) + idx * np.uint64(0x9E3779B97F4A7C15)
         z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
         z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
@@ -63,23 +64,72 @@ def config1_rigid(batch=1):
     return dict(name="config1b_box_hard_mlcp", world=w, dis=dis, vel=vel, max_rigid=8, steps=2000)
 
 
-def config2(batch=4096):
+def config2(batch=4096, first=0):
     """30-link serial chain, no contact, ABA only."""
     w = B.World(solver=B.SOLVER_VERT)
     w.reg_file(_m("chain30.ztk"))
-    u = splitmix64_uniform(0x5EED0002, batch * 60).reshape(batch, 60)
+    u = splitmix64_uniform(0x5EED0002, batch * 60, start=first * 60).reshape(batch, 60)
     dis = (u[:, :30] - 0.5) * np.pi
     vel = (u[:, 30:] - 0.5) * 2.0
     return dict(name="config2_chain30_aba", world=w, dis=dis, vel=vel, max_rigid=0, steps=1000)
 
 
-def _rot_aa(aa):
-    th = np.linalg.norm(aa)
-    if th < 1e-12:
-        return np.eye(3)
-    k = aa / th
-    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
-    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
+def _rot_aa_batch(aa):
+    """rotation matrices [B,3,3] of the angle-axis vectors aa [B,3]"""
+    th = np.linalg.norm(aa, axis=1)
+    small = th < 1e-12
+    k = aa / np.where(small, 1.0, th)[:, None]
+    K = np.zeros((aa.shape[0], 3, 3))
+    K[:, 0, 1] = -k[:, 2]; K[:, 0, 2] = k[:, 1]; K[:, 1, 0] = k[:, 2]
+    K[:, 1, 2] = -k[:, 0]; K[:, 2, 0] = -k[:, 1]; K[:, 2, 1] = k[:, 0]
+    R = np.eye(3)[None] + np.sin(th)[:, None, None] * K + (1 - np.cos(th))[:, None, None] * (K @ K)
+    R[small] = np.eye(3)
+    return R
+
+
+def link_frames(m, Q):
+    """world frames (R [B,nl,3,3], p [B,nl,3]) of every link at the joint displacements Q [B,ndof]: plain forward
+    kinematics on the flattened model, vectorised over the instances (scenario set-up only)"""
+    nl = m.nlink; Bn = Q.shape[0]
+    parent, jt, off = m.arr("parent", nl), m.arr("jtype", nl), m.arr("dofoff", nl)
+    org = m.arr("org", 12 * nl).reshape(nl, 12)
+    R = np.zeros((Bn, nl, 3, 3)); p = np.zeros((Bn, nl, 3))
+    eye = np.broadcast_to(np.eye(3), (Bn, 3, 3)); zero = np.zeros((Bn, 3))
+    for i in range(nl):
+        Ro = org[i, :9].reshape(3, 3); po = org[i, 9:]
+        Rp, pp = (eye, zero) if parent[i] < 0 else (R[:, parent[i]], p[:, parent[i]])
+        if jt[i] == B.JOINT_REVOL:
+            c, s_ = np.cos(Q[:, off[i]]), np.sin(Q[:, off[i]])
+            Rz = np.zeros((Bn, 3, 3)); Rz[:, 0, 0] = c; Rz[:, 0, 1] = -s_; Rz[:, 1, 0] = s_; Rz[:, 1, 1] = c; Rz[:, 2, 2] = 1
+            R[:, i] = Rp @ Ro @ Rz; p[:, i] = pp + Rp @ po
+        elif jt[i] == B.JOINT_PRISM:
+            R[:, i] = Rp @ Ro; p[:, i] = pp + np.einsum("bij,bj->bi", Rp, po + Ro[:, 2][None] * Q[:, off[i]][:, None])
+        elif jt[i] == B.JOINT_FLOAT:
+            R[:, i] = Rp @ Ro @ _rot_aa_batch(Q[:, off[i] + 3:off[i] + 6])
+            p[:, i] = pp + np.einsum("bij,bj->bi", Rp, po + Q[:, off[i]:off[i] + 3] @ Ro.T)
+        else:
+            R[:, i] = Rp @ Ro; p[:, i] = pp + Rp @ po
+    return R, p
+
+
+def chain_vertices_batch(m, Q, chain):
+    """world positions [B,nv,3] of the collision vertices of `chain` (shape order, vertex order) at Q [B,ndof]"""
+    nl = m.nlink
+    R, p = link_frames(m, Q)
+    ch = m.arr("chain", nl)
+    voff = m.arr("shape_voff", m.nshape + 1); slink = m.arr("shape_link", m.nshape)
+    verts = m.arr("verts", 3 * voff[-1]).reshape(-1, 3)
+    out = [np.zeros((Q.shape[0], 0, 3))]
+    for sh in range(m.nshape):
+        l = slink[sh]
+        if ch[l] == chain:
+            out.append(p[:, l][:, None, :] + np.einsum("bij,vj->bvi", R[:, l], verts[voff[sh]:voff[sh + 1]]))
+    return np.concatenate(out, axis=1)
+
+
+def chain_vertices(m, q, chain):
+    """the same for one instance: [nv,3]"""
+    return chain_vertices_batch(m, np.asarray(q, dtype=np.float64)[None], chain)[0]
 
 
 def lowest_vertex_z(m, q, chain):
@@ -87,85 +137,89 @@ def lowest_vertex_z(m, q, chain):
     return chain_vertices(m, q, chain)[:, 2].min()
 
 
-def chain_vertices(m, q, chain):
-    """world positions of the collision vertices of `chain` at joint displacement q (plain forward
-    kinematics on the flattened model; scenario set-up only)"""
+# Depth at which resting vertices are seated in the floor.  A rigid contact's compensation term asks for the
+# separating velocity K*depth (reference src/rkfd_mlcp.c:178-186; K = 1000 in contactinfo.ztk): it must stay
+# below what gravity takes back in a step, g*dt = 9.8e-3 m/s, or the body is launched off the floor
+# (round 1 seated at 0.5 mm = 0.5 m/s and measured ballistic flight).
+SEAT_DEPTH = 1.0e-5
+
+
+def seat_soles_flat(m, dis, chain, base_off, nominal, depth=None, iters=6):
+    """Stand the chain on flat soles: Gauss-Newton on (base height, base roll, base pitch, the two revolute
+    joints above each sole shape) until the lowest four vertices of every collision shape of `chain` sit
+    `depth` in the floor z = 0.  dis [B,ndof] is modified in place (all other coordinates keep their values); the
+    "lowest four" are picked once, at the pose `nominal` [ndof], so that every shard of a batch picks the same.
+    Vectorised over the instances; a handful of forward-kinematics passes."""
+    depth = SEAT_DEPTH if depth is None else depth
     nl = m.nlink
-    parent, jt, off = m.arr("parent", nl), m.arr("jtype", nl), m.arr("dofoff", nl)
-    org = m.arr("org", 12 * nl).reshape(nl, 12)
-    ch = m.arr("chain", nl)
-    R = np.zeros((nl, 3, 3)); p = np.zeros((nl, 3))
-    for i in range(nl):
-        Ro = org[i, :9].reshape(3, 3); po = org[i, 9:]
-        Rp, pp = (np.eye(3), np.zeros(3)) if parent[i] < 0 else (R[parent[i]], p[parent[i]])
-        if jt[i] == B.JOINT_REVOL:
-            c, s_ = np.cos(q[off[i]]), np.sin(q[off[i]])
-            R[i] = Rp @ Ro @ np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]]); p[i] = pp + Rp @ po
-        elif jt[i] == B.JOINT_PRISM:
-            R[i] = Rp @ Ro; p[i] = pp + Rp @ (po + Ro[:, 2] * q[off[i]])
-        elif jt[i] == B.JOINT_FLOAT:
-            R[i] = Rp @ Ro @ _rot_aa(q[off[i] + 3:off[i] + 6]); p[i] = pp + Rp @ (po + Ro @ q[off[i]:off[i] + 3])
-        else:
-            R[i] = Rp @ Ro; p[i] = pp + Rp @ po
-    voff = m.arr("shape_voff", m.nshape + 1); slink = m.arr("shape_link", m.nshape)
-    verts = m.arr("verts", 3 * voff[-1]).reshape(-1, 3)
-    out = [np.zeros((0, 3))]
+    parent, jt, off, ch = m.arr("parent", nl), m.arr("jtype", nl), m.arr("dofoff", nl), m.arr("chain", nl)
+    slink = m.arr("shape_link", m.nshape); voff = m.arr("shape_voff", m.nshape + 1)
+    unknown = [base_off + 2, base_off + 3, base_off + 4]
+    sel = []; nv = 0
+    v0 = chain_vertices(m, nominal, chain)
     for sh in range(m.nshape):
         l = slink[sh]
         if ch[l] != chain:
             continue
-        out.append(p[l] + verts[voff[sh]:voff[sh + 1]] @ R[l].T)
-    return np.concatenate(out)
+        k = 0
+        while l >= 0 and k < 2:
+            if jt[l] == B.JOINT_REVOL:
+                unknown.append(int(off[l])); k += 1
+            l = parent[l]
+        n = int(voff[sh + 1] - voff[sh])
+        sel.extend(nv + np.argsort(v0[nv:nv + n, 2], kind="stable")[:4]); nv += n
+    sel = np.array(sel); unknown = np.array(unknown)
+    eps = 1e-7
+    for _ in range(iters):
+        r = chain_vertices_batch(m, dis, chain)[:, sel, 2] + depth
+        J = np.zeros(r.shape + (len(unknown),))
+        for c, u in enumerate(unknown):
+            d2 = dis.copy(); d2[:, u] += eps
+            J[:, :, c] = (chain_vertices_batch(m, d2, chain)[:, sel, 2] + depth - r) / eps
+        dis[:, unknown] -= np.einsum("bij,bj->bi", np.linalg.pinv(J, rcond=1e-10), r)
+    return dis
 
 
-SEAT_DEPTH = 0.0005
-
-
-def _humanoid(batch, ci_file, solver, seed, model="humanoid30.ztk"):
-    """standing pose of [roki::chain::init] + per-instance joint perturbation U(-0.05,0.05) rad
-    (SURVEY.md 8d).  The base height is then set per instance so that the lowest sole vertex sits
-    SEAT_DEPTH into the floor: with the fixed height 0.3667 the perturbed feet start 2-4 mm inside
-    the floor and the rigid contact's compensation term launches the robot off the ground, which
-    leaves nothing of the contact pipeline to measure."""
+def _humanoid(batch, ci_file, solver, seed, model="humanoid30.ztk", first=0):
+    """standing pose of [roki::chain::init] + per-instance joint perturbation U(-0.05,0.05) rad (SURVEY.md 8d),
+    then stood on flat soles (seat_soles_flat): with the perturbed ankles the soles are tilted by up to 0.05 rad,
+    the robot touches the floor with ONE vertex and ends rocking on three - not the "standing, Nc ~ 8" workload
+    the configs name.  Instances first .. first+batch-1 of the seeded stream (a rank builds only its shard)."""
     w = B.World(solver=solver)
     w.contact_info(_m(ci_file))
     h = w.reg_file(_m(model))
     w.reg_file(_m("floor.ztk"))
     init = w.init_dis(h)
     n = init.shape[0]
-    u = splitmix64_uniform(seed, batch * (n - 6)).reshape(batch, n - 6)
+    u = splitmix64_uniform(seed, batch * (n - 6), start=first * (n - 6)).reshape(batch, n - 6)
     dis = np.tile(init, (batch, 1))
     dis[:, 6:] += (u - 0.5) * 0.1
-    m = w.model.contents
-    # the joint perturbations come from a small set of distinct rows only when batch is small;
-    # do the FK per instance (host-side, once)
-    for b in range(batch):
-        dis[b, 2] -= lowest_vertex_z(m, dis[b], h) + SEAT_DEPTH
+    seat_soles_flat(w.model.contents, dis, h, w.dof_offset(h), nominal=init)
     vel = np.zeros_like(dis)
     return w, dis, vel
 
 
-def config3(batch=4096, model="humanoid30.ztk"):
+def config3(batch=4096, model="humanoid30.ztk", first=0):
     """30-DoF humanoid on flat ground, Vert plugin, ELASTIC ground contact => penalty."""
-    w, dis, vel = _humanoid(batch, "contact_elastic.ztk", B.SOLVER_VERT, 0x5EED0003, model)
+    w, dis, vel = _humanoid(batch, "contact_elastic.ztk", B.SOLVER_VERT, 0x5EED0003, model, first)
     return dict(name="config3_humanoid_penalty", world=w, dis=dis, vel=vel, max_rigid=0, steps=1000)
 
 
-def config4(batch=4096, model="humanoid30.ztk", max_rigid=8):
+def config4(batch=4096, model="humanoid30.ztk", max_rigid=8, first=0):
     """30-DoF humanoid on flat ground, MLCP plugin, RIGID ground contact."""
-    w, dis, vel = _humanoid(batch, "contact_rigid.ztk", B.SOLVER_MLCP, 0x5EED0004, model)
+    w, dis, vel = _humanoid(batch, "contact_rigid.ztk", B.SOLVER_MLCP, 0x5EED0004, model, first)
     return dict(name="config4_humanoid_mlcp", world=w, dis=dis, vel=vel, max_rigid=max_rigid, steps=1000)
 
 
-def config4_vert(batch=4096, model="humanoid30.ztk"):
+def config4_vert(batch=4096, model="humanoid30.ztk", first=0):
     """config 4 under the reference's DEFAULT plugin: 30-DoF humanoid on flat ground, RIGID ground contact,
     Vert plugin (8-face friction pyramids + active-set QP).  Capacity 8 contact vertices = 64 pyramid faces,
     one per lane."""
-    w, dis, vel = _humanoid(batch, "contact_rigid.ztk", B.SOLVER_VERT, 0x5EED0004, model)
+    w, dis, vel = _humanoid(batch, "contact_rigid.ztk", B.SOLVER_VERT, 0x5EED0004, model, first)
     return dict(name="config4_humanoid_vert_qp", world=w, dis=dis, vel=vel, max_rigid=8, steps=1000)
 
 
-def config5(batch=4096, max_rigid=24):
+def config5(batch=4096, max_rigid=24, first=0):
     """config 4 + clutter: four small boxes resting on the floor around the feet; box-floor and
     box-foot pairs are RIGID ('ground body' / 'body body' of contactinfo.ztk), box-box pairs are
     unregistered (as the reference's box-drop drivers do).  54 joint coordinates, 34 links,
@@ -182,7 +236,7 @@ def config5(batch=4096, max_rigid=24):
     w.reg_file(_m("floor.ztk"))
     init = w.init_dis(h)
     n = init.shape[0]
-    u = splitmix64_uniform(0x5EED0005, batch * (n - 6)).reshape(batch, n - 6)
+    u = splitmix64_uniform(0x5EED0005, batch * (n - 6), start=first * (n - 6)).reshape(batch, n - 6)
     m = w.model.contents
     dis = np.zeros((batch, m.ndof))
     ho = w.dof_offset(h)
@@ -191,8 +245,8 @@ def config5(batch=4096, max_rigid=24):
     for k, (sx, sy) in enumerate(((1, 1), (-1, 1), (-1, -1), (1, -1))):
         o = w.dof_offset(boxes[k])
         dis[:, o:o + 3] = (0.15 * sx, 0.15 * sy, 0.025 - SEAT_DEPTH)
-    for b in range(batch):
-        dis[b, ho + 2] -= lowest_vertex_z(m, dis[b], h) + SEAT_DEPTH
+    nominal = np.zeros(m.ndof); nominal[ho:ho + n] = init
+    seat_soles_flat(m, dis, h, ho, nominal=nominal)
     vel = np.zeros_like(dis)
     return dict(name="config5_humanoid_clutter_mlcp", world=w, dis=dis, vel=vel, max_rigid=max_rigid, steps=1000)
 
@@ -238,14 +292,14 @@ def arm_press(batch=8, root="fixed", with_box=True, seed=0x5EED00A1):
     return dict(name=f"arm_press_{root}{'_box' if with_box else ''}", world=w, dis=dis, vel=vel, motor_in=inp, max_rigid=12, steps=200)
 
 
-def config3_26(batch=4096):
+def config3_26(batch=4096, first=0):
     """config 3 on the 26-DoF model with mighty.ztk's own topology (reported alongside)"""
-    d = config3(batch, model="humanoid26.ztk"); d["name"] = "config3_humanoid26_penalty"; return d
+    d = config3(batch, model="humanoid26.ztk", first=first); d["name"] = "config3_humanoid26_penalty"; return d
 
 
-def config4_26(batch=4096):
+def config4_26(batch=4096, first=0):
     """config 4 on the 26-DoF model with mighty.ztk's own topology"""
-    d = config4(batch, model="humanoid26.ztk"); d["name"] = "config4_humanoid26_mlcp"; return d
+    d = config4(batch, model="humanoid26.ztk", first=first); d["name"] = "config4_humanoid26_mlcp"; return d
 
 
 CONFIGS = {"config1": config1, "config1b": config1_rigid, "config2": config2, "config3": config3, "config4": config4, "config4v": config4_vert, "config5": config5,

@@ -9,18 +9,6 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "emu"))
         sys.path.insert(0, p)
 
 
-# rkfdBatchSpecialize compiles through hipRTC -> libamd_comgr, and the first comgr a process loads serves it for good.
-# PyTorch bundles an older one under the same soname (tests/test_shard_gloo.py imports torch): load the image's own
-# first, so that the specialised-kernel tests do not depend on the order the test files run in.
-_COMGR = "/opt/rocm/lib/libamd_comgr.so.3"
-if os.path.exists(_COMGR):
-    import ctypes
-    try:
-        ctypes.CDLL(_COMGR, mode=ctypes.RTLD_GLOBAL)
-    except OSError:
-        pass
-
-
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

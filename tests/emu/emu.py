@@ -15,7 +15,7 @@ _lib = None
 class DevState(C.Structure):
     _fields_ = [("dis", C.c_void_p), ("vel", C.c_void_p), ("acc", C.c_void_p), ("motor_in", C.c_void_p),
                 ("piv_type", C.c_void_p), ("piv_prev", C.c_void_p), ("cv_active", C.c_void_p), ("cv_type", C.c_void_p),
-                ("cv_ref", C.c_void_p), ("cv_f", C.c_void_p), ("prof", C.c_void_p), ("dbg", C.c_void_p), ("dbg_stride", C.c_int), ("batch", C.c_int)]
+                ("cv_ref", C.c_void_p), ("cv_f", C.c_void_p), ("stat", C.c_void_p), ("prof", C.c_void_p), ("dbg", C.c_void_p), ("dbg_stride", C.c_int), ("batch", C.c_int)]
 
 
 def lib():
