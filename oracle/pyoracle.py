@@ -16,33 +16,46 @@ def build():
     subprocess.run(["make", "-C", HERE], check=True, stdout=subprocess.DEVNULL)
 
 
-def lib():
+def _bind(path):
+    L = C.CDLL(path)
+    vp = C.c_void_p
+    L.rkfdOracleCreate.argtypes = [vp]; L.rkfdOracleCreate.restype = vp
+    L.rkfdOracleDestroy.argtypes = [vp]
+    L.rkfdOracleSetState.argtypes = [vp, vp, vp]
+    L.rkfdOracleGetState.argtypes = [vp, vp, vp, vp]
+    L.rkfdOracleSetMotorInput.argtypes = [vp, vp]
+    L.rkfdOracleTime.argtypes = [vp]; L.rkfdOracleTime.restype = C.c_double
+    L.rkfdOracleGetContact.argtypes = [vp, vp, vp, vp, vp]
+    L.rkfdOracleSetContact.argtypes = [vp, vp, vp, vp]
+    L.rkfdOracleGetPivot.argtypes = [vp, vp, vp]
+    L.rkfdOracleSetPivot.argtypes = [vp, vp, vp]
+    L.rkfdOracleUpdateInit.argtypes = [vp]
+    L.rkfdOracleUpdate.argtypes = [vp]
+    L.rkfdOracleUpdateN.argtypes = [vp, C.c_int]
+    L.rkfdOracleLastQPIter.argtypes = [vp]
+    L.rkfdOracleQPCycleStops.argtypes = [vp]
+    L.rkfdOracleEval.argtypes = [vp, C.c_int]
+    L.rkfdOracleGetLinkFrames.argtypes = [vp, vp, vp]
+    L.rkfdOracleGetLinkVelAcc.argtypes = [vp, vp, vp]
+    L.rkfdOracleGetMLCP.argtypes = [vp, vp, vp, vp, C.c_int]
+    return L
+
+
+_libs = {}
+
+
+def lib(path=None):
+    """the oracle library (built on first use); `path`: another build of the same source (e.g. the fused-multiply-add
+    build `make -C oracle fma`, used as a rounding control)"""
     global _lib
+    if path is not None:
+        if path not in _libs:
+            _libs[path] = _bind(path)
+        return _libs[path]
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             build()
-        L = C.CDLL(LIB_PATH)
-        vp = C.c_void_p
-        L.rkfdOracleCreate.argtypes = [vp]; L.rkfdOracleCreate.restype = vp
-        L.rkfdOracleDestroy.argtypes = [vp]
-        L.rkfdOracleSetState.argtypes = [vp, vp, vp]
-        L.rkfdOracleGetState.argtypes = [vp, vp, vp, vp]
-        L.rkfdOracleSetMotorInput.argtypes = [vp, vp]
-        L.rkfdOracleTime.argtypes = [vp]; L.rkfdOracleTime.restype = C.c_double
-        L.rkfdOracleGetContact.argtypes = [vp, vp, vp, vp, vp]
-        L.rkfdOracleSetContact.argtypes = [vp, vp, vp, vp]
-        L.rkfdOracleGetPivot.argtypes = [vp, vp, vp]
-        L.rkfdOracleSetPivot.argtypes = [vp, vp, vp]
-        L.rkfdOracleUpdateInit.argtypes = [vp]
-        L.rkfdOracleUpdate.argtypes = [vp]
-        L.rkfdOracleUpdateN.argtypes = [vp, C.c_int]
-        L.rkfdOracleLastQPIter.argtypes = [vp]
-        L.rkfdOracleQPCycleStops.argtypes = [vp]
-        L.rkfdOracleEval.argtypes = [vp, C.c_int]
-        L.rkfdOracleGetLinkFrames.argtypes = [vp, vp, vp]
-        L.rkfdOracleGetLinkVelAcc.argtypes = [vp, vp, vp]
-        L.rkfdOracleGetMLCP.argtypes = [vp, vp, vp, vp, C.c_int]
-        _lib = L
+        _lib = _bind(LIB_PATH)
     return _lib
 
 
@@ -53,8 +66,8 @@ def _p(a):
 class Oracle:
     """One simulated world (= one rkFD of the reference) on the CPU."""
 
-    def __init__(self, model_ptr):
-        self._L = lib()
+    def __init__(self, model_ptr, libpath=None):
+        self._L = lib(libpath)
         self._model = model_ptr            # keep the owner alive
         m = model_ptr.contents
         self.ndof, self.nlink, self.ncand = m.ndof, m.nlink, m.ncand

@@ -22,6 +22,7 @@
 #  define RKFD_SCHED_BARRIER() do{}while(0)
 #  define BCAST(x,l)    rkfd_emu_bcast(x,l)
 #  define BALLOT(p)     rkfd_emu_ballot(p)
+#  define ROWBC_FMAC(C,acc,x,a) ( (acc) = fma( rkfd_emu_bcast( (x), ( rkfd_emu_lane() & ~15 ) | (C) ), (a), (acc) ) )
 #else
 #  define RKFD_DEV __device__ __forceinline__
 /* the lane index is read through an opaque asm in every phase: otherwise the compiler hoists dozens of
@@ -96,6 +97,15 @@ RKFD_DEV double rkfd_rcp(double x)
   r = fma( r, fma( -x, r, 1.0 ), r );
   return r;
 }
+/* acc += x[lane C of this lane's row of 16] * a in ONE instruction: gfx90a+ gives the fp64 FMA a DPP operand with
+ * row_newbcast, so a Gauss-Seidel increment reaches the residuals of every lane of the row without a trip through
+ * the scalar registers (v_readlane pair + use: ~37 cycles measured).  C is a literal 0..15.  The s_nop covers the
+ * VALU-write -> DPP-read hazard, which the compiler does not see inside inline asm. */
+template<int C> RKFD_DEV void rkfd_rowbc_fmac(double &acc, double x, double a)
+{
+  asm volatile( "s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(a), "n"(C) );
+}
+#  define ROWBC_FMAC(C,acc,x,a) rkfd_rowbc_fmac<C>( acc, x, a )
 #  define G8SUM(x)      rkfd_g8sum(x)
 #  define G8SUM2(x,y)   rkfd_g8sum2(x,y)
 #  define G8BCAST(x,k)  rkfd_g8bcast<k>(x)

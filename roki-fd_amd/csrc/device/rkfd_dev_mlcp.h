@@ -62,6 +62,86 @@ template<bool pk> RKFD_DEV void rkfd_pgs_registers(const double *MA, int r0, int
   }
 }
 
+/* projected Gauss-Seidel for up to 16 contacts (lane = contact, all in the first row of 16 lanes): the increment of
+ * the contact whose turn it is reaches everybody's residuals through the DPP operand of the FMA itself
+ * (ROWBC_FMAC: v_fmac_f64_dpp row_newbcast), so the dependent path of a normal update is
+ *   fmac (residual) -> fma (candidate) -> cmp -> select -> sub (increment) -> fmac ...
+ * with no scalar-register round trip.  The contact loop is unrolled in blocks of RKFD_PGS_BLK (the broadcast lane is
+ * a literal); a block's matrix entries are fetched from LDS together at its top, off the dependent path, instead
+ * of three / six loads in front of every update.  Same arithmetic and update order as the general loop in
+ * rkfd_phase_mlcp (reference src/rkfd_mlcp.c:190-249). */
+#define RKFD_PGS_BLK 4
+#define RKFD_PGS_DPP_MAX 16
+template<bool pk, int C0> RKFD_DEV void rkfd_pgs_dpp_normal(const double *MA, int r0, int ld, int nc, int lane, double in_,
+                                                            double &rn, double &r1, double &r2, double &fn)
+{
+  double a0[RKFD_PGS_BLK], a1[RKFD_PGS_BLK], a2[RKFD_PGS_BLK];
+#pragma unroll
+  for( int u=0; u<RKFD_PGS_BLK; u++ ){
+    const int c = C0+u < nc ? C0+u : nc-1;       /* (a column beyond the last contact is not used: stay inside the matrix) */
+    a0[u] = MA[rkfd_ma_idx<pk>( r0, 3*c, ld )]; a1[u] = MA[rkfd_ma_idx<pk>( r0+1, 3*c, ld )]; a2[u] = MA[rkfd_ma_idx<pk>( r0+2, 3*c, ld )];
+  }
+#define RKFD_PGS_N(u) \
+  if( C0+u < nc ){ \
+    /* normal force of contact c: f_n <- max( 0, -( b + a.f - a_nn f_n ) / a_nn ) */ \
+    double ff = fn - rn*in_; \
+    if( ff < RKFD_DEV_TOL ) ff = 0.0; \
+    const double dl = ff - fn; \
+    if( lane == C0+u ) fn = ff; \
+    ROWBC_FMAC( C0+u, rn, dl, a0[u] ); ROWBC_FMAC( C0+u, r1, dl, a1[u] ); ROWBC_FMAC( C0+u, r2, dl, a2[u] ); \
+  }
+  RKFD_PGS_N(0) RKFD_PGS_N(1) RKFD_PGS_N(2) RKFD_PGS_N(3)
+#undef RKFD_PGS_N
+}
+template<bool pk, int C0> RKFD_DEV void rkfd_pgs_dpp_tangent(const double *MA, int r0, int ld, int nc, int lane, double i1, double i2, double fs,
+                                                             double &rn, double &r1, double &r2, double &f1, double &f2)
+{
+  /* (blocks of two: twelve matrix entries in flight, like the four contacts of a normal block) */
+  double a0[2], a1[2], a2[2], b0[2], b1[2], b2[2];
+#pragma unroll
+  for( int u=0; u<2; u++ ){
+    const int c = C0+u < nc ? C0+u : nc-1;
+    a0[u] = MA[rkfd_ma_idx<pk>( r0, 3*c+1, ld )]; a1[u] = MA[rkfd_ma_idx<pk>( r0+1, 3*c+1, ld )]; a2[u] = MA[rkfd_ma_idx<pk>( r0+2, 3*c+1, ld )];
+    b0[u] = MA[rkfd_ma_idx<pk>( r0, 3*c+2, ld )]; b1[u] = MA[rkfd_ma_idx<pk>( r0+1, 3*c+2, ld )]; b2[u] = MA[rkfd_ma_idx<pk>( r0+2, 3*c+2, ld )];
+  }
+#define RKFD_PGS_T(u) \
+  if( C0+u < nc ){ \
+    /* tangential forces of contact c: Gauss-Seidel value for both, then scaled onto the friction disc of radius mu f_n \
+     * (fs = ( mu f_n )^2: the normal forces do not change during the tangential pass) */ \
+    const double ff0 = f1 - r1*i1, ff1 = f2 - r2*i2; \
+    const double fnorm = ff0*ff0 + ff1*ff1; \
+    const bool zero = fnorm < RKFD_DEV_TOL || fs < RKFD_DEV_TOL; \
+    double n1 = zero ? 0.0 : ff0, n2 = zero ? 0.0 : ff1; \
+    /* only the decision of lane c matters: branch on it wave-uniformly, so that the reciprocal is evaluated only \
+     * when contact c really slides */ \
+    if( ( BALLOT( !zero && fnorm > fs ) >> ( C0+u ) ) & 1ull ){ \
+      const double sc = fs*RKFD_RCP( fnorm ); \
+      n1 = ff0*sc; n2 = ff1*sc; \
+    } \
+    const double d1 = n1 - f1, d2 = n2 - f2; \
+    if( lane == C0+u ){ f1 = n1; f2 = n2; } \
+    ROWBC_FMAC( C0+u, rn, d2, b0[u] ); ROWBC_FMAC( C0+u, r1, d2, b1[u] ); ROWBC_FMAC( C0+u, r2, d2, b2[u] ); \
+    ROWBC_FMAC( C0+u, rn, d1, a0[u] ); ROWBC_FMAC( C0+u, r1, d1, a1[u] ); ROWBC_FMAC( C0+u, r2, d1, a2[u] ); \
+  }
+  RKFD_PGS_T(0) RKFD_PGS_T(1)
+#undef RKFD_PGS_T
+}
+template<bool pk> RKFD_DEV void rkfd_pgs_dpp(const double *MA, int r0, int ld, int nc, int maxrg, int max_iter, int lane, double mu,
+                                             double in_, double i1, double i2, double &rn, double &r1, double &r2, double &fn, double &f1, double &f2)
+{
+  for( int it=0; it<max_iter; it++ ){
+    rkfd_pgs_dpp_normal<pk, 0>( MA, r0, ld, nc, lane, in_, rn, r1, r2, fn );
+    if( maxrg > 4 && nc > 4 ) rkfd_pgs_dpp_normal<pk, 4>( MA, r0, ld, nc, lane, in_, rn, r1, r2, fn );
+    if( maxrg > 8 && nc > 8 ) rkfd_pgs_dpp_normal<pk, 8>( MA, r0, ld, nc, lane, in_, rn, r1, r2, fn );
+    if( maxrg > 12 && nc > 12 ) rkfd_pgs_dpp_normal<pk, 12>( MA, r0, ld, nc, lane, in_, rn, r1, r2, fn );
+    double fs = mu*fn; fs = fs*fs;
+    rkfd_pgs_dpp_tangent<pk, 0>( MA, r0, ld, nc, lane, i1, i2, fs, rn, r1, r2, f1, f2 );
+#define RKFD_PGS_TB(C0) if( maxrg > C0 && nc > C0 ) rkfd_pgs_dpp_tangent<pk, C0>( MA, r0, ld, nc, lane, i1, i2, fs, rn, r1, r2, f1, f2 );
+    RKFD_PGS_TB(2) RKFD_PGS_TB(4) RKFD_PGS_TB(6) RKFD_PGS_TB(8) RKFD_PGS_TB(10) RKFD_PGS_TB(12) RKFD_PGS_TB(14)
+#undef RKFD_PGS_TB
+  }
+}
+
 /* ------------------------------------------------------------------------ */
 /* MLCP rigid branch (reference src/rkfd_mlcp.c:287-297).  Preconditions: sweep 2 and sweep 3
  * have been run with the wrenches applied so far (rkFDUpdateAccBias), so AC holds the free
@@ -324,7 +404,10 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
       const int jr_ = L.lrg[lane], cir_ = RKFD_CI_CI( L.CIp[jr_] );
       mu = L.typ[jr_] == RKFD_SF ? m.ci_sf[cir_] : m.ci_kf[cir_];
     }
-    if( nc <= RKFD_PGS_NC ) rkfd_pgs_registers<pk>( L.MA, r0, ld, nc, m.max_iter, on, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
+    /* (the packed-matrix kernels serve worlds with more than 16 contacts; their index arithmetic in four-contact blocks
+     * costs registers the kernel does not have, so they keep the register variant for small contact counts) */
+    if( !pk && nc <= RKFD_PGS_DPP_MAX ) rkfd_pgs_dpp<pk>( L.MA, r0, ld, nc, m.maxrg, m.max_iter, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
+    else if( pk && nc <= RKFD_PGS_NC ) rkfd_pgs_registers<pk>( L.MA, r0, ld, nc, m.max_iter, on, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
     else for( int it=0; it<m.max_iter; it++ ){
       for( int c=0; c<nc; c++ ){
         /* normal force of contact c: f_n <- max( 0, -( b + a.f - a_nn f_n ) / a_nn ) */
