@@ -142,6 +142,110 @@ template<bool pk> RKFD_DEV void rkfd_pgs_dpp(const double *MA, int r0, int ld, i
   }
 }
 
+/* the general loop: any number of contacts, increments broadcast with v_readlane */
+template<bool pk> RKFD_DEV void rkfd_pgs_general(const double *MA, int r0, int ld, int nc, int max_iter, int lane, double mu,
+                                                 double in_, double i1, double i2, double &rn, double &r1, double &r2, double &fn, double &f1, double &f2)
+{
+for( int it=0; it<max_iter; it++ ){
+    for( int c=0; c<nc; c++ ){
+      /* normal force of contact c: f_n <- max( 0, -( b + a.f - a_nn f_n ) / a_nn ) */
+      const double a0 = MA[rkfd_ma_idx<pk>( r0, 3*c, ld )], a1 = MA[rkfd_ma_idx<pk>( r0+1, 3*c, ld )], a2 = MA[rkfd_ma_idx<pk>( r0+2, 3*c, ld )];
+      double ff = fn - rn*in_;
+      if( ff < RKFD_DEV_TOL ) ff = 0.0;
+      const double dl = BCAST( ff - fn, c );
+      if( lane == c ) fn = ff;
+      rn = fma( a0, dl, rn ); r1 = fma( a1, dl, r1 ); r2 = fma( a2, dl, r2 );
+    }
+    for( int c=0; c<nc; c++ ){
+      /* tangential forces of contact c: Gauss-Seidel value for both, then scaled onto the
+       * friction disc of radius mu f_n */
+      const double a0 = MA[rkfd_ma_idx<pk>( r0, 3*c+1, ld )], a1 = MA[rkfd_ma_idx<pk>( r0+1, 3*c+1, ld )], a2 = MA[rkfd_ma_idx<pk>( r0+2, 3*c+1, ld )];
+      const double b0 = MA[rkfd_ma_idx<pk>( r0, 3*c+2, ld )], b1 = MA[rkfd_ma_idx<pk>( r0+1, 3*c+2, ld )], b2 = MA[rkfd_ma_idx<pk>( r0+2, 3*c+2, ld )];
+      const double ff0 = f1 - r1*i1, ff1 = f2 - r2*i2;
+      const double fnorm = ff0*ff0 + ff1*ff1;
+      double fs = mu*fn; fs = fs*fs;
+      double n1, n2;
+      if( fnorm < RKFD_DEV_TOL || fs < RKFD_DEV_TOL ){ n1 = 0; n2 = 0; }
+      else if( fnorm > fs ){ const double sc = fs*RKFD_RCP( fnorm ); n1 = ff0*sc; n2 = ff1*sc; }
+      else { n1 = ff0; n2 = ff1; }
+      const double d1 = BCAST( n1 - f1, c ), d2 = BCAST( n2 - f2, c );
+      if( lane == c ){ f1 = n1; f2 = n2; }
+      rn = fma( a0, d1, fma( b0, d2, rn ) );
+      r1 = fma( a1, d1, fma( b1, d2, r1 ) );
+      r2 = fma( a2, d1, fma( b2, d2, r2 ) );
+    }
+  }
+}
+
+#ifndef RKFD_EMU
+/* The contact-space matrix as a Gram product on the matrix cores (the "MFMA ... for the dense J M^-1 J' GEMM" of the north
+ * star; measurement variant, see DESIGN.md "MFMA").  In innovations form A = N'N, where column k of N holds the scaled
+ * innovations probe k leaves at the joints of its path.  The probe scratch PU is indexed by tree LEVEL, and two probes
+ * share a level without sharing the joint (the two legs), so the K dimension of the product is the JOINT: row j of the
+ * expanded panel N' is PU[depth(j)] where joint j lies on the probe's path and 0 elsewhere, then six rows per float
+ * joint.  N' is never stored: each lane builds its operand element for a k-step of four joints on the fly
+ * (v_mfma_f64_16x16x4_f64: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15], one double per lane each;
+ * C/D col = lane & 15, row = ( lane >> 4 ) + 4 reg).  Up to 32 rows: tiles (0,0), (0,1), (1,1), the fourth by symmetry. */
+typedef double rkfd_d4 __attribute__((ext_vector_type(4)));
+RKFD_DEV void rkfd_mlcp_matrix_mfma(const rkfdDevModel &m, const rkfdLds &L, int nc, int ld, bool vert)
+{
+  const int lane = LANE();
+  const int M = 3*nc, NLV = m.nlevel, NL = m.nlink, NSD = m.nside, PUS = m.npurow*M;
+  const unsigned char *TOP = L.PL + NL*NLV, *FSL = TOP + NL;
+  const int kk = lane >> 4, cc = lane & 15;
+  const int col0 = cc, col1 = 16 + cc;
+  unsigned e00 = 0, e01 = 0, e10 = 0, e11 = 0;      /* [column block][side] */
+  if( col0 < M ){ e00 = (unsigned)L.tgt[( col0/3 )*NSD]; if( NSD > 1 ) e01 = (unsigned)L.tgt[( col0/3 )*NSD+1]; }
+  if( col1 < M ){ e10 = (unsigned)L.tgt[( col1/3 )*NSD]; if( NSD > 1 ) e11 = (unsigned)L.tgt[( col1/3 )*NSD+1]; }
+  rkfd_d4 c00 = { 0, 0, 0, 0 }, c01 = { 0, 0, 0, 0 }, c11 = { 0, 0, 0, 0 };
+  /* element of N' for (joint j at depth d, column col) from one side's packed path record */
+#define RKFD_NP_ELEM(e, s, col) ( ( RKFD_CS_VALID( e ) && d >= RKFD_CS_D0( e ) && d <= RKFD_CS_DEPTH( e ) && L.PL[RKFD_CS_LINK( e )*NLV+d] == j ) ? L.PU[(s)*PUS + d*M + (col)] : 0.0 )
+  for( int j0=0; j0<NL; j0+=4 ){
+    const int j = j0 + kk;
+    const int lij = j < NL ? L.LI[j] : 0, jt = RKFD_LI_JT( lij ), d = RKFD_LI_DEPTH( lij );
+    double a0 = 0, a1 = 0;
+    if( j < NL && ( jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM ) ){
+      a0 = RKFD_NP_ELEM( e00, 0, col0 ) + RKFD_NP_ELEM( e01, 1, col0 );
+      a1 = RKFD_NP_ELEM( e10, 0, col1 ) + RKFD_NP_ELEM( e11, 1, col1 );
+    }
+    c00 = __builtin_amdgcn_mfma_f64_16x16x4f64( a0, a0, c00, 0, 0, 0 );
+    c01 = __builtin_amdgcn_mfma_f64_16x16x4f64( a0, a1, c01, 0, 0, 0 );
+    if( M > 16 ) c11 = __builtin_amdgcn_mfma_f64_16x16x4f64( a1, a1, c11, 0, 0, 0 );
+  }
+#undef RKFD_NP_ELEM
+#define RKFD_NP_FLT(e, s, col) ( ( RKFD_CS_VALID( e ) && RKFD_CS_FLOAT( e ) && FSL[RKFD_CS_TOP( e )] == f ) ? L.PU[(s)*PUS + ( NLV+q )*M + (col)] : 0.0 )
+  for( int f=0; f<m.nfloat; f++ )
+    for( int q0=0; q0<8; q0+=4 ){
+      const int q = q0 + kk;
+      double a0 = 0, a1 = 0;
+      if( q < 6 ){
+        a0 = RKFD_NP_FLT( e00, 0, col0 ) + RKFD_NP_FLT( e01, 1, col0 );
+        a1 = RKFD_NP_FLT( e10, 0, col1 ) + RKFD_NP_FLT( e11, 1, col1 );
+      }
+      c00 = __builtin_amdgcn_mfma_f64_16x16x4f64( a0, a0, c00, 0, 0, 0 );
+      c01 = __builtin_amdgcn_mfma_f64_16x16x4f64( a0, a1, c01, 0, 0, 0 );
+      if( M > 16 ) c11 = __builtin_amdgcn_mfma_f64_16x16x4f64( a1, a1, c11, 0, 0, 0 );
+    }
+#undef RKFD_NP_FLT
+  /* store: lane holds rows kk + 4 reg of column cc of each tile; relaxation on the diagonal (MLCP plugin) */
+#pragma unroll
+  for( int rg=0; rg<4; rg++ ){
+    const int r = kk + 4*rg;
+    if( r < M && cc < M ){
+      double v = c00[rg];
+      if( r == cc && !vert ) v += m.ci_l[RKFD_CI_CI( L.CIp[L.lrg[r/3]] )];
+      L.MA[r*ld + cc] = v;
+    }
+    if( r < M && col1 < M ){ L.MA[r*ld + col1] = c01[rg]; L.MA[col1*ld + r] = c01[rg]; }
+    if( 16+r < M && col1 < M ){
+      double v = c11[rg];
+      if( 16+r == col1 && !vert ) v += m.ci_l[RKFD_CI_CI( L.CIp[L.lrg[col1/3]] )];
+      L.MA[( 16+r )*ld + col1] = v;
+    }
+  }
+}
+#endif
+
 /* ------------------------------------------------------------------------ */
 /* MLCP rigid branch (reference src/rkfd_mlcp.c:287-297).  Preconditions: sweep 2 and sweep 3
  * have been run with the wrenches applied so far (rkFDUpdateAccBias), so AC holds the free
@@ -299,6 +403,10 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
   }
   SYNC();
   MST(15);
+#ifndef RKFD_EMU
+  if( !pk && m.mlcp_mfma && M <= 32 ) rkfd_mlcp_matrix_mfma( m, L, nc, ld, vert );
+  else
+#endif
   /* A, one 3x3 block per lane and pass: block ( cr, ck <= cr ) and its mirror image */
   for( int e0=0; e0<nc*nc; e0+=RKFD_WAVE ){
     const int e = e0 + lane;
@@ -404,39 +512,16 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
       const int jr_ = L.lrg[lane], cir_ = RKFD_CI_CI( L.CIp[jr_] );
       mu = L.typ[jr_] == RKFD_SF ? m.ci_sf[cir_] : m.ci_kf[cir_];
     }
-    /* (the packed-matrix kernels serve worlds with more than 16 contacts; their index arithmetic in four-contact blocks
-     * costs registers the kernel does not have, so they keep the register variant for small contact counts) */
-    if( !pk && nc <= RKFD_PGS_DPP_MAX ) rkfd_pgs_dpp<pk>( L.MA, r0, ld, nc, m.maxrg, m.max_iter, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
-    else if( pk && nc <= RKFD_PGS_NC ) rkfd_pgs_registers<pk>( L.MA, r0, ld, nc, m.max_iter, on, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
-    else for( int it=0; it<m.max_iter; it++ ){
-      for( int c=0; c<nc; c++ ){
-        /* normal force of contact c: f_n <- max( 0, -( b + a.f - a_nn f_n ) / a_nn ) */
-        const double a0 = L.MA[rkfd_ma_idx<pk>( r0, 3*c, ld )], a1 = L.MA[rkfd_ma_idx<pk>( r0+1, 3*c, ld )], a2 = L.MA[rkfd_ma_idx<pk>( r0+2, 3*c, ld )];
-        double ff = fn - rn*in_;
-        if( ff < RKFD_DEV_TOL ) ff = 0.0;
-        const double dl = BCAST( ff - fn, c );
-        if( lane == c ) fn = ff;
-        rn = fma( a0, dl, rn ); r1 = fma( a1, dl, r1 ); r2 = fma( a2, dl, r2 );
-      }
-      for( int c=0; c<nc; c++ ){
-        /* tangential forces of contact c: Gauss-Seidel value for both, then scaled onto the
-         * friction disc of radius mu f_n */
-        const double a0 = L.MA[rkfd_ma_idx<pk>( r0, 3*c+1, ld )], a1 = L.MA[rkfd_ma_idx<pk>( r0+1, 3*c+1, ld )], a2 = L.MA[rkfd_ma_idx<pk>( r0+2, 3*c+1, ld )];
-        const double b0 = L.MA[rkfd_ma_idx<pk>( r0, 3*c+2, ld )], b1 = L.MA[rkfd_ma_idx<pk>( r0+1, 3*c+2, ld )], b2 = L.MA[rkfd_ma_idx<pk>( r0+2, 3*c+2, ld )];
-        const double ff0 = f1 - r1*i1, ff1 = f2 - r2*i2;
-        const double fnorm = ff0*ff0 + ff1*ff1;
-        double fs = mu*fn; fs = fs*fs;
-        double n1, n2;
-        if( fnorm < RKFD_DEV_TOL || fs < RKFD_DEV_TOL ){ n1 = 0; n2 = 0; }
-        else if( fnorm > fs ){ const double sc = fs*RKFD_RCP( fnorm ); n1 = ff0*sc; n2 = ff1*sc; }
-        else { n1 = ff0; n2 = ff1; }
-        const double d1 = BCAST( n1 - f1, c ), d2 = BCAST( n2 - f2, c );
-        if( lane == c ){ f1 = n1; f2 = n2; }
-        rn = fma( a0, d1, fma( b0, d2, rn ) );
-        r1 = fma( a1, d1, fma( b1, d2, r1 ) );
-        r2 = fma( a2, d1, fma( b2, d2, r2 ) );
-      }
-    }
+    /* up to 4 contacts: the lane's matrix rows in registers; up to 16: increments broadcast through the DPP operand of
+     * the FMA; more, or the packed matrix (worlds with more than 16 contacts; its index arithmetic in four-contact
+     * blocks costs registers the kernel does not have): the general loop.  Measured in isolation on the box
+     * (tools/ubench/pgs.hip, cycles per update, eleven waves per CU): 3 contacts 311 / 389 / 384 (registers / DPP /
+     * general), 8 contacts 312 / 369 (DPP / general), 16 contacts 270 / 317.  Variants with fewer VALU instructions
+     * (wave-uniform branches on the deciding lane instead of selects, one-lane moves under a narrowed EXEC) were
+     * slower (8 contacts: 333): the VALU -> SALU -> branch round trips sit on the dependent path. */
+    if( nc <= RKFD_PGS_NC ) rkfd_pgs_registers<pk>( L.MA, r0, ld, nc, m.max_iter, on, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
+    else if( !pk && nc <= RKFD_PGS_DPP_MAX ) rkfd_pgs_dpp<pk>( L.MA, r0, ld, nc, m.maxrg, m.max_iter, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
+    else rkfd_pgs_general<pk>( L.MA, r0, ld, nc, m.max_iter, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
     if( on ){ L.MF[r0] = fn/dt; L.MF[r0+1] = f1/dt; L.MF[r0+2] = f2/dt; }
   }
   SYNC();

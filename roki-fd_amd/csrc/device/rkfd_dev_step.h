@@ -115,6 +115,7 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDev
   m.npurow = RKFD_SPEC_NPUROW; m.pu_alias = RKFD_SPEC_PU_ALIAS; m.vert_rigid = RKFD_SPEC_VERT_RIGID; m.qscr_alias = RKFD_SPEC_QSCR_ALIAS;
   m.has_slide = RKFD_SPEC_HAS_SLIDE; m.ma_size = RKFD_SPEC_MA_SIZE; m.ma_packed = RKFD_SPEC_MA_PACKED;
   m.max_iter = RKFD_SPEC_MAX_ITER; m.solver = RKFD_SPEC_SOLVER; m.pyramid = RKFD_SPEC_PYRAMID; m.anchor = RKFD_SPEC_ANCHOR;
+  m.mlcp_mfma = RKFD_SPEC_MLCP_MFMA;
 #else
   const rkfdDevModel &m = m_;
 #endif

@@ -411,7 +411,7 @@ static std::string spec_source(const rkfdDevModel &d)
     "#define RKFD_SPEC_NPOOL %d\n#define RKFD_SPEC_NFLOAT %d\n#define RKFD_SPEC_MAXACT %d\n#define RKFD_SPEC_NSIDE %d\n"
     "#define RKFD_SPEC_NPUROW %d\n#define RKFD_SPEC_PU_ALIAS %d\n#define RKFD_SPEC_VERT_RIGID %d\n#define RKFD_SPEC_QSCR_ALIAS %d\n"
     "#define RKFD_SPEC_HAS_SLIDE %d\n#define RKFD_SPEC_MA_SIZE %d\n#define RKFD_SPEC_MA_PACKED %d\n"
-    "#define RKFD_SPEC_MAX_ITER %d\n#define RKFD_SPEC_SOLVER %d\n#define RKFD_SPEC_PYRAMID %d\n#define RKFD_SPEC_ANCHOR %d\n"
+    "#define RKFD_SPEC_MAX_ITER %d\n#define RKFD_SPEC_SOLVER %d\n#define RKFD_SPEC_PYRAMID %d\n#define RKFD_SPEC_ANCHOR %d\n#define RKFD_SPEC_MLCP_MFMA %d\n"
     "#include \"rkfd_device.h\"\n"
     "extern \"C\" __global__ void __launch_bounds__(64, 3)\n"
     "rkfd_step_kernel_spec(rkfdDevModel m, rkfdDevState st, int first, int mode, int nsteps, int *errflag)\n"
@@ -422,7 +422,7 @@ static std::string spec_source(const rkfdDevModel &d)
     "  rkfd_instance<false, %s, %s>( m, st, b, lds, mode, nsteps, errflag );\n"
     "}\n",
     d.nlink, d.ndof, d.ncand, d.nlink_model, d.nlevel, d.nround, d.nsched, d.maxrg, d.npool, d.nfloat, d.maxact, d.nside,
-    d.npurow, d.pu_alias, d.vert_rigid, d.qscr_alias, d.has_slide, d.ma_size, d.ma_packed, d.max_iter, d.solver, d.pyramid, d.anchor,
+    d.npurow, d.pu_alias, d.vert_rigid, d.qscr_alias, d.has_slide, d.ma_size, d.ma_packed, d.max_iter, d.solver, d.pyramid, d.anchor, d.mlcp_mfma,
     d.vert_rigid ? "true" : "false", d.ma_packed ? "true" : "false" );
   return std::string( buf );
 }

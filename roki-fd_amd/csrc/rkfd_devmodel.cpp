@@ -381,6 +381,7 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   for( int j=0; j<NC; j++ )
     if( m->ci_type[cci[j]] == RKFD_CONTACT_RIGID && !is_static[cA[j]] && !is_static[cB[j]] ) nside = 2;
   dm.maxact = maxact; dm.nside = nside;
+  { const char *e = getenv( "RKFD_MLCP_MFMA" ); dm.mlcp_mfma = ( e && atoi( e ) > 0 && 3*max_rigid <= 32 ) ? 1 : 0; }
   const size_t Mrows = 3*(size_t)max_rigid;
   /* probe scratch: one row per tree level plus six for a float root, per side; it overlays the
    * C|PA block of the link arrays (dead while the contact problem is solved) when it fits */

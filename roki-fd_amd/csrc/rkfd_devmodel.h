@@ -33,6 +33,8 @@ typedef struct {
   int npurow;            /* rows of PU per side: nlevel (+6 with a float joint)                         */
   int nside;             /* 1 when every rigid-capable pair has a static cell (probe walks one-sided) else 2 */
   int maxrg;             /* capacity: rigid contact vertices solved per instance (3*maxrg <= 128) */
+  int mlcp_mfma;         /* 1: the contact matrix A = N'N is formed with v_mfma_f64_16x16x4_f64 (worlds with at most 32 rows;
+                            measurement switch RKFD_MLCP_MFMA, see DESIGN.md "MFMA") */
   double dt, fric_w;
   /* per link */
   const int *parent, *jtype, *dofoff, *mtype, *depth, *is_static;

@@ -3,11 +3,12 @@
 #   kernel trace + stats, then FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes, then SQ counters.
 # usage: tools/collect_traffic.sh <workload> <tag>
 set -e
-W=${1:-config4}; TAG=${2:-r01}
+W=${1:-config4}; TAG=${2:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_${TAG}_${W}
 rm -rf $OUT && mkdir -p $OUT
-ARGS="bench.py --workload $W --steps 20 --warmup 5 --no-cpu-baseline"
+# counter passes: the driver's command, but one timed block only (--min-seconds 0): PMC collection serialises the dispatches
+ARGS="bench.py --workload $W --steps 20 --warmup 5 --no-cpu-baseline --min-seconds 0"
 # kernel trace + stats of the SAME command whose JSON line is reported (default steps / warmup), so that
 # the average kernel duration can be compared with bench.py's own HIP-event figure
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --workload $W > $OUT.bench.json 2> $OUT.trace.log
