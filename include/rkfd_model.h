@@ -25,7 +25,10 @@
 extern "C" {
 #endif
 
-enum { RKFD_JOINT_FIXED = 0, RKFD_JOINT_REVOL = 1, RKFD_JOINT_PRISM = 2, RKFD_JOINT_FLOAT = 3 };
+/* SPHER (3 DoF, angle-axis) and BRFLOAT (RoKi's breakable float joint: 6 DoF, rigid until a force / torque threshold is
+ * passed) are read by the loader so that every model the reference ships can be inspected; they have no device path
+ * (rkfdBatchCreate refuses a world that holds one, with a message) */
+enum { RKFD_JOINT_FIXED = 0, RKFD_JOINT_REVOL = 1, RKFD_JOINT_PRISM = 2, RKFD_JOINT_FLOAT = 3, RKFD_JOINT_SPHER = 4, RKFD_JOINT_BRFLOAT = 5 };
 enum { RKFD_MOTOR_NONE = 0, RKFD_MOTOR_TRQ = 1, RKFD_MOTOR_DC = 2 };
 /* contact-info type, cf. RK_CONTACT_RIGID / RK_CONTACT_ELASTIC (reference src/rkfd_cd.c:39-46) */
 enum { RKFD_CONTACT_RIGID = 0, RKFD_CONTACT_ELASTIC = 1 };
@@ -40,7 +43,7 @@ enum { RKFD_SOLVER_VERT = 0, RKFD_SOLVER_MLCP = 1, RKFD_SOLVER_VOLUME = 2 };
 
 static inline int rkfd_joint_dof(int jtype)
 {
-  return jtype == RKFD_JOINT_FLOAT ? 6 : ( jtype == RKFD_JOINT_FIXED ? 0 : 1 );
+  return ( jtype == RKFD_JOINT_FLOAT || jtype == RKFD_JOINT_BRFLOAT ) ? 6 : ( jtype == RKFD_JOINT_SPHER ? 3 : ( jtype == RKFD_JOINT_FIXED ? 0 : 1 ) );
 }
 
 typedef struct {

@@ -104,15 +104,25 @@ void rkFDSolverDestroy(rkFDSolver *solver);
 #define rkFDSolverUpdate(s,b)                (s)->com->_update(s,b)
 #define rkFDSolverUpdatePrevDrivingTrq(s)    (s)->com->_update_ref(s)
 #define rkFDSolverUpdateDestroy(s)           (s)->com->_destroy(s)
-/* plugins with a device path.  Vert: penalty (ELASTIC) contacts only - its rigid QP branch
- * has no device path and is reported as an error by rkFDUpdate; MLCP: penalty + rigid PGS. */
+/* plugins with a device path.  Vert (the reference's default): penalty (ELASTIC) contacts + the rigid branch with
+ * friction pyramids and the active-set QP (reference src/rkfd_vert.c:258-336); MLCP: penalty + rigid PGS.
+ * Volume: the table exists so that rkFDSetSolver( &fd, Volume ) compiles as in the reference's drivers; elastic pairs
+ * run through the shared penalty path, a RIGID pair has no device path under it and is reported by rkFDUpdate
+ * (status 1, message on stderr) - nothing is approximated silently.
+ * The table is the reference's (same six entries, same call protocol); what differs: `fd` stands where the reference
+ * has `rkFDChainArray chains`, _colchk / _update_ref do nothing (collision detection and the previous driving
+ * torque are part of the device step) and rkFDUpdate launches the fused device step instead of walking the table per
+ * evaluation - so a third-party plugin written against the reference's table cannot be plugged in here; the boundary
+ * of this build is the rkFDUpdate level. */
 rkFDSolver *rkFDSolverCreate_Vert(rkFDSolver *s);
 rkFDSolver *rkFDSolverCreate_MLCP(rkFDSolver *s);
+rkFDSolver *rkFDSolverCreate_Volume(rkFDSolver *s);
 
 /* ---- rkFD (reference include/roki_fd/rkfd_sim.h:24-52) ----------------------------------- */
 typedef struct _rkFDCell {
   rkChain chain;
   struct _rkFDCell *next;
+  struct _zShape3D *shape;   /* [number of shapes of the chain] handles for the slide-mode calls */
 } rkFDCell;
 #define rkFDCellChain(c) ( &(c)->chain )
 
@@ -140,18 +150,47 @@ void rkFDDestroy(rkFD *fd);
 rkFDCell *rkFDChainReg(rkFD *fd, rkChain *chain);
 rkFDCell *rkFDChainRegFile(rkFD *fd, char filename[]);
 bool rkFDChainUnreg(rkFD *fd, rkFDCell *cell);
-/* slide mode of a collision cell (fake crawler; reference rkFDShape3DSetSlideMode / Vel / Axis, src/rkfd_sim.c:412-440):
- * the shape is named by its number in the cell's chain; axis in the link frame */
-bool rkFDCellSetSlide(rkFDCell *cell, int shape, bool mode, double vel, const double axis[3]);
+/* slide mode of a collision cell (fake crawler; reference src/rkfd_sim.c:384-440, include/roki_fd/rkfd_sim.h:74-80).
+ * zShape3D / rkCDCell are handles here: rkFDCellShape( cell, i ) names shape number i of the cell's chain (its order
+ * in the ZTK file), the collision cell of a shape is the shape itself.  Axis in the link frame. */
+typedef struct { double e[3]; } zVec3D;
+typedef struct _zShape3D { struct _rkFDCell *cell; int index; } zShape3D;
+typedef zShape3D rkCDCell;
+zShape3D *rkFDCellShape(struct _rkFDCell *cell, int i);
+int rkFDCellShapeNum(struct _rkFDCell *cell);
+void rkFDCDCellSetSlideMode(rkCDCell *cell, bool mode);
+void rkFDCDCellSetSlideVel(rkCDCell *cell, double vel);
+void rkFDCDCellSetSlideAxis(rkCDCell *cell, zVec3D *axis);
+rkCDCell *rkFDShape3DGetCDCell(struct _rkFD *fd, zShape3D *shape);
+rkCDCell *rkFDShape3DSetSlideMode(struct _rkFD *fd, zShape3D *shape, bool mode);
+rkCDCell *rkFDShape3DSetSlideVel(struct _rkFD *fd, zShape3D *shape, double vel);
+rkCDCell *rkFDShape3DSetSlideAxis(struct _rkFD *fd, zShape3D *shape, zVec3D *axis);
+/* all three at once, the shape named by its number */
+bool rkFDCellSetSlide(struct _rkFDCell *cell, int shape, bool mode, double vel, const double axis[3]);
 void rkFDChainSetDis(rkFDCell *lc, zVec dis);
 void rkFDChainSetVel(rkFDCell *lc, zVec vel);
 bool rkFDContactInfoScanFile(rkFD *fd, char filename[]);
 /* rkCDPairChainUnreg( rkFDCDBase(&fd.cd), chain ) as in reference example/chain/boxdrop_test.c:37 */
 void rkCDPairChainUnreg(rkFDCD *cd, rkChain *chain);
 
-/* only the reference's default integrator (Regular + RKG, reference src/rkfd_sim.c:46-47) exists here */
-#define rkFDODE2Assign(f,t)        ((void)0)
-#define rkFDODE2AssignRegular(f,t) ((void)0)
+/* rkFDFK / rkFDUpdateRate / rkFDUpdateFKRate (reference src/rkfd_sim.c:344-384): in the reference they push a packed
+ * state into the chains' link frames / rates on the host.  Link frames and rates live on the device here and are
+ * recomputed from the packed state by every evaluation, so these calls set the packed state the next
+ * rkFDUpdateInit / rkFDUpdate starts from (dis; vel and acc) - there is no host-side kinematics to refresh. */
+void rkFDFK(rkFD *fd, zVec dis);
+void rkFDUpdateRate(rkFD *fd, zVec vel, zVec acc);
+void rkFDUpdateFKRate(rkFD *fd);
+/* rkChainFPrintZTK of every registered chain at its current joint displacements (reference src/rkfd_sim.c:587-593) */
+void rkFDPrint(rkFD *fd);
+void rkFDFPrintZTK(FILE *fp, rkFD *fd);
+
+/* The device step integrates with the reference's default scheme only (zODE2 "Regular" wrapper + Runge-Kutta-Gill,
+ * reference src/rkfd_sim.c:46-47), which is what every driver of the reference assigns.  Asking for another one is
+ * NOT ignored: a message goes to stderr, rkFDStatus reports -2 until a supported scheme is assigned, and
+ * rkFDUpdateInit / rkFDUpdate refuse to run - a caller never gets RKG results under another integrator's name. */
+void rkfd_ode2_assign(rkFD *fd, const char *what, const char *type);
+#define rkFDODE2Assign(f,t)        rkfd_ode2_assign( f, "rkFDODE2Assign", #t )
+#define rkFDODE2AssignRegular(f,t) rkfd_ode2_assign( f, "rkFDODE2AssignRegular", #t )
 
 #define rkFDSetSolver(f,type) do{                                 \
     rkFDSolverReset( &(f)->solver );                              \
@@ -194,6 +233,8 @@ int  rkfdWorldChainDofOffset(const rkfdWorldHandle *w, int chain);
 int  rkfdWorldChainLinkOffset(const rkfdWorldHandle *w, int chain);
 /* joint displacements of the chain's [roki::chain::init] section; returns the chain's dof */
 int  rkfdWorldChainInitDis(const rkfdWorldHandle *w, int chain, double *dis);
+/* the chain written back in ZTK format (rkChainFPrintZTK); dis may be NULL (the file's [roki::chain::init]); 0 / -1 */
+int  rkfdWorldWriteZTK(const rkfdWorldHandle *w, int chain, const char *filename, const double *dis);
 
 #ifdef __cplusplus
 }

@@ -72,6 +72,8 @@ class Oracle:
         m = model_ptr.contents
         self.ndof, self.nlink, self.ncand = m.ndof, m.nlink, m.ncand
         self._o = self._L.rkfdOracleCreate(C.cast(model_ptr, C.c_void_p))
+        if not self._o:
+            raise RuntimeError("the oracle does not cover this world (spherical / breakable-float joint)")
 
     def close(self):
         if getattr(self, "_o", None):

@@ -145,8 +145,12 @@ static void *zalloc(size_t n){ return calloc( n ? n : 1, 1 ); }
 
 rkfdOracle *rkfdOracleCreate(const rkfdModel *m)
 {
-  rkfdOracle *o = (rkfdOracle *)zalloc( sizeof(rkfdOracle) );
+  rkfdOracle *o;
   int i, j, nl = m->nlink, n = m->ndof, nc = m->ncand, k;
+
+  for( i=0; i<nl; i++ )      /* joint types the loader reads but this restatement (like the device path) does not cover */
+    if( m->jtype[i] == RKFD_JOINT_SPHER || m->jtype[i] == RKFD_JOINT_BRFLOAT ) return NULL;
+  o = (rkfdOracle *)zalloc( sizeof(rkfdOracle) );
 
   o->m = m; o->nl = nl; o->n = n; o->ncand = nc;
   o->dis = zalloc( sizeof(double)*n ); o->vel = zalloc( sizeof(double)*n ); o->acc = zalloc( sizeof(double)*n );

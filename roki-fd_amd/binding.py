@@ -76,6 +76,7 @@ def lib():
     L.rkfdWorldChainDofOffset.argtypes = [vp, C.c_int]
     L.rkfdWorldChainLinkOffset.argtypes = [vp, C.c_int]
     L.rkfdWorldChainInitDis.argtypes = [vp, C.c_int, _pd]
+    L.rkfdWorldWriteZTK.argtypes = [vp, C.c_int, C.c_char_p, _pd]
     L.rkfdHipLastError.restype = C.c_char_p
     L.rkfdBatchCreate.argtypes = [C.POINTER(RkfdModel), C.c_int, C.c_int, C.c_int]
     L.rkfdBatchCreate.restype = vp

@@ -14,6 +14,7 @@ typedef struct {
   int dirty;          /* host state newer than device state */
   int status;
   int ncell;
+  int bad_ode;        /* an integrator without a device path was asked for (rkFDODE2Assign*) */
 } rkFDImpl;
 
 typedef struct { int kind; int max_rigid; } rkFDSolverPrpAMD;
@@ -138,6 +139,12 @@ static void solver_destroy(rkFDSolver *s)
   rkFDImpl *im = IMPL( s->fd );
   if( im->batch ){ rkfdBatchDestroy( im->batch ); im->batch = NULL; }
 }
+static void defci_volume(rkFDSolver *s, rkContactInfo *ci)
+{ /* reference src/rkfd_volume.c:942-950 */
+  (void)s; memset( ci, 0, sizeof(*ci) );
+  ci->type = RKFD_CONTACT_RIGID; ci->k = 1000.0; ci->l = 0.001; ci->sf = 0.5; ci->kf = 0.3;
+}
+static rkFDSolverCom rkfd_solver_Volume = { defci_volume, solver_init, solver_colchk, solver_update, solver_update_ref, solver_destroy };
 static rkFDSolverCom rkfd_solver_Vert = { defci_vert, solver_init, solver_colchk, solver_update, solver_update_ref, solver_destroy };
 static rkFDSolverCom rkfd_solver_MLCP = { defci_mlcp, solver_init, solver_colchk, solver_update, solver_update_ref, solver_destroy };
 
@@ -151,6 +158,13 @@ static rkFDSolver *solver_create(rkFDSolver *s, int kind, rkFDSolverCom *com)
 }
 rkFDSolver *rkFDSolverCreate_Vert(rkFDSolver *s){ return solver_create( s, RKFD_SOLVER_VERT, &rkfd_solver_Vert ); }
 rkFDSolver *rkFDSolverCreate_MLCP(rkFDSolver *s){ return solver_create( s, RKFD_SOLVER_MLCP, &rkfd_solver_MLCP ); }
+/* Volume: elastic pairs only on the device (penalty); a rigid pair is reported by the device step (status 1) */
+rkFDSolver *rkFDSolverCreate_Volume(rkFDSolver *s)
+{
+  rkFDSolver *r = solver_create( s, RKFD_SOLVER_VOLUME, &rkfd_solver_Volume );
+  if( r ) ( (rkFDSolverPrpAMD *)r->prp )->max_rigid = 0;
+  return r;
+}
 
 /* ---- rkFD --------------------------------------------------------------------------- */
 rkFD *rkFDCreate(rkFD *fd)
@@ -177,7 +191,7 @@ void rkFDDestroy(rkFD *fd)
   if( !im ) return;
   if( im->batch ) rkfdBatchDestroy( im->batch );
   rkFDSolverDestroy( &fd->solver );
-  for( c=fd->list; c; c=n ){ n = c->next; free( c->chain.joint ); free( c ); }
+  for( c=fd->list; c; c=n ){ n = c->next; free( c->chain.joint ); free( c->shape ); free( c ); }
   zVecFree( fd->dis ); zVecFree( fd->vel ); zVecFree( fd->acc );
   rkfdWorldDestroy( &im->world );
   free( im->motor_in );
@@ -200,6 +214,8 @@ static rkFDCell *cell_push(rkFD *fd, rkfdChainDesc *cd)
   lc->chain.fd = fd; lc->chain.id = id; lc->chain.nlink = cd->nlink; lc->chain.ndof = cd->ndof;
   lc->chain.joint = (rkJoint *)calloc( cd->nlink, sizeof(rkJoint) );
   for( i=0; i<cd->nlink; i++ ){ lc->chain.joint[i].chain = &lc->chain; lc->chain.joint[i].link = i; }
+  lc->shape = (zShape3D *)calloc( cd->nshape > 0 ? cd->nshape : 1, sizeof(zShape3D) );
+  for( i=0; i<cd->nshape; i++ ){ lc->shape[i].cell = lc; lc->shape[i].index = i; }
   for( tail=&fd->list; *tail; tail=&(*tail)->next );
   *tail = lc;
   /* grow the packed joint state (reference src/rkfd_sim.c:79-110) */
@@ -267,7 +283,7 @@ bool rkFDChainUnreg(rkFD *fd, rkFDCell *cell)
   for( c=lc->next; c; c=c->next ){ c->chain.id--; c->chain.link_off -= nl; c->chain.dof_off -= nd; }
   *pp = lc->next;
   rkfdWorldRemoveChain( &im->world, lc->chain.id );
-  free( lc->chain.joint ); free( lc );
+  free( lc->chain.joint ); free( lc->shape ); free( lc );
   if( im->batch ){ rkfdBatchDestroy( im->batch ); im->batch = NULL; }
   im->dirty = 1; im->ncell--;
   return true;
@@ -337,9 +353,72 @@ static void report(rkFD *fd)
   if( im->status != 0 ) fprintf( stderr, "rkfd: %s\n", rkfdHipLastError() );
 }
 
+/* rkFDODE2Assign / rkFDODE2AssignRegular: only "Regular" + "RKG" have a device path (see roki_fd_amd.h) */
+void rkfd_ode2_assign(rkFD *fd, const char *what, const char *type)
+{
+  rkFDImpl *im = IMPL( fd );
+  const int ok = strcmp( what, "rkFDODE2Assign" ) == 0 ? strcmp( type, "Regular" ) == 0 : strcmp( type, "RKG" ) == 0;
+  if( !ok ){
+    fprintf( stderr, "rkfd: %s( fd, %s ): this integrator has no device path (only Regular + RKG, the reference's default); updates are refused until a supported one is assigned\n", what, type );
+    im->bad_ode |= strcmp( what, "rkFDODE2Assign" ) == 0 ? 1 : 2;
+    im->status = -2;
+  } else {
+    im->bad_ode &= strcmp( what, "rkFDODE2Assign" ) == 0 ? ~1 : ~2;
+    if( !im->bad_ode && im->status == -2 ) im->status = 0;
+  }
+}
+
+void rkFDFK(rkFD *fd, zVec dis)
+{
+  if( !dis || dis->size < fd->size ) return;
+  memcpy( fd->dis->buf, dis->buf, sizeof(double)*fd->size );
+  IMPL( fd )->dirty = 1;
+}
+void rkFDUpdateRate(rkFD *fd, zVec vel, zVec acc)
+{
+  if( vel && vel->size >= fd->size ) memcpy( fd->vel->buf, vel->buf, sizeof(double)*fd->size );
+  if( acc && acc->size >= fd->size ) memcpy( fd->acc->buf, acc->buf, sizeof(double)*fd->size );
+  IMPL( fd )->dirty = 1;
+}
+void rkFDUpdateFKRate(rkFD *fd){ IMPL( fd )->dirty = 1; }
+
+void rkFDFPrintZTK(FILE *fp, rkFD *fd)
+{
+  rkFDImpl *im = IMPL( fd );
+  rkFDCell *lc;
+  for( lc=fd->list; lc; lc=lc->next )
+    rkfdChainWriteZTK( fp, im->world.chain[lc->chain.id], fd->dis ? fd->dis->buf + lc->chain.dof_off : NULL );
+}
+void rkFDPrint(rkFD *fd){ rkFDFPrintZTK( stdout, fd ); }
+
+/* slide mode through the reference's names (handles: see roki_fd_amd.h) */
+zShape3D *rkFDCellShape(rkFDCell *cell, int i)
+{
+  rkFDImpl *im = IMPL( cell->chain.fd );
+  return ( i >= 0 && i < im->world.chain[cell->chain.id]->nshape ) ? &cell->shape[i] : NULL;
+}
+int rkFDCellShapeNum(rkFDCell *cell){ return IMPL( cell->chain.fd )->world.chain[cell->chain.id]->nshape; }
+static rkfdShape *cd_shape(rkCDCell *c)
+{
+  rkFDImpl *im = IMPL( c->cell->chain.fd );
+  im->world.built = 0; im->dirty = 1;
+  return &im->world.chain[c->cell->chain.id]->shape[c->index];
+}
+void rkFDCDCellSetSlideMode(rkCDCell *cell, bool mode){ if( cell ) cd_shape( cell )->slide_mode = mode ? 1 : 0; }
+void rkFDCDCellSetSlideVel(rkCDCell *cell, double vel){ if( cell ) cd_shape( cell )->slide_vel = vel; }
+void rkFDCDCellSetSlideAxis(rkCDCell *cell, zVec3D *axis){ if( cell && axis ) memcpy( cd_shape( cell )->slide_axis, axis->e, sizeof(double)*3 ); }
+rkCDCell *rkFDShape3DGetCDCell(rkFD *fd, zShape3D *shape){ return ( shape && shape->cell && shape->cell->chain.fd == fd ) ? shape : NULL; }
+rkCDCell *rkFDShape3DSetSlideMode(rkFD *fd, zShape3D *shape, bool mode)
+{ rkCDCell *c = rkFDShape3DGetCDCell( fd, shape ); if( c ) rkFDCDCellSetSlideMode( c, mode ); return c; }
+rkCDCell *rkFDShape3DSetSlideVel(rkFD *fd, zShape3D *shape, double vel)
+{ rkCDCell *c = rkFDShape3DGetCDCell( fd, shape ); if( c ) rkFDCDCellSetSlideVel( c, vel ); return c; }
+rkCDCell *rkFDShape3DSetSlideAxis(rkFD *fd, zShape3D *shape, zVec3D *axis)
+{ rkCDCell *c = rkFDShape3DGetCDCell( fd, shape ); if( c ) rkFDCDCellSetSlideAxis( c, axis ); return c; }
+
 void rkFDUpdateInit(rkFD *fd)
 {
   rkFDImpl *im = IMPL( fd );
+  if( im->bad_ode ){ fprintf( stderr, "rkfd: rkFDUpdateInit refused: an integrator without a device path is assigned\n" ); im->status = -2; return; }
   im->dirty = 1;
   if( !rkFDSolverUpdateInit( &fd->solver ) ){ im->status = -1; return; }
   if( sync_to_device( fd ) < 0 || rkfdBatchUpdateInit( im->batch, NULL ) < 0 ){
@@ -354,6 +433,7 @@ void rkFDUpdateInit(rkFD *fd)
 rkFD *rkFDUpdate(rkFD *fd)
 {
   rkFDImpl *im = IMPL( fd );
+  if( im->bad_ode ){ fprintf( stderr, "rkfd: rkFDUpdate refused: an integrator without a device path is assigned\n" ); im->status = -2; return fd; }
   if( !im->batch ){
     fprintf( stderr, "rkfd: rkFDUpdate called without a device batch (rkFDUpdateInit failed or missing)\n" );
     im->status = -1;
@@ -435,6 +515,14 @@ const rkfdModel *rkfdWorldModel(rkfdWorld *w)
 {
   if( !w->built && rkfdWorldBuild( w ) < 0 ) return NULL;
   return &w->model;
+}
+int rkfdWorldWriteZTK(const rkfdWorld *w, int chain, const char *filename, const double *dis)
+{
+  FILE *fp;
+  if( chain < 0 || chain >= w->nchain || !( fp = fopen( filename, "w" ) ) ) return -1;
+  rkfdChainWriteZTK( fp, w->chain[chain], dis );
+  fclose( fp );
+  return 0;
 }
 int rkfdWorldChainInitDis(const rkfdWorld *w, int chain, double *dis)
 {

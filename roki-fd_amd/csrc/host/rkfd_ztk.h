@@ -5,16 +5,18 @@
  * not available here, so this is an independent reader of the same text
  * format, restricted to the tags/keys used by the models the path is run on:
  *   [roki::chain] name
- *   [zeo::shape]  name type(box|polyhedron) center depth width height vert face
+ *   [zeo::shape]  name type(box|polyhedron|sphere|cylinder|cone) center depth width height radius div vert face
  *   [roki::motor] name type(dc|trq) motorconstant admittance maxvoltage minvoltage
  *                 gearratio rotorinertia gearinertia max min
- *   [roki::link]  name jointtype mass stuff COM inertia frame pos att parent shape motor
- *                 stiffness viscosity coulomb staticfriction
+ *   [roki::link]  name jointtype(fixed|revolute|prismatic|float|spherical|breakablefloat) mass stuff COM inertia frame
+ *                 pos att parent shape motor stiffness viscosity coulomb staticfriction forcethreshold torquethreshold
  *   [roki::chain::init] joint
  *   [roki::contact] bind staticfriction kineticfriction compensation relaxation
  *                 elasticity viscosity
- * Other tags ([zeo::optic] ...) and keys are skipped.  Non-convex or curved
- * shapes (cylinder, sphere, cone ...) are skipped with a note (out of scope).
+ * Other tags ([zeo::optic] ...) and keys are skipped.  The curved primitives (sphere, cylinder, cone) become the convex
+ * polyhedra Zeo's zShape3DToPH would make of them with `div` divisions (default 32) [UNVERIFIED-DEP: the exact vertex
+ * placement of Zeo's tessellation]; `COM: auto` / `inertia: auto` are computed from the link's shapes (uniform density).
+ * rkfdChainWriteZTK writes a chain back in the same format (the role of rkChainFPrintZTK, reference src/rkfd_sim.c:587-593).
  */
 #ifndef RKFD_ZTK_H
 #define RKFD_ZTK_H
@@ -23,12 +25,18 @@
 
 #define RKFD_NAME_MAX 64
 
+enum { RKFD_SHAPE_NONE = 0, RKFD_SHAPE_BOX = 1, RKFD_SHAPE_PH = 2, RKFD_SHAPE_SPHERE = 3, RKFD_SHAPE_CYLINDER = 4, RKFD_SHAPE_CONE = 5 };
 typedef struct {
   char name[RKFD_NAME_MAX];
   int nvert;
   double *vert;      /* [nvert*3] link frame */
   int nplane;
   double *plane;     /* [nplane*4] outward unit normal + offset */
+  int nface;
+  int *face;         /* [nface*3] triangles (vertex indices), kept for the writer and the auto mass properties */
+  int ptype;         /* what the file said: RKFD_SHAPE_* */
+  double prm[8];     /* box: center(3) depth width height; sphere: center(3) radius; cylinder / cone: two points (6) radius */
+  int div;
   /* slide mode of the shape's collision cell (fake crawler; reference src/rkfd_sim.c:384-440): off by default */
   int slide_mode; double slide_vel, slide_axis[3];
 } rkfdShape;
@@ -49,6 +57,8 @@ typedef struct {
   double mass, com[3], inertia[9];
   double org[12];    /* R(9 row-major) p(3) */
   double stiff, visc, coulomb, sfric;
+  double ep_f, ep_t; /* breakable float joint: force / torque thresholds */
+  int auto_com, auto_inertia;   /* "COM: auto" / "inertia: auto" were given (resolved when the chain is read) */
   int motor;         /* index into chain motors, -1 none */
   int nshape;
   int shape[8];      /* indices into chain shapes */
@@ -72,6 +82,8 @@ typedef struct {
 /* returns NULL on failure (message on stderr), like rkChainReadZTK */
 rkfdChainDesc *rkfdChainReadZTK(const char *filename);
 void rkfdChainDescFree(rkfdChainDesc *c);
+/* writes the chain in ZTK format; dis (may be NULL) goes into [roki::chain::init].  The role of rkChainFPrintZTK. */
+void rkfdChainWriteZTK(FILE *fp, const rkfdChainDesc *c, const double *dis);
 /* deep copy (the role of rkChainClone in reference src/rkfd_sim.c:217); NULL on allocation failure */
 rkfdChainDesc *rkfdChainDescClone(const rkfdChainDesc *c);
 

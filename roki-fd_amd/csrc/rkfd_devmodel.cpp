@@ -34,8 +34,11 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   if( NC > RKFD_MAX_CAND ) FAIL( "ncand %d exceeds the per-wave limit %d", NC, RKFD_MAX_CAND );
   if( max_rigid < 0 ) max_rigid = 0;
   if( 3*max_rigid > RKFD_MAX_ROWS ) FAIL( "3*max_rigid %d exceeds the per-wave limit %d", 3*max_rigid, RKFD_MAX_ROWS );
-  for( int i=0; i<NLm; i++ )
+  for( int i=0; i<NLm; i++ ){
+    if( m->jtype[i] == RKFD_JOINT_SPHER || m->jtype[i] == RKFD_JOINT_BRFLOAT )
+      FAIL( "link %d has a %s joint: read by the loader, but without a device path (DESIGN.md, out of scope)", i, m->jtype[i] == RKFD_JOINT_SPHER ? "spherical" : "breakable float" );
     if( m->parent[i] >= i ) FAIL( "link %d: parent index must be smaller than the link index", i );
+  }
 
   /* ---- merge rigidly attached links ------------------------------------------------------
    * A link on a FIXED joint moves with its parent: it is folded into the nearest ancestor that is

@@ -72,24 +72,114 @@ def test_chain_reg_clone_unreg_in_c(R, tmp_path):
     assert out[3] == "model nlink 33 ndof 36 ncand 16"                    # chain 31 + floor 1 + cloned box 1; box x floor candidates
 
 
+def test_reference_api_names_in_c(R, tmp_path):
+    """the names of reference include/roki_fd/rkfd_sim.h:65-67,74-80,85-93 and rkFDPrint (src/rkfd_sim.c:587-593) through
+    include/roki_fd_amd.h, from C, without a GPU: another integrator than Regular + RKG is refused loudly (it
+    used to be a silent no-op), rkFDSetSolver( &fd, Volume ) compiles and carries the reference's default contact info"""
+    import subprocess
+    root = os.path.join(os.path.dirname(__file__), "..")
+    exe = str(tmp_path / "api_surface")
+    subprocess.run(["gcc", "-O1", "-Wall", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "c", "api_surface.c"),
+                    "-L" + os.path.join(root, "roki-fd_amd"), "-lrkfd_amd", "-Wl,-rpath," + os.path.join(root, "roki-fd_amd"), "-o", exe], check=True)
+    r = subprocess.run([exe, os.path.join(root, "models"), str(tmp_path / "printed.ztk")], check=True, capture_output=True, text=True)
+    out = r.stdout.splitlines()
+    assert out[0] == "status after Regular + RKG: 0"
+    assert out[1] == "status after RK4: -2" and "no device path" in r.stderr
+    assert out[2] == "time after the refused update: 0"
+    assert out[3] == "status after RKG again: 0"
+    assert out[4] == "Volume default relaxation 0.001"
+    assert out[5] == "box shapes 1" and out[6] == "slide cell found"
+    assert out[7] == "slide mode 1 vel 0.25 axis 0 0 1"
+    assert out[8] == "dis[7] 0.08 vel[7] -0.16"
+    assert out[9] == "read back: ok, size 4"
+    assert "joint: forearm 0.125" in open(tmp_path / "printed.ztk").read() or "0.125" in open(tmp_path / "printed.ztk").read()
+
+
 REF_MODELS = "/root/reference/example/model"
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_MODELS), reason="reference checkout not present (it never is on the GPU box)")
 def test_reader_loads_the_reference_shipped_models(R):
-    """the independent ZTK reader against the reference's own example models (read as data): every
-    model whose joints are fixed / revolute / prismatic / float loads; spherical and breakable-float
-    joints are reported as unsupported, not mis-read"""
+    """the independent ZTK reader against the reference's own example models (read as data): all 12 load - curved
+    primitives (sphere / cylinder / cone) as convex polyhedra, `COM: auto` / `inertia: auto` from the shapes,
+    spherical (3 DoF) and breakable-float (6 DoF) joints with their sizes.  Worlds with the last two are refused by
+    the device path with a message, not mis-simulated."""
     expect = {"arm_2DoF.ztk": (3, 2), "arm_2DoF_trq.ztk": (3, 2), "box.ztk": (1, 6), "box_small.ztk": (1, 6), "crawler.ztk": (3, 6),
-              "floor.ztk": (1, 0), "floor_hardsoft.ztk": (2, 0), "mighty.ztk": (25, 26), "puma.ztk": (7, 6)}
-    for f, (nl, nd) in expect.items():
+              "floor.ztk": (1, 0), "floor_hardsoft.ztk": (2, 0), "mighty.ztk": (25, 26), "puma.ztk": (7, 6),
+              "arm.ztk": (6, 12), "dualarm.ztk": None, "wall.ztk": None}
+    for f, dims in expect.items():
         w = R.World()
         w.reg_file(os.path.join(REF_MODELS, f))
         m = w.model.contents
-        assert (m.nlink, m.ndof) == (nl, nd), f
-    for f in ("arm.ztk", "dualarm.ztk", "wall.ztk"):
-        with pytest.raises(R.RkfdError):
-            R.World().reg_file(os.path.join(REF_MODELS, f))
+        if dims is not None:
+            assert (m.nlink, m.ndof) == dims, f
+        assert m.nlink > 0 and np.isfinite(m.arr("mass", m.nlink)).all() and np.isfinite(m.arr("inertia", 9 * m.nlink)).all()
+    # puma.ztk: every link carries curved shapes; they arrive as convex vertex sets with face planes
+    w = R.World(); w.reg_file(os.path.join(REF_MODELS, "puma.ztk")); m = w.model.contents
+    assert m.nshape == 7
+    voff = m.arr("shape_voff", m.nshape + 1); foff = m.arr("shape_foff", m.nshape + 1)
+    assert (np.diff(voff) >= 8).all() and (np.diff(foff) >= 6).all()
+    verts = m.arr("verts", 3 * voff[-1]).reshape(-1, 3); planes = m.arr("planes", 4 * foff[-1]).reshape(-1, 4)
+    convex = 0
+    for sh in range(m.nshape):                      # convex: every vertex on the inner side of every face plane
+        v = verts[voff[sh]:voff[sh + 1]]; p = planes[foff[sh]:foff[sh + 1]]
+        convex += int((v @ p[:, :3].T - p[:, 3] < 1e-9).all())
+    assert convex >= 6          # the sphere, the cylinders, the cone and the forearm prism; the upper arm's loop has one reflex corner (the reader says so)
+    # arm.ztk: `COM: auto` / `inertia: auto` of a link made of a sphere and a cylinder: positive definite, COM inside
+    w = R.World(); w.reg_file(os.path.join(REF_MODELS, "arm.ztk")); m = w.model.contents
+    I = m.arr("inertia", 9 * m.nlink).reshape(-1, 3, 3)
+    for i in range(1, m.nlink):
+        assert np.allclose(I[i], I[i].T) and (np.linalg.eigvalsh(I[i]) > 0).all()
+    # spherical / breakable-float joints: read, but refused by the device path (and the oracle) with a message
+    for f in ("arm.ztk", "wall.ztk"):
+        w = R.World(); w.reg_file(os.path.join(REF_MODELS, f))
+        assert R.lib().rkfdLdsBytesFor(w.model, 0) < 0
+        assert b"joint" in R.lib().rkfdHipLastError()
+
+
+def test_auto_mass_properties_of_a_box(R, tmp_path):
+    """`COM: auto` / `inertia: auto`: a 0.2 x 0.4 x 0.6 box of mass 3 off the origin - closed form m/12 (b^2 + c^2) ..."""
+    f = tmp_path / "b.ztk"
+    f.write_text("[roki::chain]\nname: b\n[zeo::shape]\nname: s\ntype: box\ncenter: 0.1, -0.2, 0.3\ndepth: 0.2\nwidth: 0.4\nheight: 0.6\n"
+                 "[roki::link]\nname: l\njointtype: float\nmass: 3.0\nCOM: auto\ninertia: auto\nshape: s\n")
+    w = R.World(); w.reg_file(str(f)); m = w.model.contents
+    assert np.allclose(m.arr("com", 3), (0.1, -0.2, 0.3), atol=1e-14)
+    assert np.allclose(m.arr("inertia", 9).reshape(3, 3), np.diag([3 / 12 * (0.16 + 0.36), 3 / 12 * (0.04 + 0.36), 3 / 12 * (0.04 + 0.16)]), atol=1e-14)
+
+
+def test_malformed_polyhedron_is_refused(R, tmp_path):
+    """a negative vertex index or a face naming a vertex that does not exist fails the load with a
+    message instead of corrupting the heap"""
+    head = "[roki::chain]\nname: b\n[zeo::shape]\nname: s\ntype: polyhedron\n"
+    tail = "[roki::link]\nname: l\njointtype: float\nmass: 1\nshape: s\n"
+    good = "vert: 0 { 0, 0, 0 }\nvert: 1 { 1, 0, 0 }\nvert: 2 { 0, 1, 0 }\nvert: 3 { 0, 0, 1 }\nface: 0 1 2\nface: 0 1 3\nface: 0 2 3\nface: 1 2 3\n"
+    for body, ok in ((good, True), (good.replace("vert: 3", "vert: -3"), False), (good + "face: 1 2 7\n", False), (good + "face: 1 -2 3\n", False)):
+        f = tmp_path / "p.ztk"; f.write_text(head + body + tail)
+        if ok:
+            R.World().reg_file(str(f))
+        else:
+            with pytest.raises(R.RkfdError):
+                R.World().reg_file(str(f))
+
+
+def test_ztk_writer_round_trip(R, tmp_path):
+    """rkfdWorldWriteZTK (the role of rkChainFPrintZTK / rkFDPrint, reference src/rkfd_sim.c:587-593): a chain written
+    and read back gives the same flattened model, bit for bit, and carries the joint displacements handed to the writer"""
+    for name in ("humanoid30.ztk", "arm_revroot.ztk", "box.ztk", "floor_hardsoft.ztk"):
+        w = R.World(); c = w.reg_file(os.path.join(R.scenarios.MODELS, name)); m = w.model.contents
+        dis = np.linspace(0.1, 0.9, m.ndof) if m.ndof else np.zeros(1)
+        out = str(tmp_path / ("w_" + name))
+        assert R.lib().rkfdWorldWriteZTK(w._w, c, out.encode(), dis.ctypes.data_as(R.binding._pd)) == 0
+        w2 = R.World(); c2 = w2.reg_file(out); m2 = w2.model.contents
+        assert (m.nlink, m.ndof, m.nshape) == (m2.nlink, m2.ndof, m2.nshape)
+        for fld, n in (("parent", m.nlink), ("jtype", m.nlink), ("mtype", m.nlink), ("org", 12 * m.nlink), ("mass", m.nlink), ("com", 3 * m.nlink),
+                       ("inertia", 9 * m.nlink), ("sfric", m.nlink), ("coulomb", m.nlink), ("mot_k", m.nlink), ("mot_gear", m.nlink), ("mot_inertia", m.nlink),
+                       ("shape_link", m.nshape), ("shape_voff", m.nshape + 1), ("shape_foff", m.nshape + 1)):
+            assert np.array_equal(m.arr(fld, n), m2.arr(fld, n)), (name, fld)
+        nv = m.arr("shape_voff", m.nshape + 1)[-1]; npl = m.arr("shape_foff", m.nshape + 1)[-1]
+        assert np.array_equal(m.arr("verts", 3 * nv), m2.arr("verts", 3 * nv)) and np.allclose(m.arr("planes", 4 * npl), m2.arr("planes", 4 * npl), atol=1e-15)
+        if m.ndof:
+            assert np.array_equal(w2.init_dis(c2), dis)
 
 
 def test_specialized_step_kernel_compiles_without_a_gpu(R):
