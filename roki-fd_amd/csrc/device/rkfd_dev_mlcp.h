@@ -142,6 +142,50 @@ template<bool pk> RKFD_DEV void rkfd_pgs_dpp(const double *MA, int r0, int ld, i
   }
 }
 
+/* the same for exactly 8 contacts - the humanoid standing on both soles, the contact problem the headline workload
+ * solves in almost every evaluation: the contact count is a literal, so the per-update guards of the block form above
+ * (a scalar compare, a branch and the compiler's mask bookkeeping per update) are gone.  Same arithmetic and order.
+ * Measured in isolation (tools/ubench/pgs.hip, eleven waves per CU): 265 cycles per update against 312 for the
+ * guarded blocks and 368 for the general loop. */
+template<bool pk> RKFD_DEV void rkfd_pgs_dpp8(const double *MA, int r0, int ld, int max_iter, int lane, double mu,
+                                              double in_, double i1, double i2, double &rn, double &r1, double &r2, double &fn, double &f1, double &f2)
+{
+  for( int it=0; it<max_iter; it++ ){
+#define RKFD_PGS_N8(C0) { \
+      double a0[4], a1[4], a2[4]; \
+      _Pragma("unroll") for( int u=0; u<4; u++ ){ \
+        a0[u] = MA[rkfd_ma_idx<pk>( r0, 3*( C0+u ), ld )]; a1[u] = MA[rkfd_ma_idx<pk>( r0+1, 3*( C0+u ), ld )]; a2[u] = MA[rkfd_ma_idx<pk>( r0+2, 3*( C0+u ), ld )]; } \
+      RKFD_PGS_N1( C0, 0 ) RKFD_PGS_N1( C0, 1 ) RKFD_PGS_N1( C0, 2 ) RKFD_PGS_N1( C0, 3 ) }
+#define RKFD_PGS_N1(C0, u) { \
+      double ff = fn - rn*in_; \
+      if( ff < RKFD_DEV_TOL ) ff = 0.0; \
+      const double dl = ff - fn; \
+      if( lane == C0+u ) fn = ff; \
+      ROWBC_FMAC( C0+u, rn, dl, a0[u] ); ROWBC_FMAC( C0+u, r1, dl, a1[u] ); ROWBC_FMAC( C0+u, r2, dl, a2[u] ); }
+    RKFD_PGS_N8( 0 ) RKFD_PGS_N8( 4 )
+#undef RKFD_PGS_N1
+#undef RKFD_PGS_N8
+    double fs = mu*fn; fs = fs*fs;
+#define RKFD_PGS_T1(c) { \
+      const double a0 = MA[rkfd_ma_idx<pk>( r0, 3*c+1, ld )], a1 = MA[rkfd_ma_idx<pk>( r0+1, 3*c+1, ld )], a2 = MA[rkfd_ma_idx<pk>( r0+2, 3*c+1, ld )]; \
+      const double b0 = MA[rkfd_ma_idx<pk>( r0, 3*c+2, ld )], b1 = MA[rkfd_ma_idx<pk>( r0+1, 3*c+2, ld )], b2 = MA[rkfd_ma_idx<pk>( r0+2, 3*c+2, ld )]; \
+      const double ff0 = f1 - r1*i1, ff1 = f2 - r2*i2; \
+      const double fnorm = ff0*ff0 + ff1*ff1; \
+      const bool zero = fnorm < RKFD_DEV_TOL || fs < RKFD_DEV_TOL; \
+      double n1 = zero ? 0.0 : ff0, n2 = zero ? 0.0 : ff1; \
+      if( ( BALLOT( !zero && fnorm > fs ) >> c ) & 1ull ){ \
+        const double sc = fs*RKFD_RCP( fnorm ); \
+        n1 = ff0*sc; n2 = ff1*sc; \
+      } \
+      const double d1 = n1 - f1, d2 = n2 - f2; \
+      if( lane == c ){ f1 = n1; f2 = n2; } \
+      ROWBC_FMAC( c, rn, d2, b0 ); ROWBC_FMAC( c, r1, d2, b1 ); ROWBC_FMAC( c, r2, d2, b2 ); \
+      ROWBC_FMAC( c, rn, d1, a0 ); ROWBC_FMAC( c, r1, d1, a1 ); ROWBC_FMAC( c, r2, d1, a2 ); }
+    RKFD_PGS_T1( 0 ) RKFD_PGS_T1( 1 ) RKFD_PGS_T1( 2 ) RKFD_PGS_T1( 3 ) RKFD_PGS_T1( 4 ) RKFD_PGS_T1( 5 ) RKFD_PGS_T1( 6 ) RKFD_PGS_T1( 7 )
+#undef RKFD_PGS_T1
+  }
+}
+
 /* the general loop: any number of contacts, increments broadcast with v_readlane */
 template<bool pk> RKFD_DEV void rkfd_pgs_general(const double *MA, int r0, int ld, int nc, int max_iter, int lane, double mu,
                                                  double in_, double i1, double i2, double &rn, double &r1, double &r2, double &fn, double &f1, double &f2)
@@ -520,6 +564,7 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
      * (wave-uniform branches on the deciding lane instead of selects, one-lane moves under a narrowed EXEC) were
      * slower (8 contacts: 333): the VALU -> SALU -> branch round trips sit on the dependent path. */
     if( nc <= RKFD_PGS_NC ) rkfd_pgs_registers<pk>( L.MA, r0, ld, nc, m.max_iter, on, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
+    else if( !pk && nc == 8 ) rkfd_pgs_dpp8<pk>( L.MA, r0, ld, m.max_iter, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
     else if( !pk && nc <= RKFD_PGS_DPP_MAX ) rkfd_pgs_dpp<pk>( L.MA, r0, ld, nc, m.maxrg, m.max_iter, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
     else rkfd_pgs_general<pk>( L.MA, r0, ld, nc, m.max_iter, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
     if( on ){ L.MF[r0] = fn/dt; L.MF[r0+1] = f1/dt; L.MF[r0+2] = f2/dt; }
