@@ -1,16 +1,33 @@
 #!/bin/bash
 # everything profiles/ holds for one round, on the GPU box: rocprofv3 evidence per workload, phase cycles, bench lines
+# usage: bash tools/collect_all.sh [tag]      (then, in the build container: python3 tools/copy_profiles.py [tag])
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out
 for W in config4 config3 config2; do
   bash tools/collect_traffic.sh $W $TAG > gpurun_out/collect_${W}.log 2>&1
   echo "collected $W"
 done
-WARM=100 python3 tools/prof_phases.py config2 config3 config4 config4v config5 > gpurun_out/phase_cycles.txt 2>&1
+# FETCH_SIZE / WRITE_SIZE against a known byte count in this kernel's access pattern (8 B per lane, 30-double rows)
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_${TAG}_cal/fetch -- tools/ubench/traffic_cal > gpurun_out/traffic_cal.txt 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_${TAG}_cal/write -- tools/ubench/traffic_cal >> gpurun_out/traffic_cal.txt 2>&1
+echo "traffic calibration done"
+# the MFMA variant of the contact-matrix build: instruction counters of the same command
+RKFD_MLCP_MFMA=1 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d gpurun_out/prof_${TAG}_mfma/on -- python3 bench.py --warmup 5 --steps 20 --no-cpu-baseline --min-seconds 0 > gpurun_out/mfma_on.json 2> gpurun_out/mfma_on.log || true
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d gpurun_out/prof_${TAG}_mfma/off -- python3 bench.py --warmup 5 --steps 20 --no-cpu-baseline --min-seconds 0 > gpurun_out/mfma_off.json 2> gpurun_out/mfma_off.log || true
+python3 tools/mfma_ab.py config4 > gpurun_out/mfma_ab.txt 2>&1
+echo "mfma done"
+( echo "== rollout window (5 steps after 10) =="; WARM=10 python3 tools/prof_phases.py config2 config3 config4 config4v config5; echo "== rocking regime (5 steps after 100) =="; WARM=100 python3 tools/prof_phases.py config4 config5 ) > gpurun_out/phase_cycles.txt 2>&1
 echo "phases done"
+python3 bench.py --warmup 5 --steps 20 > gpurun_out/bench_driver_cmd.json 2> gpurun_out/bench_driver_cmd.log
+python3 bench.py --horizon 0 --no-cpu-baseline > gpurun_out/bench_config4_h0.json 2> gpurun_out/bench_config4_h0.log
 python3 bench.py --workload config5 --steps 100 --warmup 20 > gpurun_out/bench_config5.json 2> gpurun_out/bench_config5.log
-echo "bench config5 done"
-python3 bench.py --workload config4v --fuse 40 > gpurun_out/bench_config4v.json 2> gpurun_out/bench_config4v.log
-echo "bench config4v done"
+python3 bench.py --workload config5 --steps 100 --warmup 20 --horizon 0 --no-cpu-baseline > gpurun_out/bench_config5_h0.json 2> gpurun_out/bench_config5_h0.log
+python3 bench.py --workload config4v --steps 100 --fuse 25 > gpurun_out/bench_config4v.json 2> gpurun_out/bench_config4v.log
+python3 bench.py --workload config3_26 --no-cpu-baseline > gpurun_out/bench_config3_26.json 2> gpurun_out/bench_config3_26.log
+python3 bench.py --workload config4_26 --no-cpu-baseline > gpurun_out/bench_config4_26.json 2> gpurun_out/bench_config4_26.log
+echo "benches done"
+tools/ubench/pgs 11 > gpurun_out/ubench_pgs.txt 2>&1
 python3 tools/parity_report.py 1000 16 > gpurun_out/parity_report.txt 2>&1
 echo "parity report done"

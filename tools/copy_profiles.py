@@ -1,6 +1,23 @@
 """copies what tools/collect_all.sh left under gpurun_out/ into profiles/ (run in the build container)"""
 import glob, json, os, shutil, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+import csv
+
+
+def cal_factor():
+    """known bytes / counter bytes of tools/ubench/traffic_cal.hip (8 B per lane rows of 30 doubles), read and write"""
+    out = {}
+    rows, nd = 1 << 21, 30
+    known = 8.0 * rows * nd
+    for kind, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        fs = glob.glob(f"gpurun_out/prof_{tag}_cal/{kind}/**/*counter_collection.csv", recursive=True)
+        v = sorted(float(r["Counter_Value"]) for r in csv.DictReader(open(fs[0])) if "rkfd_traffic_cal" in r["Kernel_Name"] and r["Counter_Name"] == ctr)
+        out[kind] = known / (v[len(v) // 2] * 1024.0)
+    return out
+
+
+CAL = cal_factor()
+print("calibration (known bytes / counter bytes): read %.3f write %.3f" % (CAL["fetch"], CAL["write"]))
 tr = {}
 for w in ("config2", "config3", "config4"):
     s = json.load(open(f"gpurun_out/prof_{tag}_{w}_summary.json"))
@@ -8,8 +25,13 @@ for w in ("config2", "config3", "config4"):
     ks = sorted(glob.glob(f"gpurun_out/prof_{tag}_{w}/trace/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)[-1]
     shutil.copy(ks, f"profiles/{tag}_{w}_kernel_stats.csv")
     dj = json.loads(open(f"gpurun_out/prof_{tag}_{w}.bench.json").read().strip().splitlines()[-1])
-    tr[w] = {"batch": dj["roofline"].get("instances_per_launch", 4096), "hbm_bytes_per_launch": s["hbm_bytes_per_launch"], "fetch_size_raw_kib": s["FETCH_SIZE"], "write_size_kib": s["WRITE_SIZE"],
-             "note": "FETCH_SIZE*1024*2 (gfx950 under-count of wide reads) + WRITE_SIZE*1024; separate --pmc passes; median over the launches of a 20-step run (traffic per launch does not depend on the step count); `batch` = instances per launch"}
+    hb = s["FETCH_SIZE"] * 1024.0 * CAL["fetch"] + s["WRITE_SIZE"] * 1024.0 * CAL["write"]
+    s["hbm_bytes_per_launch"] = hb
+    tr[w] = {"batch": dj["roofline"].get("instances_per_launch", 4096), "hbm_bytes_per_launch": hb, "fetch_size_raw_kib": s["FETCH_SIZE"], "write_size_kib": s["WRITE_SIZE"],
+             "calibration_read": CAL["fetch"], "calibration_write": CAL["write"],
+             "note": "FETCH_SIZE*1024*cal_read + WRITE_SIZE*1024*cal_write; separate --pmc passes; median over the launches of the driver's command; the calibration "
+                     "factors are known bytes / counter bytes of tools/ubench/traffic_cal.hip, which reads and writes instance-major rows of 30 doubles with 8 B per lane "
+                     "like the step kernel (MI355X_MICROARCH.md: the x2 rule holds for 16 B-per-lane streams, other widths must be calibrated); `batch` = instances per launch"}
     name = f"{tag}_bench_default.json" if w == "config4" else f"{tag}_bench_{w}.json"
     d = json.loads(open(f"gpurun_out/prof_{tag}_{w}.bench.json").read().strip().splitlines()[-1]); d["roofline"]["traffic"] = s["hbm_bytes_per_launch"]
     open("profiles/" + name, "w").write(json.dumps(d) + "\n")
@@ -18,6 +40,32 @@ for w in ("config2", "config3", "config4"):
 json.dump(tr, open(f"profiles/{tag}_hbm_traffic.json", "w"), indent=1)
 shutil.copy("gpurun_out/phase_cycles.txt", f"profiles/{tag}_phase_cycles.txt")
 shutil.copy("gpurun_out/parity_report.txt", f"profiles/{tag}_parity_report.txt")
+shutil.copy("gpurun_out/traffic_cal.txt", f"profiles/{tag}_traffic_calibration.txt")
+open(f"profiles/{tag}_traffic_calibration.txt", "a").write("calibration (known bytes / counter bytes): read %.4f write %.4f\n" % (CAL["fetch"], CAL["write"]))
+for f in ("mfma_ab.txt", "ubench_pgs.txt"):
+    shutil.copy("gpurun_out/" + f, f"profiles/{tag}_" + f)
+mf = {}
+for k in ("on", "off"):
+    fs = glob.glob(f"gpurun_out/prof_{tag}_mfma/{k}/**/*counter_collection.csv", recursive=True)
+    acc = {}
+    if fs:
+        for r in csv.DictReader(open(fs[0])):
+            if "rkfd_step_kernel" in r["Kernel_Name"]:
+                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    mf["RKFD_MLCP_MFMA=" + ("1" if k == "on" else "0")] = {c: sorted(v)[len(v) // 2] for c, v in acc.items()}
+    try:
+        mf["RKFD_MLCP_MFMA=" + ("1" if k == "on" else "0")]["steps_per_s"] = json.loads(open(f"gpurun_out/mfma_{k}.json").read().strip().splitlines()[-1])["value"]
+    except Exception:
+        pass
+json.dump(mf, open(f"profiles/{tag}_mfma_counters.json", "w"), indent=1)
+print("mfma counters", mf)
+for w in ("driver_cmd", "config4_h0", "config5_h0", "config3_26", "config4_26"):
+    try:
+        line = open(f"gpurun_out/bench_{w}.json").read().strip().splitlines()[-1]
+        open(f"profiles/{tag}_bench_{w}.json", "w").write(line + "\n"); d = json.loads(line)
+        print(w, "%.4g steps/s" % d["value"], "contacts %.2f" % d["config"]["mean_rigid_contacts"])
+    except Exception as e:
+        print(w, "missing:", e)
 for w in ("config5", "config4v"):
     line = open(f"gpurun_out/bench_{w}.json").read().strip().splitlines()[-1]
     open(f"profiles/{tag}_bench_{w}.json", "w").write(line + "\n"); d = json.loads(line)
