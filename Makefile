@@ -7,7 +7,7 @@ ARCH    ?= gfx950
 PKG      = roki-fd_amd
 CSRC     = $(PKG)/csrc
 BUILD    = $(PKG)/build
-INC      = -Iinclude -I$(CSRC) -I$(CSRC)/host
+INC      = -Iinclude -I$(CSRC) -I$(CSRC)/host -I$(BUILD)
 CFLAGS   = -O2 -Wall -fPIC $(INC)
 # machine LICM off: hoisted literals / addresses held across the step loop cost ~35 VGPRs and the third wave per SIMD
 ROCM_LIBDIR ?= $(abspath $(dir $(realpath $(HIPCC)))/../lib)
@@ -29,7 +29,12 @@ $(BUILD)/rkfd_devmodel.o: $(CSRC)/rkfd_devmodel.cpp $(CSRC)/*.h $(CSRC)/device/*
 
 # the compiler's per-kernel resource report is kept beside the object: tests/test_build_resources.py checks that no
 # kernel spills to scratch and that all of them fit three waves per SIMD (168 VGPRs)
-$(BUILD)/rkfd_capi.o: $(CSRC)/rkfd_capi.hip $(CSRC)/*.h $(CSRC)/device/*.h include/*.h | $(BUILD)
+# the device sources as string literals inside the library: rkfdBatchSpecialize (hipRTC) needs no source files at run time
+DEVSRC = include/rkfd_model.h $(CSRC)/rkfd_devmodel.h $(CSRC)/rkfd_device.h $(sort $(wildcard $(CSRC)/device/*.h))
+$(BUILD)/rkfd_device_src.inc: $(DEVSRC) tools/embed_sources.py | $(BUILD)
+	python3 tools/embed_sources.py $@ $(DEVSRC)
+
+$(BUILD)/rkfd_capi.o: $(CSRC)/rkfd_capi.hip $(BUILD)/rkfd_device_src.inc $(CSRC)/*.h $(CSRC)/device/*.h include/*.h | $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(BUILD)/rkfd_capi.remarks || ( cat $(BUILD)/rkfd_capi.remarks; exit 1 )
 	@grep -E "Function Name|VGPRs:|ScratchSize|Occupancy|VGPRs Spill|SGPRs Spill" $(BUILD)/rkfd_capi.remarks | sed 's/.*remark: *//; s/ \[-Rpass.*//' > $(PKG)/kernel_resources.txt
 	@grep -vE "remark:|^ +[0-9]+ \||^ +\||\^" $(BUILD)/rkfd_capi.remarks || true

@@ -76,8 +76,10 @@ int rkfdBatchSetSplit(rkfdBatch *b, int nsplit);
 /* Compile the step kernel for THIS world (hipRTC, a few seconds): the same device code with the world's dimensions
  * as literals, so that the LDS layout, loop bounds and table strides fold into immediates (+7 % steps/s on the
  * 30-DoF humanoid).  Results are bit-identical to the generic kernels, which stay in use for the profiling entry
- * point.  Needs the package's csrc/ and include/ directories beside the library at run time; 0, or -1 with a message
- * (the generic kernels remain in use then).  rkfdSpecializeCompile: the compile step alone, without a GPU - bytes
+ * point.  Self-contained: the library carries the device sources it hands to hipRTC, and binds hipRTC and the compiler
+ * library beside it (the ROCm it was built with; RKFD_ROCM_LIBDIR overrides) in a private link namespace, so neither files
+ * beside the library nor the order in which the host program loaded other ROCm-bundling libraries matter; 0, or -1 with
+ * a message (the generic kernels remain in use then).  rkfdSpecializeCompile: the compile step alone, without a GPU - bytes
  * of code object, or -1. */
 int rkfdBatchSpecialize(rkfdBatch *b);
 int rkfdSpecializeCompile(const rkfdModel *m, int max_rigid);

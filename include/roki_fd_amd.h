@@ -27,6 +27,9 @@ typedef struct { int size; double *buf; } zVecStruct;
 typedef zVecStruct *zVec;
 zVec zVecAlloc(int size);
 void zVecFree(zVec v);
+/* zVecFreeAtOnce( n, v1, ..., vn ), zRandInit() as used by reference example/chain/arm_box_test.c:85, boxdrop_hardsoft_test.c:18 */
+void zVecFreeAtOnce(int n, ...);
+void zRandInit(void);
 double zRandF(double min, double max);
 void zVecFPrint(FILE *fp, zVec v);
 #define zVecSize(v)      ( (v)->size )

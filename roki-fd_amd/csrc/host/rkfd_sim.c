@@ -4,6 +4,8 @@
  */
 #include <stdlib.h>
 #include <string.h>
+#include <stdarg.h>
+#include <time.h>
 #include "roki_fd_amd.h"
 #include "rkfd_world.h"
 
@@ -32,6 +34,14 @@ zVec zVecAlloc(int size)
   return v;
 }
 void zVecFree(zVec v){ if( v ){ free( v->buf ); free( v ); } }
+void zVecFreeAtOnce(int n, ...)
+{
+  va_list ap;
+  va_start( ap, n );
+  while( n-- > 0 ) zVecFree( va_arg( ap, zVec ) );
+  va_end( ap );
+}
+void zRandInit(void){ srand( (unsigned)time( NULL ) ); }
 /* uniform random number in [min,max] (ZM's zRandF, used by reference example/chain/boxdrop_test.c:30-32) */
 double zRandF(double min, double max){ return min + ( max - min )*( (double)rand()/(double)RAND_MAX ); }
 void zVecFPrint(FILE *fp, zVec v)

@@ -16,6 +16,7 @@
 #include "rkfd_hip.h"
 #include "rkfd_device.h"
 #include "rkfd_devmodel_host.h"
+#include "rkfd_device_src.inc"       /* the device headers as string literals (tools/embed_sources.py), for hipRTC */
 
 static thread_local char g_err[512] = "";
 #define SETERR(...) snprintf( g_err, sizeof(g_err), __VA_ARGS__ )
@@ -392,14 +393,6 @@ static int launch(rkfdBatch *b, int mode, int nsteps, void *stream)
   return 0;
 }
 /* ---- the step kernel compiled for one world (hipRTC) ---------------------------------------------------- */
-static std::string lib_dir(void)
-{
-  Dl_info di;
-  if( !dladdr( (const void *)&lib_dir, &di ) || !di.dli_fname ) return ".";
-  std::string p( di.dli_fname );
-  const size_t k = p.rfind( '/' );
-  return k == std::string::npos ? std::string( "." ) : p.substr( 0, k );
-}
 /* source of the specialised kernel: the dimensions of the world as literals in front of the same device code */
 static std::string spec_source(const rkfdDevModel &d)
 {
@@ -484,17 +477,16 @@ static const rkfdRtc *rtc_api(void)
   pthread_mutex_unlock( &mu );
   return s == 1 ? &api : NULL;
 }
-/* compile for gfx950; needs the device headers beside the library (csrc/) and include/ beside the package */
+/* compile for gfx950 from the sources the library carries (rkfd_device_src.inc): nothing is read from disk */
 static int spec_compile(const rkfdDevModel &d, std::vector<char> &code)
 {
   const rkfdRtc *rtc = rtc_api();
   if( !rtc ) return -1;
-  const std::string src = spec_source( d ), dir = lib_dir();
+  const std::string src = spec_source( d );
   if( const char *dump = getenv( "RKFD_SPEC_DUMP" ) ){ FILE *f = fopen( dump, "w" ); if( f ){ fputs( src.c_str(), f ); fclose( f ); } }   /* diagnostic */
-  const std::string i1 = "-I" + dir + "/csrc", i2 = "-I" + dir + "/../include";
-  const char *opts[] = { "--offload-arch=gfx950", "-O3", "-Wno-unused-value", "-mllvm", "-disable-machine-licm", i1.c_str(), i2.c_str() };
+  const char *opts[] = { "--offload-arch=gfx950", "-O3", "-Wno-unused-value", "-mllvm", "-disable-machine-licm" };
   hiprtcProgram prog;
-  if( rtc->create( &prog, src.c_str(), "rkfd_step_kernel_spec.hip", 0, NULL, NULL ) != HIPRTC_SUCCESS ){ SETERR( "hiprtcCreateProgram failed" ); return -1; }
+  if( rtc->create( &prog, src.c_str(), "rkfd_step_kernel_spec.hip", rkfd_src_count, (const char **)rkfd_src_text, (const char **)rkfd_src_name ) != HIPRTC_SUCCESS ){ SETERR( "hiprtcCreateProgram failed" ); return -1; }
   const hiprtcResult r = rtc->compile( prog, (int)( sizeof(opts)/sizeof(opts[0]) ), opts );
   if( r != HIPRTC_SUCCESS ){
     size_t n = 0; rtc->logsize( prog, &n );

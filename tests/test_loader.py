@@ -96,6 +96,26 @@ def test_reference_api_names_in_c(R, tmp_path):
 
 
 REF_MODELS = "/root/reference/example/model"
+REF_DRIVERS = "/root/reference/example/chain"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_DRIVERS), reason="reference checkout not present (it never is on the GPU box)")
+def test_reference_drivers_compile_and_link_unmodified(R, tmp_path):
+    """the reference's five example drivers (read where they lie, not copied) compile with -Werror=implicit-function-declaration
+    against include/roki_fd/roki_fd.h and link against librkfd_amd.so as they are - #include <roki_fd/roki_fd.h>,
+    rkFDODE2Assign( &fd, Regular ), rkFDSetSolver( &fd, Volume ), zVecFreeAtOnce, rkCDPairChainUnreg and all.
+    (They select the Volume plugin, whose rigid branch has no device path: run on a GPU they report that and stop
+    short of contact forces; with their commented-out rkFDSetSolver( &fd, MLCP ) line they run.)"""
+    import glob
+    import subprocess
+    root = os.path.join(os.path.dirname(__file__), "..")
+    drivers = sorted(glob.glob(os.path.join(REF_DRIVERS, "*_test.c")))
+    assert len(drivers) == 5
+    for d in drivers:
+        exe = str(tmp_path / os.path.basename(d)[:-2])
+        subprocess.run(["gcc", "-O1", "-Werror=implicit-function-declaration", "-I" + os.path.join(root, "include"), d, "-L" + os.path.join(root, "roki-fd_amd"),
+                        "-lrkfd_amd", "-lm", "-Wl,-rpath," + os.path.join(root, "roki-fd_amd"), "-o", exe], check=True)
+        assert os.path.exists(exe)
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_MODELS), reason="reference checkout not present (it never is on the GPU box)")
