@@ -281,7 +281,8 @@ def main():
     assert nlaunch > 0
     kernel_ms = launch_ms / nlaunch           # average duration of one launch of the step kernel
     mean_rg, mean_el, counted = b.contact_stats()
-    assert counted == Bn * timed_steps, (counted, Bn, timed_steps)
+    if sc["world"].model.contents.ncand > 0:       # (worlds without contact candidates keep no contact statistics)
+        assert counted == Bn * timed_steps, (counted, Bn, timed_steps)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

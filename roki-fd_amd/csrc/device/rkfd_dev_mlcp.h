@@ -564,7 +564,7 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
      * (wave-uniform branches on the deciding lane instead of selects, one-lane moves under a narrowed EXEC) were
      * slower (8 contacts: 333): the VALU -> SALU -> branch round trips sit on the dependent path. */
     if( nc <= RKFD_PGS_NC ) rkfd_pgs_registers<pk>( L.MA, r0, ld, nc, m.max_iter, on, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
-    else if( !pk && nc == 8 ) rkfd_pgs_dpp8<pk>( L.MA, r0, ld, m.max_iter, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
+    else if( nc == 8 ) rkfd_pgs_dpp8<pk>( L.MA, r0, ld, m.max_iter, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
     else if( !pk && nc <= RKFD_PGS_DPP_MAX ) rkfd_pgs_dpp<pk>( L.MA, r0, ld, nc, m.maxrg, m.max_iter, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
     else rkfd_pgs_general<pk>( L.MA, r0, ld, nc, m.max_iter, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
     if( on ){ L.MF[r0] = fn/dt; L.MF[r0+1] = f1/dt; L.MF[r0+2] = f2/dt; }

@@ -5,7 +5,7 @@ set -e
 TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-for W in config4 config3 config2; do
+for W in ${WORKLOADS:-config4 config3 config2}; do
   bash tools/collect_traffic.sh $W $TAG > gpurun_out/collect_${W}.log 2>&1
   echo "collected $W"
 done
