@@ -84,6 +84,16 @@ def counted_flops(workload, horizon):
         return None
 
 
+def valu_issue(workload):
+    """VALU instructions per instance-step from the rocprofv3 SQ pass on file (profiles/r02_<workload>_rocprof_summary.json)"""
+    try:
+        with open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_{workload}_rocprof_summary.json")) as fp:
+            rec = json.load(fp)
+        return rec["SQ_INSTS_VALU"] / rec["SQ_WAVES"]
+    except (OSError, ValueError, KeyError, ZeroDivisionError):
+        return None
+
+
 def _oracle_rollouts(Oracle, sc, inst, horizon, deadline, block=None):
     """one oracle instance doing the bench's workload: rollouts of `horizon` steps from its start state
     (horizon 0: one trajectory in blocks of 200 steps) until the deadline; returns the steps done"""
@@ -328,11 +338,21 @@ def main():
         }
         del steps_per_launch
         fl = counted_flops(args.workload, H)
-        if fl is not None:
-            # second axis SURVEY 8d asks for: fp64 vector throughput (dense peak 78.6 TFLOP/s, MI355X_MICROARCH.md)
+        if fl is not None and args.workload != "config4v":
+            # second axis SURVEY 8d asks for: fp64 vector throughput (dense peak 78.6 TFLOP/s, MI355X_MICROARCH.md).  The flops are
+            # those of the REFERENCE's formulation (counted on the oracle over the same rollout window: link-local ABA, column-probed
+            # MLCP), not the device's instruction count - the device's innovations form needs fewer.  Not given for the Vert plugin:
+            # the oracle's generic pseudo-inverse KKT solves cost ~10x what the device's structured solve does.
             tf = fl * Bn / (step_ms * 1e-3) / 1e12      # whole step: the launches of one step overlap
             res["roofline_valu"] = {"bound": "valu_fp64", "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6,
-                                    "alg_flops_per_instance_step": fl}
+                                    "alg_flops_per_instance_step": fl, "flops_counted_on": "the reference's formulation (oracle), same rollout window"}
+        vi = valu_issue(args.workload)
+        if vi is not None:
+            # what bounds the kernel: VALU instruction issue.  Instructions per instance-step from the rocprofv3
+            # SQ_INSTS_VALU pass on file; one wave-wide VALU instruction occupies its SIMD for 4 cycles (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.02
+            # quad-cycles measured); 256 CUs x 4 SIMDs.  The clock under this kernel is ~1.8-2.0 GHz, the nominal 2.4 GHz is used.
+            ips = vi * Bn / (step_ms * 1e-3)
+            res["valu_issue"] = {"valu_insts_per_instance_step": vi, "simd_busy_fraction_at_2.4GHz": ips * 4.0 / (256 * 4 * 2.4e9)}
         if world == 1 and not args.no_cpu_baseline:      # the CPU baseline is a single-GPU-run figure (rank 0, N = 1)
             res["cpu_baseline"] = cpu_baseline(R, args.workload, H)
             res["cpu_baseline_all_cores"] = cpu_baseline_all_cores(R, args.workload, H)

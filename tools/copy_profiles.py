@@ -21,12 +21,12 @@ print("calibration (known bytes / counter bytes): read %.3f write %.3f" % (CAL["
 tr = {}
 for w in ("config2", "config3", "config4"):
     s = json.load(open(f"gpurun_out/prof_{tag}_{w}_summary.json"))
-    shutil.copy(f"gpurun_out/prof_{tag}_{w}_summary.json", f"profiles/{tag}_{w}_rocprof_summary.json")
     ks = sorted(glob.glob(f"gpurun_out/prof_{tag}_{w}/trace/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)[-1]
     shutil.copy(ks, f"profiles/{tag}_{w}_kernel_stats.csv")
     dj = json.loads(open(f"gpurun_out/prof_{tag}_{w}.bench.json").read().strip().splitlines()[-1])
     hb = s["FETCH_SIZE"] * 1024.0 * CAL["fetch"] + s["WRITE_SIZE"] * 1024.0 * CAL["write"]
-    s["hbm_bytes_per_launch"] = hb
+    s["hbm_bytes_per_launch"] = hb; s["hbm_bytes_per_launch_note"] = "FETCH_SIZE*1024*%.4f + WRITE_SIZE*1024*%.4f (calibrated on tools/ubench/traffic_cal.hip; hbm_read_bytes_x2 is the uncalibrated 16 B-per-lane rule, kept for reference)" % (CAL["fetch"], CAL["write"])
+    json.dump(s, open(f"profiles/{tag}_{w}_rocprof_summary.json", "w"), indent=1)
     tr[w] = {"batch": dj["roofline"].get("instances_per_launch", 4096), "hbm_bytes_per_launch": hb, "fetch_size_raw_kib": s["FETCH_SIZE"], "write_size_kib": s["WRITE_SIZE"],
              "calibration_read": CAL["fetch"], "calibration_write": CAL["write"],
              "note": "FETCH_SIZE*1024*cal_read + WRITE_SIZE*1024*cal_write; separate --pmc passes; median over the launches of the driver's command; the calibration "
