@@ -8,6 +8,11 @@
 #include <vector>
 #include "rkfd_device.h"
 
+template<int C> __device__ __forceinline__ void mov_lane(double &dst, double src)
+{
+  unsigned long long keep;
+  asm volatile( "s_mov_b64 %1, exec\n\ts_mov_b64 exec, %3\n\tv_mov_b64 %0, %2\n\ts_mov_b64 exec, %1" : "+v"(dst), "=&s"(keep) : "v"(src), "s"( 1ull << C ) );
+}
 // experiment: the DPP scheme for a literal contact count, no per-update guards.  SL: 0 = wave-uniform branch on the sliding test,
 // 1 = branch-free (reciprocal always evaluated, selected)
 template<int NC, int SL> __device__ __forceinline__ void pgs_static(const double *MA, int r0, int ld, int lane, double mu, double in_, double i1, double i2,
@@ -18,7 +23,7 @@ template<int NC, int SL> __device__ __forceinline__ void pgs_static(const double
       double a0[NC], a1[NC], a2[NC];
 #pragma unroll
       for( int c=0; c<NC; c++ ){ a0[c] = MA[r0*ld+3*c]; a1[c] = MA[( r0+1 )*ld+3*c]; a2[c] = MA[( r0+2 )*ld+3*c]; }
-#define NUPD(c) { double ff = fn - rn*in_; if( ff < RKFD_DEV_TOL ) ff = 0.0; const double dl = ff - fn; if( lane == c ) fn = ff; \
+#define NUPD(c) { double ff = fn - rn*in_; if( ff < RKFD_DEV_TOL ) ff = 0.0; const double dl = ff - fn; if( SL >= 2 ) mov_lane<c>( fn, ff ); else if( lane == c ) fn = ff; \
         ROWBC_FMAC( c, rn, dl, a0[c] ); ROWBC_FMAC( c, r1, dl, a1[c] ); ROWBC_FMAC( c, r2, dl, a2[c] ); }
       NUPD(0) NUPD(1) NUPD(2) NUPD(3) if( NC > 4 ){ NUPD(4) NUPD(5) NUPD(6) NUPD(7) }
 #undef NUPD
@@ -26,10 +31,11 @@ template<int NC, int SL> __device__ __forceinline__ void pgs_static(const double
     double fs = mu*fn; fs = fs*fs;
 #define TUPD(c) { const double a0 = MA[r0*ld+3*c+1], a1 = MA[( r0+1 )*ld+3*c+1], a2 = MA[( r0+2 )*ld+3*c+1], b0 = MA[r0*ld+3*c+2], b1 = MA[( r0+1 )*ld+3*c+2], b2 = MA[( r0+2 )*ld+3*c+2]; \
       const double ff0 = f1 - r1*i1, ff1 = f2 - r2*i2; const double fnorm = ff0*ff0 + ff1*ff1; \
-      const bool zero = fnorm < RKFD_DEV_TOL || fs < RKFD_DEV_TOL; double n1 = zero ? 0.0 : ff0, n2 = zero ? 0.0 : ff1; \
-      if( SL == 0 ){ if( ( BALLOT( !zero && fnorm > fs ) >> c ) & 1ull ){ const double sc = fs*RKFD_RCP( fnorm ); n1 = ff0*sc; n2 = ff1*sc; } } \
+      const bool zero = fnorm < RKFD_DEV_TOL || fs < RKFD_DEV_TOL; double n1 = ff0, n2 = ff1; \
+      if( SL == 3 ){ if( ( BALLOT( zero ) >> c ) & 1ull ){ n1 = 0.0; n2 = 0.0; } } else { n1 = zero ? 0.0 : ff0; n2 = zero ? 0.0 : ff1; } \
+      if( SL == 0 || SL >= 2 ){ if( ( BALLOT( !zero && fnorm > fs ) >> c ) & 1ull ){ const double sc = fs*RKFD_RCP( fnorm ); n1 = ff0*sc; n2 = ff1*sc; } } \
       else { const double sc = fs*RKFD_RCP( fnorm ); const bool sl = !zero && fnorm > fs; n1 = sl ? ff0*sc : n1; n2 = sl ? ff1*sc : n2; } \
-      const double d1 = n1 - f1, d2 = n2 - f2; if( lane == c ){ f1 = n1; f2 = n2; } \
+      const double d1 = n1 - f1, d2 = n2 - f2; if( SL >= 2 ){ mov_lane<c>( f1, n1 ); mov_lane<c>( f2, n2 ); } else if( lane == c ){ f1 = n1; f2 = n2; } \
       ROWBC_FMAC( c, rn, d2, b0 ); ROWBC_FMAC( c, r1, d2, b1 ); ROWBC_FMAC( c, r2, d2, b2 ); ROWBC_FMAC( c, rn, d1, a0 ); ROWBC_FMAC( c, r1, d1, a1 ); ROWBC_FMAC( c, r2, d1, a2 ); }
     TUPD(0) TUPD(1) TUPD(2) TUPD(3) if( NC > 4 ){ TUPD(4) TUPD(5) TUPD(6) TUPD(7) }
 #undef TUPD
@@ -59,6 +65,8 @@ template<int V> __global__ void __launch_bounds__(64, 3) k_pgs(const double *A, 
     if( V == 2 ) rkfd_pgs_registers<false>( MA, r0, ld, nc, 10, on, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
     if( V == 3 ) pgs_static<8, 0>( MA, r0, ld, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
     if( V == 4 ) pgs_static<8, 1>( MA, r0, ld, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
+    if( V == 5 ) pgs_static<8, 2>( MA, r0, ld, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
+    if( V == 6 ) pgs_static<8, 3>( MA, r0, ld, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
     acc += fn + f1 + f2;
     asm volatile( "" : "+v"(acc) );
   }
@@ -72,7 +80,7 @@ int main(int argc, char **argv)
   const int res = argc > 1 ? atoi( argv[1] ) : 11;
   hipDeviceProp_t p; hipGetDeviceProperties( &p, 0 );
   const int ncu = p.multiProcessorCount;
-  for( int nc : { 3, 4, 8, 12, 16 } ){
+  for( int nc : { 3, 4, 8, 12, 16, 24 } ){
     const int M = 3*nc;
     // A = G G' + 1e-4 I with G M x 6 (a rigid body's contact matrix has rank 6), b < 0 so that forces are non-zero
     std::vector<double> G( M*6 ), A( M*M ), B( M );
@@ -86,12 +94,13 @@ int main(int argc, char **argv)
     hipMemcpy( dA, A.data(), sizeof(double)*M*M, hipMemcpyHostToDevice ); hipMemcpy( dB, B.data(), sizeof(double)*M, hipMemcpyHostToDevice );
     const size_t ldsb = 14064;         // the humanoid's footprint: 11 workgroups per CU
     std::vector<double> ref;
-    for( int v=0; v<5; v++ ){
+    for( int v=0; v<7; v++ ){
       if( v == 2 && nc > 4 ) continue;
       if( v >= 3 && nc != 8 ) continue;
+      if( v == 1 && nc > 16 ) continue;
       for( int full=0; full<2; full++ ){
         const int nb = full ? nblk : ncu;
-        void (*k)(const double *, const double *, double *, long long *, int, int, int, int) = v == 0 ? k_pgs<0> : ( v == 1 ? k_pgs<1> : ( v == 2 ? k_pgs<2> : ( v == 3 ? k_pgs<3> : k_pgs<4> ) ) );
+        void (*k)(const double *, const double *, double *, long long *, int, int, int, int) = v == 0 ? k_pgs<0> : ( v == 1 ? k_pgs<1> : ( v == 2 ? k_pgs<2> : ( v == 3 ? k_pgs<3> : ( v == 4 ? k_pgs<4> : ( v == 5 ? k_pgs<5> : k_pgs<6> ) ) ) ) );
         hipLaunchKernelGGL( k, dim3( nb ), dim3( 64 ), ldsb, 0, dA, dB, dout, dcyc, nc, 16, 20, 0 );
         hipDeviceSynchronize();
         std::vector<long long> c( nb ); std::vector<double> o( 64 );
@@ -100,7 +109,7 @@ int main(int argc, char **argv)
         if( v == 0 && !full ) ref = o;
         double dev = 0; for( int i=0; i<nc; i++ ) dev = fmax( dev, fabs( o[i] - ref[i] ) );
         printf( "nc %2d  %-9s %s per CU: %8.0f cycles per solve = %6.1f per update   (result deviates from the general loop by %.1e)\n", nc,
-                v == 0 ? "general" : ( v == 1 ? "dpp" : ( v == 2 ? "registers" : ( v == 3 ? "static8" : "static8-nb" ) ) ), full ? "all " : "one ", mean, mean/( 20.0*nc ), dev );
+                v == 0 ? "general" : ( v == 1 ? "dpp" : ( v == 2 ? "registers" : ( v == 3 ? "static8" : ( v == 4 ? "static8-nb" : ( v == 5 ? "static8-mov" : "static8-mov-z" ) ) ) ) ), full ? "all " : "one ", mean, mean/( 20.0*nc ), dev );
       }
     }
     hipFree( dA ); hipFree( dB ); hipFree( dout ); hipFree( dcyc );
