@@ -40,7 +40,7 @@ def aa_from_rpy_deg(rx, ry, rz):
     return l * (th / a) if a > 1e-12 else np.zeros(3)
 
 
-def config1(batch=1, solver=B.SOLVER_VERT):
+def config1(batch=1, solver=B.SOLVER_VERT, first=0):
     """box over the soft half of floor_hardsoft: ELASTIC 'soft body' contact => penalty path."""
     w = B.World(solver=solver)
     w.contact_info(_m("contactinfo.ztk"))
@@ -52,7 +52,7 @@ def config1(batch=1, solver=B.SOLVER_VERT):
     return dict(name="config1_box_soft_penalty", world=w, dis=dis, vel=vel, max_rigid=0, steps=2000)
 
 
-def config1_rigid(batch=1):
+def config1_rigid(batch=1, first=0):
     """box over the hard half: RIGID 'ground body' contact with the MLCP plugin."""
     w = B.World(solver=B.SOLVER_MLCP)
     w.contact_info(_m("contactinfo.ztk"))
