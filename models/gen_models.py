@@ -273,6 +273,22 @@ def humanoid(ref_root):
     w("humanoid30.ztk", header30 + h30)
 
 
+def humanoid_shell():
+    """humanoid30_shell.ztk (SYNTHETIC): humanoid30 with a tessellated sphere (div 16: 114 vertices) on six links, so that
+    the world holds ~760 candidate contact vertices like the reference's mighty.ztk with its body meshes (749): the
+    multi-chunk collision sweep with a humanoid.  Generated from the committed humanoid30.ztk (no reference needed)."""
+    text = open(os.path.join(HERE, "humanoid30.ztk")).read()
+    links = ["body", "left_knee_flexion", "right_knee_flexion", "left_elbow_flexion", "right_elbow_flexion", "neck_pitch"]
+    shapes = "".join(f"[zeo::shape]\nname: shell_{l}\ntype: sphere\ncenter: 0, 0, 0\nradius: 0.03\ndiv: 16\n\n" for l in links)
+    text = text.replace("[zeo::shape]\nname: left_sole", shapes + "[zeo::shape]\nname: left_sole", 1)
+    for l in links:
+        text = re.sub(r"(\[roki::link\]\nname: %s\n)" % l, r"\1shape: shell_%s\n" % l, text, count=1)
+    text = text.replace("name : humanoid30", "name : humanoid30_shell", 1)
+    text = text.replace("% humanoid30 (SYNTHETIC", "% humanoid30_shell: humanoid30 + six tessellated spheres (models/gen_models.py: humanoid_shell)\n% humanoid30 (SYNTHETIC", 1)
+    assert text.count("shape: shell_") == len(links)
+    w("humanoid30_shell.ztk", text)
+
+
 def main():
     w("box.ztk", box("box", 0.1, 0.1, 0.1, 0.5, "8.33e-4"))
     w("box_small.ztk", box("box_small", 0.05, 0.10, 0.05, 0.125, "5.208333333e-05"))
@@ -289,6 +305,7 @@ def main():
         humanoid(ref)
     else:
         print("reference checkout not found: humanoid26/30.ztk left untouched")
+    humanoid_shell()
 
 
 if __name__ == "__main__":

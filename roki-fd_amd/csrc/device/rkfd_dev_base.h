@@ -323,7 +323,7 @@ typedef struct {
   double *MA, *MB, *MF, *PU;      /* contact problem: [ma_size] the matrix (ALIASES IST|POOL; full rows or a packed lower triangle, rkfd_ma_idx),
                                      [M] bias vector, [M] forces (ALIAS the bias vector in the PGS kernels), [nside*npurow*M] (ALIASES C|PA when it fits) */
   int *tgt, *cnt;
-  unsigned char *lrg, *lel;       /* [maxact] candidates in rigid / elastic contact, in candidate order */
+  unsigned short *lrg, *lel;      /* [maxact] candidates in rigid / elastic contact, in candidate order */
   unsigned char *act, *typ;       /* [NC] in contact, stick / slip type                   */
   unsigned char *asl;             /* [NC] active-contact slot of a candidate              */
   int *LI;                        /* [NL] packed link info (RKFD_LI_*)                    */
@@ -376,9 +376,9 @@ RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int
   L->LI = ip; ip += NL;
   unsigned short *sp = (unsigned short *)ip;
   L->CHP = sp; sp += NL; L->CFO = sp; sp += NC;
+  L->lrg = sp; sp += maxact; L->lel = sp; sp += maxact;
   unsigned char *bp = (unsigned char *)sp;
   L->act = bp; bp += NC; L->typ = bp; bp += NC; L->asl = bp; bp += NC;
-  L->lrg = bp; bp += maxact; L->lel = bp; bp += maxact;
   L->CRC = bp; if( vert_rigid ) bp += M;
   L->PL = bp;
 }

@@ -163,7 +163,7 @@ RKFD_DEV void rkfd_phase_collision(const rkfdDevModel &m, const rkfdLds &L)
  * wrenches (rkFDContactForcePushWrench, reference src/rkfd_util.c:268-282): in world
  * coordinates the wrench on the owner link is (x x f, f), on the other link its negative.
  * lanes 0..5 own one component each and walk the list in order (deterministic). */
-RKFD_DEV void rkfd_push_wrenches(const rkfdDevModel &m, const rkfdLds &L, const unsigned char *list, int n)
+RKFD_DEV void rkfd_push_wrenches(const rkfdDevModel &m, const rkfdLds &L, const unsigned short *list, int n)
 {
   const int lane = LANE();
   if( lane < 6 && n > 0 ){

@@ -137,7 +137,7 @@ int rkfdWorldBuild(rkfdWorld *w)
   double *org = NULL, *mass = NULL, *com = NULL, *inertia = NULL;
   double *stiff = NULL, *visc = NULL, *coulomb = NULL, *sfric = NULL;
   double *mot_k = NULL, *mot_admit = NULL, *mot_vmax = NULL, *mot_vmin = NULL, *mot_gear = NULL, *mot_inertia = NULL;
-  int *shape_link = NULL, *shape_voff = NULL, *shape_foff = NULL, *shape_chain = NULL;
+  int *shape_link = NULL, *shape_voff = NULL, *shape_foff = NULL, *shape_chain = NULL, *shape_convex = NULL;
   int *shape_slide_mode = NULL; double *shape_slide_vel = NULL, *shape_slide_axis = NULL;
   double *verts = NULL, *planes = NULL;
   int *pair_shape = NULL, *pair_ci = NULL, *ci_type = NULL;
@@ -161,6 +161,7 @@ int rkfdWorldBuild(rkfdWorld *w)
   {
     int *sc = (int *)malloc( sizeof(int)*( nshape ? nshape : 1 ) );
     int *sv = (int *)malloc( sizeof(int)*( nshape ? nshape : 1 ) );
+    int *scv = (int *)malloc( sizeof(int)*( nshape ? nshape : 1 ) );
     int n = 0, x, y;
     for( c=0; c<w->nchain; c++ ){
       rkfdChainDesc *cd = w->chain[c];
@@ -168,16 +169,18 @@ int rkfdWorldBuild(rkfdWorld *w)
         for( s=0; s<cd->link[i].nshape; s++ ){
           rkfdShape *sh = &cd->shape[cd->link[i].shape[s]];
           if( sh->nvert == 0 || sh->nplane == 0 ) continue;
-          sc[n] = c; sv[n] = sh->nvert; n++;
+          sc[n] = c; sv[n] = sh->nvert; scv[n] = sh->convex; n++;
         }
     }
     for( y=0; y<n; y++ )
       for( x=0; x<y; x++ ){
         if( sc[x] == sc[y] ) continue;
         if( w->nopair[sc[x]*w->nchain+sc[y]] ) continue;
-        npair++; ncand += sv[x] + sv[y];
+        /* a shape's vertices are candidates against the OTHER shape of the pair only when that one is convex (the
+         * inside test is the intersection of its face half-spaces) */
+        npair++; ncand += ( scv[y] ? sv[x] : 0 ) + ( scv[x] ? sv[y] : 0 );
       }
-    free( sc ); free( sv );
+    free( sc ); free( sv ); free( scv );
   }
 
   for( pass=0; pass<2; pass++ ){
@@ -196,7 +199,7 @@ int rkfdWorldBuild(rkfdWorld *w)
     GET( mot_k, double, nlink ); GET( mot_admit, double, nlink ); GET( mot_vmax, double, nlink );
     GET( mot_vmin, double, nlink ); GET( mot_gear, double, nlink ); GET( mot_inertia, double, nlink );
     GET( shape_link, int, nshape ); GET( shape_voff, int, nshape+1 ); GET( shape_foff, int, nshape+1 );
-    GET( shape_chain, int, nshape );
+    GET( shape_chain, int, nshape ); GET( shape_convex, int, nshape );
     GET( shape_slide_mode, int, nshape ); GET( shape_slide_vel, double, nshape ); GET( shape_slide_axis, double, nshape*3 );
     GET( shape_stuff, const char *, nshape );
     GET( verts, double, nvert*3 ); GET( planes, double, nplane*4 );
@@ -231,7 +234,7 @@ int rkfdWorldBuild(rkfdWorld *w)
         for( s=0; s<l->nshape; s++ ){
           rkfdShape *sh = &cd->shape[l->shape[s]];
           if( sh->nvert == 0 || sh->nplane == 0 ) continue;
-          shape_link[si] = li; shape_chain[si] = c; shape_stuff[si] = l->stuff;
+          shape_link[si] = li; shape_chain[si] = c; shape_stuff[si] = l->stuff; shape_convex[si] = sh->convex;
           shape_voff[si] = vi; shape_foff[si] = fi;
           shape_slide_mode[si] = sh->slide_mode; shape_slide_vel[si] = sh->slide_vel;
           memcpy( &shape_slide_axis[3*si], sh->slide_axis, sizeof(double)*3 );
@@ -259,6 +262,7 @@ int rkfdWorldBuild(rkfdWorld *w)
           pair_ci[pi] = assoc_ci( w, shape_stuff[x], shape_stuff[y] );
           for( s=0; s<2; s++ ){
             int sh = pair_shape[2*pi+s];
+            if( !shape_convex[pair_shape[2*pi+1-s]] ) continue;
             for( k=shape_voff[sh]; k<shape_voff[sh+1]; k++ ){
               cand_pair[ci] = pi; cand_side[ci] = s; cand_vert[ci] = k; ci++;
             }

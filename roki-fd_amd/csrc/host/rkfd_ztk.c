@@ -188,6 +188,10 @@ static int shape_build_planes(rkfdShape *s, int nface, const int *face)
       s->nplane++;
     }
   }
+  s->convex = 1;
+  for( i=0; i<s->nplane && s->convex; i++ )
+    for( j=0; j<s->nvert; j++ )
+      if( v3_dot( &s->plane[4*i], &s->vert[3*j] ) - s->plane[4*i+3] > 1e-9 ){ s->convex = 0; break; }
   return 0;
 }
 
@@ -352,15 +356,6 @@ static int shape_make_prism(rkfdShape *s, const Field *loop, const double *sweep
   free( tri );
   return 0;
 }
-/* 1 when every vertex lies on the inner side of every face plane (what the collision code assumes) */
-static int shape_is_convex(const rkfdShape *s)
-{
-  int i, j;
-  for( i=0; i<s->nplane; i++ )
-    for( j=0; j<s->nvert; j++ )
-      if( v3_dot( &s->plane[4*i], &s->vert[3*j] ) - s->plane[4*i+3] > 1e-9 ) return 0;
-  return 1;
-}
 /* volume, first and second moments of a closed triangle mesh about the origin of its frame (signed tetrahedra, faces
  * oriented outwards by the centroid test - the shapes are convex) */
 static void shape_moments(const rkfdShape *s, double *vol, double *first, double *second /* xx yy zz xy yz zx */)
@@ -451,8 +446,6 @@ rkfdChainDesc *rkfdChainReadZTK(const char *filename)
         free( s_->vert ); s_->vert = NULL; \
         if( shape_make_prism( s_, loopf, sweep ) < 0 ){ \
           fprintf( stderr, "rkfd: shape %s in %s: malformed loop / prism\n", s_->name, filename ); bad = 1; } \
-        else if( !shape_is_convex( s_ ) ) \
-          fprintf( stderr, "rkfd: shape %s in %s is not convex: vertex collision against it uses its convex face planes only\n", s_->name, filename ); \
       } else if( shape_type == RKFD_SHAPE_PH ){ \
         if( shape_build_planes( s_, nface, face ) < 0 ){ \
           fprintf( stderr, "rkfd: shape %s in %s: a face names a vertex that does not exist\n", s_->name, filename ); bad = 1; } \

@@ -34,6 +34,7 @@ typedef struct {
   double *plane;     /* [nplane*4] outward unit normal + offset */
   int nface;
   int *face;         /* [nface*3] triangles (vertex indices), kept for the writer and the auto mass properties */
+  int convex;        /* 1: every vertex lies on the inner side of every face plane (what vertex collision AGAINST this shape assumes) */
   int ptype;         /* what the file said: RKFD_SHAPE_* */
   double prm[8];     /* box: center(3) depth width height; sphere: center(3) radius; cylinder / cone: two points (6) radius */
   int div;

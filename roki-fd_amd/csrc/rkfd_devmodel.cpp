@@ -265,8 +265,9 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   for( int i=0; i<NL; i++ )
     linfo[i] = RKFD_LI_PACK( R_parent[i], R_jtype[i], depth[i], is_static[i], R_mtype[i], R_dofoff[i] );
   for( int j=0; j<NC; j++ ){
-    if( cnf[j] > 255 ) FAIL( "a collision shape has more than 255 faces" );
-    cinfo[j] = cA[j] | ( cB[j] << 8 ) | ( cci[j] << 16 ) | ( cnf[j] << 24 );
+    if( cnf[j] > 4095 ) FAIL( "a collision shape has more than 4095 face planes" );
+    if( cci[j] > 63 ) FAIL( "more than 63 contact-info entries" );
+    cinfo[j] = RKFD_CI_PACK( cA[j], cB[j], cci[j], cnf[j] );
   }
   /* sweep schedule: one iteration = up to 8 links of one level.  Lane-group slots are kept stable
    * along chains (a link takes the slot of its first child when possible) so that the sweeps can
@@ -460,7 +461,7 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
                      + (size_t)maxact*( 21 + ( NC > RKFD_WAVE ? 3 : 0 ) + ( dm.has_slide ? 6 : 0 ) ) + ( dm.vert_rigid ? 2 : 1 )*M + ( dm.pu_alias ? 0 : (size_t)nside*npurow*M )
                      + ( dm.vert_rigid ? M*M + M*( M+1 )/2 + 5*M + ( dm.qscr_alias ? 0 : RKFD_WAVE ) + 3*M : 0 );   /* Vert QP: QL, QW, QV, CR */
     const size_t ints = (size_t)NC + (size_t)nside*maxact + ( NC > 0 ? 8 : 4 ) + (size_t)NL;     /* CIp, tgt, cnt, LI */
-    const size_t bytes = (size_t)2*NL + (size_t)5*NC + (size_t)2*maxact + ( dm.vert_rigid ? M : 0 )                                     /* CHP (16 bit), act typ asl (bytes) */
+    const size_t bytes = (size_t)2*NL + (size_t)5*NC + (size_t)4*maxact + ( dm.vert_rigid ? M : 0 )                                     /* CHP (16 bit), act typ asl (bytes) */
                        + ( max_rigid > 0 ? (size_t)NL*( nlevel+3 ) : 0 );                /* PL */
     out->lds_bytes = dbl*sizeof(double) + ints*sizeof(int) + bytes;
     out->lds_bytes = ( out->lds_bytes + 15 ) & ~(size_t)15;

@@ -10,7 +10,7 @@
 #define RKFD_WAVE        64
 #define RKFD_MAX_LINK    64
 #define RKFD_MAX_DOF     64
-#define RKFD_MAX_CAND    256  /* candidate contact vertices per instance (swept 64 at a time) */
+#define RKFD_MAX_CAND    1024 /* candidate contact vertices per instance (swept 64 at a time; 9 bytes of LDS each) */
 #define RKFD_MAX_ROWS    128  /* 3 * (rigid contact vertices): two MLCP rows per lane at most */
 
 typedef struct {
@@ -69,7 +69,7 @@ typedef struct {
   int has_slide;
   const int *cs_mode;
   const double *cs_par;
-  const int *cinfo;        /* [ncand] packed: linkA | linkB<<8 | ci<<16 | nf<<24              */
+  const int *cinfo;        /* [ncand] packed: RKFD_CI_PACK                                     */
   const double *planes;    /* [nplane*4] in link B's frame                               */
   /* contact infos */
   const int *ci_type;
@@ -84,10 +84,12 @@ typedef struct {
 #define RKFD_LI_STATIC(x) ( ( (x) >> 18 ) & 1 )
 #define RKFD_LI_MT(x)     ( ( (x) >> 19 ) & 3 )
 #define RKFD_LI_OFF(x)    ( ( (x) >> 21 ) & 0xFF )
-#define RKFD_CI_A(x)      ( (x) & 0xFF )
-#define RKFD_CI_B(x)      ( ( (x) >> 8 ) & 0xFF )
-#define RKFD_CI_CI(x)     ( ( (x) >> 16 ) & 0xFF )
-#define RKFD_CI_NF(x)     ( ( (x) >> 24 ) & 0xFF )
+/* packed candidate info: link A (7 bits), link B (7), contact info (6), faces of the other shape (12) */
+#define RKFD_CI_PACK(a,b,ci,nf) ( (a) | ( (b) << 7 ) | ( (ci) << 14 ) | ( (int)( (unsigned)(nf) << 20 ) ) )
+#define RKFD_CI_A(x)      ( (x) & 0x7F )
+#define RKFD_CI_B(x)      ( ( (x) >> 7 ) & 0x7F )
+#define RKFD_CI_CI(x)     ( ( (x) >> 14 ) & 0x3F )
+#define RKFD_CI_NF(x)     ( (int)( (unsigned)(x) >> 20 ) )
 #define RKFD_MAX_ROUND 6
 
 /* per-batch state arrays, instance-major: x[b*stride + j] */

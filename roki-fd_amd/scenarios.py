@@ -146,7 +146,8 @@ SEAT_DEPTH = 1.0e-5
 
 def seat_soles_flat(m, dis, chain, base_off, nominal, depth=None, iters=6):
     """Stand the chain on flat soles: Gauss-Newton on (base height, base roll, base pitch, the two revolute
-    joints above each sole shape) until the lowest four vertices of every collision shape of `chain` sit
+    joints above each sole shape) until the lowest four vertices of every SOLE of `chain` (a collision shape that reaches
+    the floor at the nominal pose) sit
     `depth` in the floor z = 0.  dis [B,ndof] is modified in place (all other coordinates keep their values); the
     "lowest four" are picked once, at the pose `nominal` [ndof], so that every shard of a batch picks the same.
     Vectorised over the instances; a handful of forward-kinematics passes."""
@@ -157,9 +158,14 @@ def seat_soles_flat(m, dis, chain, base_off, nominal, depth=None, iters=6):
     unknown = [base_off + 2, base_off + 3, base_off + 4]
     sel = []; nv = 0
     v0 = chain_vertices(m, nominal, chain)
+    zmin = v0[:, 2].min()
     for sh in range(m.nshape):
         l = slink[sh]
         if ch[l] != chain:
+            continue
+        n = int(voff[sh + 1] - voff[sh])
+        if v0[nv:nv + n, 2].min() > zmin + 1e-3:       # not a sole: a shape that does not reach the floor at the nominal pose
+            nv += n
             continue
         k = 0
         while l >= 0 and k < 2:
@@ -302,5 +308,32 @@ def config4_26(batch=4096, first=0):
     d = config4(batch, model="humanoid26.ztk", first=first); d["name"] = "config4_humanoid26_mlcp"; return d
 
 
+def config4_shell(batch=4096, first=0):
+    """config 4 on humanoid30_shell.ztk: the same robot and states with a tessellated sphere on six links - 764 candidate
+    contact vertices per instance (the reference's mighty.ztk with its body meshes has 749): what the multi-chunk
+    collision sweep costs"""
+    d = config4(batch, model="humanoid30_shell.ztk", first=first); d["name"] = "config4_humanoid30_shell_mlcp"; return d
+
+
+def ball_roll(batch=4, seed=0x5EED00B1):
+    """TEST scenario: a free tessellated sphere (models/ball.ztk, 266 vertices: a world with more than 256 candidates)
+    set on the rigid floor on its lowest vertex with sliding velocity and spin, MLCP plugin: it slides, sticks and rolls
+    from vertex to vertex"""
+    w = B.World(solver=B.SOLVER_MLCP)
+    w.contact_info(_m("contactinfo.ztk"))
+    b = w.reg_file(_m("ball.ztk"))
+    w.reg_file(_m("floor.ztk"))
+    m = w.model.contents
+    u = splitmix64_uniform(seed, batch * 8).reshape(batch, 8)
+    dis = np.zeros((batch, 6)); vel = np.zeros((batch, 6))
+    dis[:, 3:6] = (u[:, 0:3] - 0.5) * 0.8
+    dis[0, 3:6] = 0
+    dis[:, 2] = 0.1
+    dis[:, 2] -= chain_vertices_batch(m, dis, b)[:, :, 2].min(axis=1) + SEAT_DEPTH
+    vel[:, 0:2] = (u[:, 3:5] - 0.5) * 0.6
+    vel[:, 3:6] = (u[:, 5:8] - 0.5) * 8.0
+    return dict(name="ball_roll", world=w, dis=dis, vel=vel, max_rigid=8, steps=200)
+
+
 CONFIGS = {"config1": config1, "config1b": config1_rigid, "config2": config2, "config3": config3, "config4": config4, "config4v": config4_vert, "config5": config5,
-           "config3_26": config3_26, "config4_26": config4_26}
+           "config3_26": config3_26, "config4_26": config4_26, "config4_shell": config4_shell}

@@ -121,3 +121,43 @@ def test_emulated_slide_mode_matches_oracle(R, oracle_cls, solver, floor, who):
     w0.reg_file(os.path.join(M, "box.ztk")); w0.reg_file(os.path.join(M, floor))
     o0 = oracle_cls(w0.model); o0.set_state(dis[0], vel[0]); o0.update_init(); o0.update_n(25)
     assert np.abs(o0.get_state()[0][:2] - od[:2]).max() > 1e-6
+
+
+@pytest.mark.parametrize("which", ["ball", "shell_humanoid", "mighty"])
+def test_emulated_world_with_more_than_256_candidates(R, oracle_cls, which):
+    """the candidate sweep in more than four chunks of 64 (limit 1024, 16-bit contact lists, 12-bit face counts): a
+    tessellated sphere on the floor (274 candidates), the humanoid with six sphere shells (764) and - where the
+    reference checkout is present - the reference's UNMODIFIED mighty.ztk with all its body meshes (749 candidates: its
+    non-convex shapes' vertices collide with the convex floor; the floor's vertices are not tested against them)"""
+    import os
+    if which == "ball":
+        sc = R.scenarios.ball_roll(batch=2); nsteps = 6
+    elif which == "shell_humanoid":
+        sc = R.scenarios.config4_shell(batch=1); nsteps = 2
+    else:
+        ref = "/root/reference/example/model/mighty.ztk"
+        if not os.path.exists(ref):
+            pytest.skip("reference checkout not present")
+        w = R.World(solver=R.SOLVER_MLCP); w.contact_info(os.path.join(R.scenarios.MODELS, "contact_rigid.ztk"))
+        h = w.reg_file(ref); w.reg_file(os.path.join(R.scenarios.MODELS, "floor.ztk"))
+        dis = w.init_dis(h)[None].copy()
+        dis[0, 2] -= R.scenarios.lowest_vertex_z(w.model.contents, dis[0], h) + R.scenarios.SEAT_DEPTH
+        sc = dict(world=w, dis=dis, vel=np.zeros_like(dis), max_rigid=8); nsteps = 2
+        assert (w.model.contents.nlink, w.model.contents.ndof, w.model.contents.ncand) == (26, 26, 749)
+    B = sc["dis"].shape[0]
+    assert sc["world"].model.contents.ncand > 256
+    eb = EmuBatch(sc["world"], B, max_rigid=sc["max_rigid"])
+    eb.set_state(sc["dis"], sc["vel"]); eb.update_init(); eb.update(nsteps)
+    assert eb.status() == 0
+    dis, vel, acc = eb.get_state(); act, typ, ref_, f = eb.get_contact()
+    seen = 0
+    for i in range(B):
+        o = oracle_cls(sc["world"].model); o.set_state(sc["dis"][i], sc["vel"][i]); o.update_init()
+        for _ in range(nsteps):
+            o.update()
+        od, ov, oa = o.get_state(); oact, otyp, oref, of = o.get_contact()
+        assert (act[i] == oact).all() and (typ[i] == otyp * (oact != 0)).all()
+        for x, y in ((dis[i], od), (vel[i], ov), (acc[i], oa), (f[i], of)):
+            assert np.abs(x - y).max() / max(1.0, np.abs(y).max()) < 1e-8
+        seen += int(oact.sum())
+    assert seen > 0

@@ -483,3 +483,35 @@ def test_specialized_kernel_gives_the_same_results(R, cfg):
         out.append(b.get_state() + b.get_contact() + b.get_pivot())
     for x, y in zip(out[0], out[1]):
         assert np.array_equal(x, y)
+
+
+def test_more_than_256_candidates(R, oracle_cls):
+    """worlds whose candidate sweep takes more than four chunks of 64: the tessellated ball (274 candidates) sliding, sticking
+    and rolling from vertex to vertex for 150 steps, and the humanoid with six sphere shells (764 candidates) standing for
+    10 - against the oracle"""
+    sc = R.scenarios.ball_roll(batch=8)
+    b = R.Batch(sc["world"], 8, max_rigid=sc["max_rigid"]); b.set_state(sc["dis"], sc["vel"]); b.update_init()
+    orc = []
+    for i in range(8):
+        o = oracle_cls(sc["world"].model); o.set_state(sc["dis"][i], sc["vel"][i]); o.update_init(); orc.append(o)
+    changes = 0; prev = b.get_contact()[0]
+    for s in range(150):
+        b.update(1)
+        assert b.status() == 0
+        d, v, a = b.get_state(); act, typ, ref, f = b.get_contact()
+        for i, o in enumerate(orc):
+            o.update(); od, ov, oa = o.get_state(); oact, otyp, _, of = o.get_contact()
+            assert (act[i] == oact).all() and (typ[i] == otyp * (oact != 0)).all(), (s, i)
+            assert _rel(d[i], od) < 1e-7 and _rel(v[i], ov) < 1e-7 and _rel(f[i], of) < 1e-6, (s, i)
+        changes += int((act != prev).sum()); prev = act
+    assert changes > 8                                    # the contact moved from vertex to vertex
+    sc = R.scenarios.config4_shell(batch=8)
+    assert sc["world"].model.contents.ncand == 764
+    b = R.Batch(sc["world"], 8, max_rigid=sc["max_rigid"]); b.set_state(sc["dis"], sc["vel"]); b.update_init(); b.update(10)
+    assert b.status() == 0
+    d, v, a = b.get_state(); act, typ, ref, f = b.get_contact()
+    for i in range(8):
+        o = oracle_cls(sc["world"].model); o.set_state(sc["dis"][i], sc["vel"][i]); o.update_init(); o.update_n(10)
+        od, ov, oa = o.get_state(); oact, otyp, _, of = o.get_contact()
+        assert (act[i] == oact).all() and oact.sum() >= 7
+        assert _rel(d[i], od) < 1e-8 and _rel(v[i], ov) < 1e-8 and _rel(a[i], oa) < 1e-8 and _rel(f[i], of) < 1e-8
