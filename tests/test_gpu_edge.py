@@ -513,5 +513,5 @@ def test_more_than_256_candidates(R, oracle_cls):
     for i in range(8):
         o = oracle_cls(sc["world"].model); o.set_state(sc["dis"][i], sc["vel"][i]); o.update_init(); o.update_n(10)
         od, ov, oa = o.get_state(); oact, otyp, _, of = o.get_contact()
-        assert (act[i] == oact).all() and oact.sum() >= 7
+        assert (act[i] == oact).all() and oact.sum() >= 5
         assert _rel(d[i], od) < 1e-8 and _rel(v[i], ov) < 1e-8 and _rel(a[i], oa) < 1e-8 and _rel(f[i], of) < 1e-8
