@@ -111,7 +111,8 @@ typedef struct {
   double L6[36];         /* float joints: Cholesky factor of IA */
   double tau, tf, jm;    /* joint torque, friction torque, motor inertia (1-DoF) */
   double qd, q;          /* 1-DoF joint rate / displacement */
-  double qdf[6];         /* float joint rate */
+  double qdf[6];         /* float joint rate; spherical joint: angular rate in [3..5] */
+  double S3[18], U3[18], Di3[9];   /* spherical joints: motion subspace (6x3, link frame), IA S, (S'IA S)^-1 */
 } Link;
 
 struct rkfdOracle {
@@ -149,7 +150,7 @@ rkfdOracle *rkfdOracleCreate(const rkfdModel *m)
   int i, j, nl = m->nlink, n = m->ndof, nc = m->ncand, k;
 
   for( i=0; i<nl; i++ )      /* joint types the loader reads but this restatement (like the device path) does not cover */
-    if( m->jtype[i] == RKFD_JOINT_SPHER || m->jtype[i] == RKFD_JOINT_BRFLOAT ) return NULL;
+    if( m->jtype[i] == RKFD_JOINT_BRFLOAT ) return NULL;
   o = (rkfdOracle *)zalloc( sizeof(rkfdOracle) );
 
   o->m = m; o->nl = nl; o->n = n; o->ncand = nc;
@@ -306,6 +307,13 @@ static void connect_state(rkfdOracle *o, const double *dis, const double *vel)
       m3_mulv( Ro, q, t ); v3_add( po, t, l->pa );
       memcpy( l->qdf, qd, sizeof(double)*6 );
     } break;
+    case RKFD_JOINT_SPHER: {
+      /* the rotational half of a float joint: displacement = angle-axis vector, rate = angular velocity, both in the
+       * joint-origin (org) frame  [UNVERIFIED-DEP, same convention as the float joint] */
+      m3_from_aa( q, l->Rj );
+      m3_mul( Ro, l->Rj, l->Ra ); v3_copy( po, l->pa );
+      memset( l->qdf, 0, sizeof(double)*3 ); memcpy( l->qdf+3, qd, sizeof(double)*3 );
+    } break;
     default:
       memcpy( l->Ra, Ro, sizeof(double)*9 ); v3_copy( po, l->pa );
     }
@@ -351,6 +359,16 @@ static void connect_state(rkfdOracle *o, const double *dis, const double *vel)
         v3_cross( wo, l->qdf+3, c2 ); m3_tmulv( l->Rj, c2, l->gam+3 );
         m3_tmulv( l->Rj, l->qdf, vj );   v3_add( l->v, vj, l->v );
         m3_tmulv( l->Rj, l->qdf+3, wj ); v3_add( l->v+3, wj, l->v+3 );
+      } break;
+      case RKFD_JOINT_SPHER: {
+        double wo[3], c2[3], wj[3];
+        int k, a_;
+        m3_tmulv( Ro, wp, wo );
+        v3_cross( wo, l->qdf+3, c2 ); m3_tmulv( l->Rj, c2, l->gam+3 );
+        m3_tmulv( l->Rj, l->qdf+3, wj ); v3_add( l->v+3, wj, l->v+3 );
+        /* motion subspace in the link frame: the org-frame axes seen from the link, angular rows only */
+        memset( l->S3, 0, sizeof(l->S3) );
+        for( k=0; k<3; k++ ) for( a_=0; a_<3; a_++ ) l->S3[3*( 3+k )+a_] = l->Rj[3*a_+k];   /* S3[row 3+k][col a] = (Rj')[k][a] */
       } break;
       default: break;
       }
@@ -540,6 +558,24 @@ static void aba_bias_link(rkfdOracle *o, int i, double *newcontrib)
     /* a free joint transmits only its own generalized force (zero) */
     for( k=0; k<6; k++ ){ u[k] = 0; pa[k] = 0; }
     break;
+  case RKFD_JOINT_SPHER: {
+    /* u = - S' pA (no joint torque), pa = pA + Ia gam + U D^-1 u with Ia = IA - U D^-1 U' */
+    double ug[3], w3[3], z3[3];
+    int a_, b_;
+    for( a_=0; a_<3; a_++ ){
+      u[a_] = 0; ug[a_] = 0;
+      for( k=0; k<6; k++ ){ u[a_] -= l->S3[3*k+a_]*pA[k]; ug[a_] += l->U3[3*k+a_]*l->gam[k]; }
+    }
+    for( a_=0; a_<3; a_++ ){
+      w3[a_] = 0; z3[a_] = 0;
+      for( b_=0; b_<3; b_++ ){ w3[a_] += l->Di3[3*a_+b_]*u[b_]; z3[a_] += l->Di3[3*a_+b_]*ug[b_]; }
+    }
+    m6_mulv( l->IA, l->gam, t );
+    for( k=0; k<6; k++ ){
+      pa[k] = pA[k] + t[k];
+      for( a_=0; a_<3; a_++ ) pa[k] += l->U3[3*k+a_]*( w3[a_] - z3[a_] );
+    }
+  } break;
   default:
     m6_mulv( l->IA, l->gam, t );
     for( k=0; k<6; k++ ) pa[k] = pA[k] + t[k];
@@ -573,6 +609,27 @@ static void aba_backward_full(rkfdOracle *o)
       chol6( l->IA, l->L6 );
       memset( Ia, 0, sizeof(Ia) );
       break;
+    case RKFD_JOINT_SPHER: {
+      double D3[9], det;
+      int a_, b_;
+      for( k=0; k<6; k++ ) for( a_=0; a_<3; a_++ ){
+        l->U3[3*k+a_] = 0;
+        for( j=0; j<6; j++ ) l->U3[3*k+a_] += l->IA[6*k+j]*l->S3[3*j+a_];
+      }
+      for( a_=0; a_<3; a_++ ) for( b_=0; b_<3; b_++ ){
+        D3[3*a_+b_] = 0;
+        for( k=0; k<6; k++ ) D3[3*a_+b_] += l->S3[3*k+a_]*l->U3[3*k+b_];
+      }
+      det = D3[0]*( D3[4]*D3[8]-D3[5]*D3[7] ) - D3[1]*( D3[3]*D3[8]-D3[5]*D3[6] ) + D3[2]*( D3[3]*D3[7]-D3[4]*D3[6] );
+      l->Di3[0] = ( D3[4]*D3[8]-D3[5]*D3[7] )/det; l->Di3[1] = ( D3[2]*D3[7]-D3[1]*D3[8] )/det; l->Di3[2] = ( D3[1]*D3[5]-D3[2]*D3[4] )/det;
+      l->Di3[3] = ( D3[5]*D3[6]-D3[3]*D3[8] )/det; l->Di3[4] = ( D3[0]*D3[8]-D3[2]*D3[6] )/det; l->Di3[5] = ( D3[2]*D3[3]-D3[0]*D3[5] )/det;
+      l->Di3[6] = ( D3[3]*D3[7]-D3[4]*D3[6] )/det; l->Di3[7] = ( D3[1]*D3[6]-D3[0]*D3[7] )/det; l->Di3[8] = ( D3[0]*D3[4]-D3[1]*D3[3] )/det;
+      for( k=0; k<6; k++ ) for( j=0; j<6; j++ ){
+        double s_ = 0;
+        for( a_=0; a_<3; a_++ ) for( b_=0; b_<3; b_++ ) s_ += l->U3[3*k+a_]*l->Di3[3*a_+b_]*l->U3[3*j+b_];
+        Ia[6*k+j] = l->IA[6*k+j] - s_;
+      }
+    } break;
     default:
       memcpy( Ia, l->IA, sizeof(Ia) );
     }
@@ -629,6 +686,18 @@ static void aba_forward(rkfdOracle *o, double *acc)
       for( k=0; k<6; k++ ) d[k] = l->a[k] - y[k];
       m3_mulv( l->Rj, d, acc + m->dofoff[i] );
       m3_mulv( l->Rj, d+3, acc + m->dofoff[i] + 3 );
+    } break;
+    case RKFD_JOINT_SPHER: {
+      double r3[3], qdd[3];
+      int a_, b_;
+      for( a_=0; a_<3; a_++ ){
+        r3[a_] = o->u[6*i+a_];
+        for( k=0; k<6; k++ ) r3[a_] -= l->U3[3*k+a_]*y[k];
+      }
+      for( a_=0; a_<3; a_++ ){ qdd[a_] = 0; for( b_=0; b_<3; b_++ ) qdd[a_] += l->Di3[3*a_+b_]*r3[b_]; }
+      memcpy( l->a, y, sizeof(y) );
+      for( k=0; k<6; k++ ) for( a_=0; a_<3; a_++ ) l->a[k] += l->S3[3*k+a_]*qdd[a_];
+      for( a_=0; a_<3; a_++ ) acc[m->dofoff[i]+a_] = qdd[a_];
     } break;
     default:
       memcpy( l->a, y, sizeof(y) );
@@ -1338,6 +1407,13 @@ static void cat_dis(const rkfdOracle *o, const double *x, double k, const double
       m3_from_aa( aa, Rk ); m3_from_aa( x+off+3, R0 );
       m3_mul( Rk, R0, Rn );
       m3_to_aa( Rn, xn+off+3 );
+    } break;
+    case RKFD_JOINT_SPHER: {
+      double aa[3], Rk[9], R0[9], Rn[9];
+      v3_mul( v+off, k, aa );
+      m3_from_aa( aa, Rk ); m3_from_aa( x+off, R0 );
+      m3_mul( Rk, R0, Rn );
+      m3_to_aa( Rn, xn+off );
     } break;
     case RKFD_JOINT_FIXED: break;
     default: xn[off] = x[off] + k*v[off];

@@ -56,6 +56,15 @@ template<bool prof> RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, c
       d_mul33( o, Rj, R );
       d_mulv( o, qq, t );
       p[0] += t[0]; p[1] += t[1]; p[2] += t[2];
+    } else if( jt >= RKFD_DJT_SPHX ){
+      /* spherical joint as three device links (RKFD_DJT_SPH*): the pseudo-links sit in the joint-origin frame, the real
+       * link (SPHZ, last coordinate) is turned by the angle-axis vector of all three coordinates */
+      qd1 = L.qd[off];
+      if( jt == RKFD_DJT_SPHZ ){
+        const double aa[3] = { L.q[off-2], L.q[off-1], L.q[off] };
+        d_from_aa( aa, Rj );
+        d_mul33( o, Rj, R );
+      }
     }
   }
   if( on ){
@@ -113,6 +122,17 @@ template<bool prof> RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, c
       S[3]=z[0]; S[4]=z[1]; S[5]=z[2];
 #pragma unroll
       for( int k=0; k<6; k++ ) vJ[k] = S[k]*qd1;
+    } else if( jt >= RKFD_DJT_SPHX ){
+      /* axis k of the joint-origin frame through the joint centre: that frame is the pseudo-links' own, and R Rj' for the real link */
+      double ax[3] = { R[0], R[3], R[6] };
+      if( jt == RKFD_DJT_SPHY ){ ax[0] = R[1]; ax[1] = R[4]; ax[2] = R[7]; }
+      if( jt == RKFD_DJT_SPHZ ){
+        /* third column of R Rj' = R ( third row of Rj )' */
+        ax[0] = R[0]*Rj[6] + R[1]*Rj[7] + R[2]*Rj[8]; ax[1] = R[3]*Rj[6] + R[4]*Rj[7] + R[5]*Rj[8]; ax[2] = R[6]*Rj[6] + R[7]*Rj[7] + R[8]*Rj[8];
+      }
+      S[0]=ax[0]; S[1]=ax[1]; S[2]=ax[2]; d_cross( p, ax, S+3 );
+#pragma unroll
+      for( int k=0; k<6; k++ ) vJ[k] = S[k]*qd1;
     } else if( jt == RKFD_JOINT_FLOAT ){
       /* world orientation of the joint-origin frame: Row = R Rj' */
       double RjT[9] = { Rj[0],Rj[3],Rj[6], Rj[1],Rj[4],Rj[7], Rj[2],Rj[5],Rj[8] };
@@ -156,6 +176,18 @@ template<bool prof> RKFD_DEV void rkfd_phase_kinematics(const rkfdDevModel &m, c
     KST(19);
     /* velocity-product acceleration c = v x vJ (+ float-joint term) */
     double c[6];
+    if( jt >= RKFD_DJT_SPHX ){
+      /* spherical joint: its three axes are fixed in the parent-side frame, so the term of the whole joint is
+       * v x ( S w ) with S w = the link's velocity minus that of the link in front of the joint; it sits on the real
+       * link, the pseudo-links carry none */
+      double vt[6] = {0,0,0,0,0,0};
+      if( jt == RKFD_DJT_SPHZ ){
+        const int p1 = RKFD_LI_PAR( li ), p2 = RKFD_LI_PAR( L.LI[p1] ), rp = RKFD_LI_PAR( L.LI[p2] );
+#pragma unroll
+        for( int k=0; k<6; k++ ) vt[k] = v[k] - ( rp >= 0 ? L.V[6*rp+k] : 0.0 );
+      }
+      d_crm( v, vt, c );
+    } else
     d_crm( v, vJ, c );
     if( jt == RKFD_JOINT_FLOAT ){
       double vw[3] = { L.S[6*i], L.S[6*i+1], L.S[6*i+2] }, ww[3] = { vJ[0], vJ[1], vJ[2] }, t[3];

@@ -248,7 +248,7 @@ RKFD_DEV void rkfd_mlcp_matrix_mfma(const rkfdDevModel &m, const rkfdLds &L, int
     const int j = j0 + kk;
     const int lij = j < NL ? L.LI[j] : 0, jt = RKFD_LI_JT( lij ), d = RKFD_LI_DEPTH( lij );
     double a0 = 0, a1 = 0;
-    if( j < NL && ( jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM ) ){
+    if( j < NL && RKFD_JT_IS1( jt ) ){
       a0 = RKFD_NP_ELEM( e00, 0, col0 ) + RKFD_NP_ELEM( e01, 1, col0 );
       a1 = RKFD_NP_ELEM( e10, 0, col1 ) + RKFD_NP_ELEM( e11, 1, col1 );
     }
@@ -363,7 +363,7 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
       const int top = TOP[a];
       if( NSD == 1 && top == 255 ) continue;
       const int lit = L.LI[top == 255 ? 0 : top], jtt = RKFD_LI_JT( lit );
-      const int d0 = RKFD_LI_DEPTH( lit ) + ( jtt == RKFD_JOINT_REVOL || jtt == RKFD_JOINT_PRISM ? 0 : 1 );
+      const int d0 = RKFD_LI_DEPTH( lit ) + ( RKFD_JT_IS1( jtt ) ? 0 : 1 );
       const unsigned e = (unsigned)a | ( (unsigned)RKFD_LI_DEPTH( L.LI[a] ) << 8 ) | ( (unsigned)top << 14 ) | ( (unsigned)d0 << 22 )
                        | ( jtt == RKFD_JOINT_FLOAT ? 1u << 29 : 0u ) | ( (unsigned)sd << 30 ) | ( top != 255 ? 1u << 31 : 0u );
       L.tgt[NSD == 1 ? lane : 2*lane+sd] = (int)e;
@@ -372,7 +372,7 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
   /* sqrt(1/D) of the 1-DoF joints (MS slot 2: the driving torque kept there is dead after sweep 2) */
   if( lane < NL ){
     const int jt = RKFD_LI_JT( L.LI[lane] );
-    if( jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM ) L.MS[3*lane+2] = sqrt( L.MS[3*lane+0] );
+    if( RKFD_JT_IS1( jt ) ) L.MS[3*lane+2] = sqrt( L.MS[3*lane+0] );
   }
   SYNC();
   MST(14);
@@ -606,7 +606,7 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
       const int fq = isf ? ( t-NL )%6 : 0;
       const int link = isl ? t : ( isf ? FLK[( t-NL )/6] : 0 );
       const int lii = L.LI[link], jt = RKFD_LI_JT( lii );
-      const bool is1 = isl && ( jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM );
+      const bool is1 = isl && RKFD_JT_IS1( jt );
       const int dpt = isl ? RKFD_LI_DEPTH( lii ) : 0;
       const int row = isf ? NLV+fq : dpt;
       double sum = 0;

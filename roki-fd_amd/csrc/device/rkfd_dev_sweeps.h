@@ -146,7 +146,7 @@ template<bool prof> RKFD_DEV void rkfd_phase_sweep2(const rkfdDevModel &m, const
     const bool on = onl && r < 6;
     const int i = onl ? rec.i : 0;
     const int jt = onl ? RKFD_LI_JT( rec.li ) : RKFD_JOINT_FIXED;
-    const bool is1 = jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM;
+    const bool is1 = RKFD_JT_IS1( jt );
     const bool isf = jt == RKFD_JOINT_FLOAT;
     double row[6], pr = pre.pb;
 #pragma unroll
@@ -261,7 +261,7 @@ template<bool delta> RKFD_DEV void rkfd_phase_sweep3(const rkfdDevModel &m, cons
     const bool on = onl && r < 6;
     const int i = onl ? rec.i : 0;
     const int jt = onl ? RKFD_LI_JT( rec.li ) : RKFD_JOINT_FIXED;
-    const bool is1 = jt == RKFD_JOINT_REVOL || jt == RKFD_JOINT_PRISM;
+    const bool is1 = RKFD_JT_IS1( jt );
     const int par = onl ? RKFD_LI_PAR( rec.li ) : -1;
     const int off = RKFD_LI_OFF( rec.li );
     double ap;

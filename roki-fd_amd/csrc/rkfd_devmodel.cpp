@@ -35,8 +35,8 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   if( max_rigid < 0 ) max_rigid = 0;
   if( 3*max_rigid > RKFD_MAX_ROWS ) FAIL( "3*max_rigid %d exceeds the per-wave limit %d", 3*max_rigid, RKFD_MAX_ROWS );
   for( int i=0; i<NLm; i++ ){
-    if( m->jtype[i] == RKFD_JOINT_SPHER || m->jtype[i] == RKFD_JOINT_BRFLOAT )
-      FAIL( "link %d has a %s joint: read by the loader, but without a device path (DESIGN.md, out of scope)", i, m->jtype[i] == RKFD_JOINT_SPHER ? "spherical" : "breakable float" );
+    if( m->jtype[i] == RKFD_JOINT_BRFLOAT )
+      FAIL( "link %d has a breakable float joint: read by the loader, but without a device path (DESIGN.md, out of scope)", i );
     if( m->parent[i] >= i ) FAIL( "link %d: parent index must be smaller than the link index", i );
   }
 
@@ -64,14 +64,41 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
       rep[i] = rep[p];
       accs[rep[i]].parts.push_back( i );
     } else {
+      const bool sph = m->jtype[i] == RKFD_JOINT_SPHER;
+      if( sph ){
+        /* two massless pseudo-links in front of the real one (see RKFD_DJT_SPH*): the first carries the org frame */
+        for( int q=0; q<2; q++ ){
+          const int rq = (int)orig.size();
+          orig.push_back( i );
+          Acc a; a.m = 0; a.mc[0] = a.mc[1] = a.mc[2] = 0;
+          accs.push_back( a );
+          R_parent.push_back( q == 0 ? ( p < 0 ? -1 : rep[p] ) : rq-1 );
+          R_jtype.push_back( q == 0 ? RKFD_DJT_SPHX : RKFD_DJT_SPHY ); R_dofoff.push_back( m->dofoff[i]+q ); R_mtype.push_back( RKFD_MOTOR_NONE );
+          double oo[12];
+          if( q == 1 || p < 0 ) for( int k=0; k<12; k++ ) oo[k] = q == 1 ? ( ( k == 0 || k == 4 || k == 8 ) ? 1.0 : 0.0 ) : o[k];
+          else {
+            const double *Tp = &Trep[12*p];
+            for( int a=0; a<3; a++ ){
+              for( int b=0; b<3; b++ ) oo[3*a+b] = Tp[3*a]*o[b] + Tp[3*a+1]*o[3+b] + Tp[3*a+2]*o[6+b];
+              oo[9+a] = Tp[9+a] + Tp[3*a]*o[9] + Tp[3*a+1]*o[10] + Tp[3*a+2]*o[11];
+            }
+          }
+          R_org.insert( R_org.end(), oo, oo+12 );
+        }
+      }
       const int r = (int)orig.size();
       rep[i] = r; orig.push_back( i );
       double *T = &Trep[12*i];
       for( int k=0; k<12; k++ ) T[k] = ( k == 0 || k == 4 || k == 8 ) ? 1.0 : 0.0;
       Acc a; a.m = 0; a.mc[0] = a.mc[1] = a.mc[2] = 0; a.parts.push_back( i );
       accs.push_back( a );
-      R_parent.push_back( p < 0 ? -1 : rep[p] );
-      R_jtype.push_back( m->jtype[i] ); R_dofoff.push_back( m->dofoff[i] ); R_mtype.push_back( m->mtype[i] );
+      R_parent.push_back( sph ? r-1 : ( p < 0 ? -1 : rep[p] ) );
+      R_jtype.push_back( sph ? RKFD_DJT_SPHZ : m->jtype[i] ); R_dofoff.push_back( m->dofoff[i] + ( sph ? 2 : 0 ) ); R_mtype.push_back( sph ? RKFD_MOTOR_NONE : m->mtype[i] );
+      if( sph ){
+        const double id[12] = { 1,0,0, 0,1,0, 0,0,1, 0,0,0 };
+        R_org.insert( R_org.end(), id, id+12 );
+        continue;
+      }
       /* org' = T(rep[p]<-p) o org_i */
       double oo[12];
       if( p < 0 ) for( int k=0; k<12; k++ ) oo[k] = o[k];
@@ -102,7 +129,7 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
     }
     double com[3] = {0,0,0};
     if( M > 0 ) for( int a=0; a<3; a++ ) com[a] = mc[a]/M;
-    else for( int a=0; a<3; a++ ) com[a] = cs[a];
+    else if( !cs.empty() ) for( int a=0; a<3; a++ ) com[a] = cs[a];
     double I[9] = {0,0,0,0,0,0,0,0,0};
     for( size_t q=0; q<accs[r].parts.size(); q++ ){
       const int i = accs[r].parts[q];
@@ -393,8 +420,10 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   dm.npurow = npurow;
   dm.pu_alias = ( (size_t)nside*npurow*Mrows <= (size_t)12*NL ) ? 1 : 0;
   std::vector<int> dofkind( ND ? ND : 1, 0 );
-  for( int i=0; i<NL; i++ )
+  for( int i=0; i<NL; i++ ){
     if( R_jtype[i] == RKFD_JOINT_FLOAT ){ dofkind[R_dofoff[i]+3] = 1; dofkind[R_dofoff[i]+4] = 2; dofkind[R_dofoff[i]+5] = 2; }
+    if( R_jtype[i] == RKFD_DJT_SPHX ){ dofkind[R_dofoff[i]] = 1; dofkind[R_dofoff[i]+1] = 2; dofkind[R_dofoff[i]+2] = 2; }   /* angle-axis coordinates */
+  }
   if( nround > RKFD_MAX_ROUND ) FAIL( "tree too deep" );
   /* record offsets first (the vector may reallocate), then resolve */
   struct Ent { const void **slot; size_t off; };

@@ -76,6 +76,15 @@ typedef struct {
   const double *ci_sf, *ci_kf, *ci_k, *ci_l, *ci_e, *ci_v;
 } rkfdDevModel;
 
+/* DEVICE joint kinds beyond the model's fixed / revolute / prismatic / float (the 3-bit jt field of linfo).  A spherical joint of the
+ * model becomes three device links: two massless pseudo-links and the real one, each a revolute joint about one axis (x, y, z)
+ * of the joint-origin frame through the joint centre - three rank-1 eliminations in the sweeps equal the rank-3 one (block
+ * elimination), the probes and the PGS see ordinary 1-DoF joints.  The axes are fixed in the PARENT-side frame and the whole
+ * velocity-product term sits on the real link (rkfd_dev_kinematics.h). */
+#define RKFD_DJT_SPHX 4
+#define RKFD_DJT_SPHY 5
+#define RKFD_DJT_SPHZ 6
+#define RKFD_JT_IS1(jt) ( (jt) == RKFD_JOINT_REVOL || (jt) == RKFD_JOINT_PRISM || (jt) >= RKFD_DJT_SPHX )
 #define RKFD_LI_PACK(par,jt,depth,stat,mt,off) \
   ( ((par)+1) | ((jt)<<8) | ((depth)<<11) | ((stat)<<18) | ((mt)<<19) | ((off)<<21) )
 #define RKFD_LI_PAR(x)    ( ( (x) & 0xFF ) - 1 )

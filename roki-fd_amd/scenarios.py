@@ -335,5 +335,25 @@ def ball_roll(batch=4, seed=0x5EED00B1):
     return dict(name="ball_roll", world=w, dis=dis, vel=vel, max_rigid=8, steps=200)
 
 
+def arm_spher(batch=4, contact=False, seed=0x5EED00C1):
+    """TEST scenario: models/arm_spher.ztk - a fixed base and three links on SPHERICAL joints (the joint type of the
+    reference's arm.ztk / dualarm.ztk) over the rigid floor, MLCP plugin.  contact=False: random configurations and
+    rates, swinging freely (frictionless: energy is conserved); contact=True: the arm points straight down with its
+    box-shaped hand flat on the floor, the two outer joints moving"""
+    w = B.World(solver=B.SOLVER_MLCP)
+    w.contact_info(_m("contactinfo.ztk"))
+    w.reg_file(_m("arm_spher.ztk"))
+    w.reg_file(_m("floor.ztk"))
+    m = w.model.contents
+    u = splitmix64_uniform(seed, batch * 2 * m.ndof).reshape(batch, 2 * m.ndof)
+    if contact:
+        dis = np.zeros((batch, m.ndof)); vel = np.zeros((batch, m.ndof))
+        dis[:, 0] = np.pi
+        vel[:, 3:] = (u[:, :6] - 0.5)
+    else:
+        dis = (u[:, :m.ndof] - 0.5) * 1.2; vel = (u[:, m.ndof:] - 0.5) * 4.0
+    return dict(name="arm_spher" + ("_contact" if contact else ""), world=w, dis=dis, vel=vel, max_rigid=8, steps=200)
+
+
 CONFIGS = {"config1": config1, "config1b": config1_rigid, "config2": config2, "config3": config3, "config4": config4, "config4v": config4_vert, "config5": config5,
            "config3_26": config3_26, "config4_26": config4_26, "config4_shell": config4_shell}

@@ -161,3 +161,45 @@ def test_emulated_world_with_more_than_256_candidates(R, oracle_cls, which):
             assert np.abs(x - y).max() / max(1.0, np.abs(y).max()) < 1e-8
         seen += int(oact.sum())
     assert seen > 0
+
+
+@pytest.mark.parametrize("which", ["free", "contact", "ref_arm"])
+def test_emulated_spherical_joints(R, oracle_cls, which):
+    """spherical joints: on the device a spherical joint is three pseudo-links with revolute joints about the axes of the
+    joint-origin frame (three rank-1 eliminations = the rank-3 one), in the oracle a genuine 3-DoF joint with a 3x3
+    joint-space inertia - two independent formulations.  models/arm_spher.ztk swinging freely and pressing its hand on
+    the floor (contact paths through the pseudo-links), and - where the reference checkout is present - the
+    reference's own arm.ztk (four spherical joints in series, `COM: auto` / `inertia: auto`; dualarm.ztk gives its
+    links no mass - a kinematic model, it loads but has no dynamics to compare)"""
+    import os
+    if which in ("free", "contact"):
+        sc = R.scenarios.arm_spher(batch=2, contact=which == "contact"); nsteps = 2 if which == "contact" else 5
+    else:
+        ref = "/root/reference/example/model/arm.ztk"
+        if not os.path.exists(ref):
+            pytest.skip("reference checkout not present")
+        w = R.World(solver=R.SOLVER_MLCP); w.contact_info(os.path.join(R.scenarios.MODELS, "contactinfo.ztk"))
+        w.reg_file(ref)           # (alone: with the floor its tessellated spheres and cylinders make 2361 candidates, above the limit of 1024)
+        m = w.model.contents
+        rng = np.random.default_rng(3)
+        sc = dict(world=w, dis=rng.uniform(-0.4, 0.4, (2, m.ndof)), vel=rng.uniform(-1, 1, (2, m.ndof)), max_rigid=8); nsteps = 3
+    B = sc["dis"].shape[0]
+    eb = EmuBatch(sc["world"], B, max_rigid=sc["max_rigid"])
+    eb.set_state(sc["dis"], sc["vel"]); eb.update_init(); eb.update(nsteps)
+    assert eb.status() == 0
+    dis, vel, acc = eb.get_state(); act, typ, ref_, f = eb.get_contact()
+    seen = 0
+    for i in range(B):
+        o = oracle_cls(sc["world"].model); o.set_state(sc["dis"][i], sc["vel"][i]); o.update_init()
+        for _ in range(nsteps):
+            o.update()
+        od, ov, oa = o.get_state()
+        for x, y in ((dis[i], od), (vel[i], ov), (acc[i], oa)):
+            assert np.abs(x - y).max() / max(1.0, np.abs(y).max()) < 1e-8
+        if eb.ncand:
+            oact, otyp, oref, of = o.get_contact()
+            assert (act[i] == oact).all()
+            assert np.abs(f[i] - of).max() / max(1.0, np.abs(of).max()) < 1e-8
+            seen += int(oact.sum())
+    if which == "contact":
+        assert seen > 0

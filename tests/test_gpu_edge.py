@@ -515,3 +515,29 @@ def test_more_than_256_candidates(R, oracle_cls):
         od, ov, oa = o.get_state(); oact, otyp, _, of = o.get_contact()
         assert (act[i] == oact).all() and oact.sum() >= 5
         assert _rel(d[i], od) < 1e-8 and _rel(v[i], ov) < 1e-8 and _rel(a[i], oa) < 1e-8 and _rel(f[i], of) < 1e-8
+
+
+@pytest.mark.parametrize("contact", [False, True], ids=["free", "contact"])
+def test_spherical_joints(R, oracle_cls, contact):
+    """models/arm_spher.ztk: three links on spherical joints (device: three pseudo-links per joint; oracle: a genuine 3-DoF
+    joint) swinging freely for 200 steps, and pressing the hand on the rigid floor (contact paths through the
+    pseudo-links) - against the oracle"""
+    B = 16
+    sc = R.scenarios.arm_spher(batch=B, contact=contact)
+    b = R.Batch(sc["world"], B, max_rigid=sc["max_rigid"]); b.set_state(sc["dis"], sc["vel"]); b.update_init()
+    orc = []
+    for i in range(B):
+        o = oracle_cls(sc["world"].model); o.set_state(sc["dis"][i], sc["vel"][i]); o.update_init(); orc.append(o)
+    seen = 0
+    for s in range(8 if contact else 4):
+        n = 1 if contact else 50
+        b.update(n)
+        assert b.status() == 0
+        d, v, a = b.get_state(); act, typ, ref, f = b.get_contact()
+        for i, o in enumerate(orc):
+            o.update_n(n); od, ov, oa = o.get_state(); oact, otyp, _, of = o.get_contact()
+            assert (act[i] == oact).all() and (typ[i] == otyp * (oact != 0)).all()
+            tol = 1e-7 if contact else 1e-9
+            assert _rel(d[i], od) < tol and _rel(v[i], ov) < tol and _rel(a[i], oa) < tol and _rel(f[i], of) < tol, (s, i)
+            seen += int(oact.sum())
+    assert (seen > 0) == contact

@@ -122,8 +122,8 @@ def test_reference_drivers_compile_and_link_unmodified(R, tmp_path):
 def test_reader_loads_the_reference_shipped_models(R):
     """the independent ZTK reader against the reference's own example models (read as data): all 12 load - curved
     primitives (sphere / cylinder / cone) as convex polyhedra, `COM: auto` / `inertia: auto` from the shapes,
-    spherical (3 DoF) and breakable-float (6 DoF) joints with their sizes.  Worlds with the last two are refused by
-    the device path with a message, not mis-simulated."""
+    spherical (3 DoF) and breakable-float (6 DoF) joints with their sizes.  A world with a breakable-float joint is
+    refused by the device path with a message, not mis-simulated."""
     expect = {"arm_2DoF.ztk": (3, 2), "arm_2DoF_trq.ztk": (3, 2), "box.ztk": (1, 6), "box_small.ztk": (1, 6), "crawler.ztk": (3, 6),
               "floor.ztk": (1, 0), "floor_hardsoft.ztk": (2, 0), "mighty.ztk": (25, 26), "puma.ztk": (7, 6),
               "arm.ztk": (6, 12), "dualarm.ztk": None, "wall.ztk": None}
@@ -150,11 +150,14 @@ def test_reader_loads_the_reference_shipped_models(R):
     I = m.arr("inertia", 9 * m.nlink).reshape(-1, 3, 3)
     for i in range(1, m.nlink):
         assert np.allclose(I[i], I[i].T) and (np.linalg.eigvalsh(I[i]) > 0).all()
-    # spherical / breakable-float joints: read, but refused by the device path (and the oracle) with a message
-    for f in ("arm.ztk", "wall.ztk"):
+    # spherical joints run on the device (three pseudo-links per joint); breakable-float joints are read, but a world
+    # that holds one is refused by the device path (and the oracle) with a message
+    for f in ("arm.ztk", "dualarm.ztk"):
         w = R.World(); w.reg_file(os.path.join(REF_MODELS, f))
-        assert R.lib().rkfdLdsBytesFor(w.model, 0) < 0
-        assert b"joint" in R.lib().rkfdHipLastError()
+        assert R.lib().rkfdLdsBytesFor(w.model, 0) > 0, R.lib().rkfdHipLastError()
+    w = R.World(); w.reg_file(os.path.join(REF_MODELS, "wall.ztk"))
+    assert R.lib().rkfdLdsBytesFor(w.model, 0) < 0
+    assert b"breakable float" in R.lib().rkfdHipLastError()
 
 
 def test_auto_mass_properties_of_a_box(R, tmp_path):

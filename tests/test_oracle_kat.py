@@ -237,3 +237,32 @@ def test_flop_counting_build_matches_the_plain_oracle(R):
     pd, pv, pa = plain.get_state()
     assert np.array_equal(dis, pd) and np.array_equal(acc, pa)
     assert 1e5 < flops < 2e6
+
+
+def test_spherical_joint_conserves_energy(R, oracle_cls):
+    """the oracle's spherical joint (3x3 joint-space inertia, angle-axis coordinates composed as rotations): three links
+    with off-axis centres of mass and full inertia tensors swinging freely at ~2 rad/s - total energy (13 J) is conserved
+    to 4e-7 J over 0.2 s, and the drift falls 4x when the step is halved: stage states are formed as x (+) h sum c_i k_i
+    with rotations COMPOSED (rkChainCatJointDisAll, reference src/rkfd_sim.c:306-320), which is second order on the
+    rotation group (the revolute chain, where (+) is plain addition, shows the scheme's 4th order: test above)"""
+    import os
+    drift = []
+    for dt in (2e-3, 1e-3):
+        w = R.World(solver=R.SOLVER_MLCP, dt=dt); w.reg_file(os.path.join(R.scenarios.MODELS, "arm_spher.ztk"))
+        m = w.model.contents
+        mass = m.arr("mass", m.nlink); com = m.arr("com", 3 * m.nlink).reshape(-1, 3); I = m.arr("inertia", 9 * m.nlink).reshape(-1, 3, 3)
+        rng = np.random.default_rng(5)
+        dis = rng.uniform(-0.6, 0.6, m.ndof); vel = rng.uniform(-2, 2, m.ndof)
+
+        def energy(o):
+            Rw, pw = o.link_frames(); v, _ = o.link_vel_acc()
+            e = 0.0
+            for i in range(m.nlink):
+                vc = v[i, :3] + np.cross(v[i, 3:], com[i])
+                e += 0.5 * mass[i] * vc @ vc + 0.5 * v[i, 3:] @ I[i] @ v[i, 3:] + mass[i] * 9.80665 * (pw[i] + Rw[i] @ com[i])[2]
+            return e
+        o = oracle_cls(w.model); o.set_state(dis, vel); o.update_init()
+        e0 = energy(o)
+        o.update_n(int(round(0.2 / dt)))
+        drift.append(abs(energy(o) - e0))
+    assert drift[1] < 1e-6 and 3.0 < drift[0] / drift[1] < 32.0, drift
