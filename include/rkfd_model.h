@@ -25,9 +25,10 @@
 extern "C" {
 #endif
 
-/* SPHER (3 DoF, angle-axis) and BRFLOAT (RoKi's breakable float joint: 6 DoF, rigid until a force / torque threshold is
- * passed) are read by the loader so that every model the reference ships can be inspected; they have no device path
- * (rkfdBatchCreate refuses a world that holds one, with a message) */
+/* SPHER: 3 DoF, displacement = angle-axis vector, rate = angular velocity, both in the joint-origin frame (the rotational half of
+ * the float joint's convention).  BRFLOAT (RoKi's breakable float joint: 6 DoF, rigid until a force / torque threshold is passed)
+ * is read by the loader so that every model the reference ships can be inspected; it has no device path (rkfdBatchCreate
+ * refuses a world that holds one, with a message) */
 enum { RKFD_JOINT_FIXED = 0, RKFD_JOINT_REVOL = 1, RKFD_JOINT_PRISM = 2, RKFD_JOINT_FLOAT = 3, RKFD_JOINT_SPHER = 4, RKFD_JOINT_BRFLOAT = 5 };
 enum { RKFD_MOTOR_NONE = 0, RKFD_MOTOR_TRQ = 1, RKFD_MOTOR_DC = 2 };
 /* contact-info type, cf. RK_CONTACT_RIGID / RK_CONTACT_ELASTIC (reference src/rkfd_cd.c:39-46) */
