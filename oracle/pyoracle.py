@@ -38,6 +38,9 @@ def _bind(path):
     L.rkfdOracleGetLinkFrames.argtypes = [vp, vp, vp]
     L.rkfdOracleGetLinkVelAcc.argtypes = [vp, vp, vp]
     L.rkfdOracleGetMLCP.argtypes = [vp, vp, vp, vp, C.c_int]
+    L.rkfdOracleVolumePairs.argtypes = [vp]
+    L.rkfdOracleGetVolumePair.argtypes = [vp, C.c_int, vp, C.c_int]
+    L.rkfdOracleVolumeLP.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp]
     return L
 
 
@@ -158,9 +161,33 @@ class Oracle:
         self._L.rkfdOracleGetLinkVelAcc(self._o, _p(v), _p(a))
         return v, a
 
+    def volume_pairs(self):
+        """Volume plugin: the colliding rigid pairs of the last evaluation, each a dict (pair, ntri, type, volume, center,
+        norm, wrench (world, force 3 + torque 3 about the centre), q 6x6, c 6, planes [(v, n)])"""
+        out = []
+        for k in range(self._L.rkfdOracleVolumePairs(self._o)):
+            buf = np.zeros(64 + 6 * 96)
+            n = self._L.rkfdOracleGetVolumePair(self._o, k, _p(buf), buf.size)
+            assert 0 < n <= buf.size
+            ncp = int(buf[2])
+            out.append(dict(pair=int(buf[0]), ntri=int(buf[1]), type=int(buf[3]), volume=buf[4], center=buf[5:8].copy(),
+                            norm=buf[8:11].copy(), wrench=buf[11:17].copy(), q=buf[17:53].reshape(6, 6).copy(),
+                            c=buf[53:59].copy(), planes=buf[59:59 + 6 * ncp].reshape(ncp, 6).copy()))
+        return out
+
     def mlcp(self):
         cap = 3 * max(self.ncand, 1)
         a = np.zeros(cap * cap); b = np.zeros(cap); f = np.zeros(cap)
         nc = self._L.rkfdOracleGetMLCP(self._o, _p(a), _p(b), _p(f), cap)
         n3 = 3 * nc
         return nc, a[:n3 * n3].reshape(n3, n3).copy(), b[:n3].copy(), f[:n3].copy()
+
+
+def volume_lp(A, b, c=None):
+    """the oracle's simplex LP: min c'x s.t. Ax = b, x >= 0 (c None: any feasible vertex).  Returns x or None."""
+    A = np.ascontiguousarray(A, dtype=np.float64); b = np.ascontiguousarray(b, dtype=np.float64)
+    mr, n = A.shape
+    x = np.zeros(n)
+    cc = None if c is None else np.ascontiguousarray(c, dtype=np.float64)
+    ok = lib().rkfdOracleVolumeLP(mr, n, _p(A), _p(b), _p(cc), _p(x))
+    return x if ok else None

@@ -115,6 +115,21 @@ typedef struct {
   double S3[18], U3[18], Di3[9];   /* spherical joints: motion subspace (6x3, link frame), IA S, (S'IA S)^-1 */
 } Link;
 
+/* Volume plugin (rkfd_oracle_volume.h): a colliding rigid pair with its intersection volume and contact-plane conditions */
+#define VOL_MAXPV 48      /* vertices of one clipped face polygon */
+#define VOL_MAXCP 96      /* contact-plane conditions of one pair */
+
+typedef struct { double v[3], n[3], r[2], s[2], th; } VolCP;
+struct VolPair_ {
+  int pair, ci, la, lb, sa, sb;
+  double norm[3], axis[9], center[3], volume;
+  int ntri, captri; double *tri;      /* colvol: 12 doubles per triangle (3 vertices, face normal) */
+  int ncp; VolCP cp[VOL_MAXCP];
+  double wrench[6];
+  double q[36], c[6];                 /* the pair's 6x6 objective and linear term (kept for the tests) */
+};
+typedef struct VolPair_ VolPair;
+
 struct rkfdOracle {
   const rkfdModel *m;
   int nl, n, ncand;
@@ -139,6 +154,10 @@ struct rkfdOracle {
   double *qp_q, *qp_c, *qp_nf, *qp_ans; int *qp_idx;
   /* RKG workspace */
   double *k_v[4], *k_a[4], *xd, *xv, *tv, *ta;
+  /* Volume plugin (rkfd_oracle_volume.h): face loops of the shapes, the colliding rigid pairs of this evaluation, the
+   * stick / slip type per model pair, LPs that failed twice (diagnostic) */
+  int vol_ready, *fl_off, *fl_idx, nvp, *vp_type, vol_lp_fail;
+  VolPair *vp;
 };
 
 /* ------------------------------------------------------------------------ */
@@ -210,6 +229,10 @@ void rkfdOracleDestroy(rkfdOracle *o)
   free( o->ma ); free( o->mb ); free( o->mt ); free( o->mf );
   for( k=0; k<4; k++ ){ free( o->k_v[k] ); free( o->k_a[k] ); }
   free( o->xd ); free( o->xv ); free( o->tv ); free( o->ta );
+  if( o->vol_ready ){
+    for( k=0; k<o->m->npair; k++ ) free( o->vp[k].tri );
+    free( o->vp ); free( o->vp_type ); free( o->fl_off ); free( o->fl_idx );
+  }
   free( o );
 }
 
@@ -1121,15 +1144,29 @@ static void sym_pinv_solve(int n, double *K, const double *rhs, double *x)
  * force components of its contact */
 static double qp_cond(const double *nf, int n, int P, const double *ans, int i)
 {
-  int c = i/P;
-  return v3_dot( &nf[n*i+3*c], &ans[3*c] );
+  if( P > 0 ){
+    int c = i/P;
+    return v3_dot( &nf[n*i+3*c], &ans[3*c] );
+  } else {
+    double s = 0; int j;
+    for( j=0; j<n; j++ ) s += nf[n*i+j]*ans[j];
+    return s;
+  }
 }
 
 #define QP_ASM_TOL 1.0e-8
 /* rkFDQPSolveASM (reference src/rkfd_opt_qp.c:43-181): min x'Qx/2 + c'x  s.t.  nf x >= d.
  * n unknowns, mc constraints; idx = active-set flags (output as well: used for the stick / slip
  * decision).  Returns the number of KKT solves. */
+static int qp_asm_ex(int n, int mc, int P, const double *q, const double *c, const double *nf, const double *d, const double *init, double *ans, int *idx);
 static int qp_asm(int n, int mc, int P, const double *q, const double *c, const double *nf, const double *d, double *ans, int *idx)
+{
+  return qp_asm_ex( n, mc, P, q, c, nf, d, NULL, ans, idx );
+}
+/* P > 0: the Vert plugin's condition function (a row touches the three unknowns of contact i / P) and start point;
+ * P == 0: the solver's defaults for the condition (_rkFDQPSolveASMConditionDefault, :22-25: the whole row) with the
+ * caller's start point init (the Volume plugin, reference src/rkfd_volume.c:530-546) */
+static int qp_asm_ex(int n, int mc, int P, const double *q, const double *c, const double *nf, const double *d, const double *init, double *ans, int *idx)
 {
   int nmax = n + mc, m = 0, nm, i, j, k, iter = 0, nhist = 0, caphist = 16;
   double *qa = (double *)malloc( sizeof(double)*nmax*nmax ), *xy = (double *)malloc( sizeof(double)*nmax );
@@ -1139,7 +1176,8 @@ static int qp_asm(int n, int mc, int P, const double *q, const double *c, const 
 
   /* _rkFDSolverQPASMInit (reference src/rkfd_vert.c:235-244): unit normal forces */
   for( i=0; i<n; i++ ) ans[i] = 0.0;
-  for( i=0; i<n/3; i++ ) ans[3*i] = 1.0;
+  if( init ) for( i=0; i<n; i++ ) ans[i] = init[i];
+  else for( i=0; i<n/3; i++ ) ans[3*i] = 1.0;
   /* _rkFDQPSolveASMInitIndex (:29-42) */
   for( i=0; i<mc; i++ ){
     idx[i] = fabs( qp_cond( nf, n, P, ans, i ) - d[i] ) < TOL ? 1 : 0;
@@ -1319,6 +1357,8 @@ static int vert_rigid(rkfdOracle *o, int doUpRef)
   return 0;
 }
 
+#include "rkfd_oracle_volume.h"
+
 /* ------------------------------------------------------------------------ */
 /* _rkFDUpdate / _rkFDUpdateRef (reference src/rkfd_sim.c:533-549) */
 static int evaluate(rkfdOracle *o, const double *dis, const double *vel, double *acc, int doUpRef)
@@ -1338,10 +1378,15 @@ static int evaluate(rkfdOracle *o, const double *dis, const double *vel, double 
   joint_friction( o, doUpRef );
   aba_prepare( o );
   if( o->nel != 0 ) penalty( o, doUpRef );
-  if( o->nrg != 0 ){
+  if( m->solver == RKFD_SOLVER_VOLUME ){
+    /* rkFDSolverColChk_Volume / rkFDSolverUpdate_Volume (reference src/rkfd_volume.c:1003-1019): the rigid pairs go by
+     * their intersection volumes, not by contact vertices */
+    vol_collision( o );
+    if( o->nvp != 0 ){ if( volume_rigid( o, doUpRef ) < 0 ) return -1; cached = 1; }
+  } else if( o->nrg != 0 ){
     if( m->solver == RKFD_SOLVER_MLCP ){ if( mlcp( o, doUpRef ) < 0 ) return -1; }
     else if( m->solver == RKFD_SOLVER_VERT ){ if( vert_rigid( o, doUpRef ) < 0 ) return -1; }
-    else return -1;                                 /* Volume plugin: not restated */
+    else return -1;
     cached = 1;
   }
   /* _rkFDUpdateAcc (reference src/rkfd_sim.c:502-523) */
@@ -1476,6 +1521,27 @@ int rkfdOracleUpdateN(rkfdOracle *o, int nsteps)
 
 /* number of KKT solves of the last Vert QP (diagnostic) */
 int rkfdOracleLastQPIter(const rkfdOracle *o){ return o->last_qp_iter; }
+/* Volume plugin, pair k of the last evaluation -> out[0..]: model pair, number of triangles, number of contact-plane
+ * conditions, type; volume; center 3; norm 3; wrench 6; q 36; c 6; then (v 3, n 3) per condition, up to cap doubles */
+int rkfdOracleGetVolumePair(const rkfdOracle *o, int k, double *out, int cap)
+{
+  const VolPair *vp;
+  int i, n = 0;
+  if( !o->vol_ready || k < 0 || k >= o->nvp ) return o->vol_ready ? -o->nvp - 1 : -1;
+  vp = &o->vp[k];
+#define PUT(x) do{ if( n < cap ) out[n] = (x); n++; }while(0)
+  PUT( vp->pair ); PUT( vp->ntri ); PUT( vp->ncp ); PUT( o->vp_type[vp->pair] ); PUT( vp->volume );
+  for( i=0; i<3; i++ ) PUT( vp->center[i] );
+  for( i=0; i<3; i++ ) PUT( vp->norm[i] );
+  for( i=0; i<6; i++ ) PUT( vp->wrench[i] );
+  for( i=0; i<36; i++ ) PUT( vp->q[i] );
+  for( i=0; i<6; i++ ) PUT( vp->c[i] );
+  for( k=0; k<vp->ncp; k++ ){ for( i=0; i<3; i++ ) PUT( vp->cp[k].v[i] ); for( i=0; i<3; i++ ) PUT( vp->cp[k].n[i] ); }
+#undef PUT
+  return n;
+}
+int rkfdOracleVolumePairs(const rkfdOracle *o){ return o->vol_ready ? o->nvp : 0; }
+int rkfdOracleVolumeLP(int mr, int n, const double *A, const double *b, const double *c, double *x){ return vol_lp( mr, n, A, b, c, x ); }
 int rkfdOracleQPCycleStops(const rkfdOracle *o){ return o->qp_cycle_stops; }
 
 /* test access to the two numerical building blocks of the Vert rigid branch */

@@ -55,6 +55,11 @@ int  rkfdOracleLastQPIter(const rkfdOracle *o);
 void rkfdOracleGetLastQP(const rkfdOracle *o, int *n, int *mc, double *q, double *c, double *nf, double *ans, int *idx);
 /* how many Vert QPs so far were ended by the circulation check instead of at the optimum (diagnostic) */
 int  rkfdOracleQPCycleStops(const rkfdOracle *o);
+/* Volume plugin: number of colliding rigid pairs of the last evaluation; the data of one of them (see the .c); the
+ * simplex LP min c'x s.t. Ax = b, x >= 0 (c NULL: feasibility only) */
+int  rkfdOracleVolumePairs(const rkfdOracle *o);
+int  rkfdOracleGetVolumePair(const rkfdOracle *o, int k, double *out, int cap);
+int  rkfdOracleVolumeLP(int mr, int n, const double *A, const double *b, const double *c, double *x);
 /* nsteps x rkFDUpdate */
 int  rkfdOracleUpdateN(rkfdOracle *o, int nsteps);
 /* one dynamics evaluation at the current state: _rkFDUpdate / _rkFDUpdateRef
