@@ -331,9 +331,16 @@ typedef struct {
   unsigned short *CFO;            /* [NC] first plane of the candidate's partner shape    */
   unsigned short *CHP;            /* [NL] children lists (CSR values; offsets in the schedule): child | ( its pool slot + 1 ) << 8 */
   unsigned char *PL;              /* [NL*nlevel] ancestor at depth d (MLCP only), one byte each */
+  /* Volume plugin (kernel variant sv == 2 only; rkfd_dev_volume.h): per colliding pair VD [np*48] and its contact-plane
+   * conditions VPL [np*ncp*8]; face polygons VPOLY [nf*pv*3] and reduction scratch VRED [16*nf+16] of the collision phase, sharing
+   * their storage with the solve's:
+   * QP: VQL [n(n+1)/2] Q / its factor, VQW [n*mc], VS, VEV [mc*mc], VQV [5n + mc + 64]; simplex workspace VLP; VI [np*2]
+   * conditions of a pair, its model pair.  n = 6 np, mc = np ( 1 + ncp ). */
+  double *VD, *VPL, *VPOLY, *VRED, *VQL, *VQW, *VS, *VEV, *VQV, *VLP;
+  int *VI;
 } rkfdLds;
-
-RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int M, int nlevel, int npool, int nfloat, int maxact, int nside, int pu_alias, int npurow, int vert_rigid, int has_slide, int ma_size)
+RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int M, int nlevel, int npool, int nfloat, int maxact, int nside, int pu_alias, int npurow, int vert_rigid, int has_slide, int ma_size,
+                             int vol_np, int vol_ncp, int vol_pv, int vol_nf, int pyramid)
 /* must match the byte count computed in rkfd_devmodel.cpp */
 {
   double *d = (double *)base;
@@ -365,14 +372,26 @@ RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int
   L->CF = d; d += maxact*3;
   L->SV = d; L->SD = d; if( has_slide ){ L->SV = d; d += maxact*3; L->SD = d; d += maxact*3; }
   /* PGS: a lane reads its three entries of b before it writes its three forces, so they share storage */
-  L->MB = d; d += M; L->MF = L->MB; if( vert_rigid ){ L->MF = d; d += M; }
+  L->MB = d; d += M; L->MF = L->MB; if( vert_rigid || vol_np ){ L->MF = d; d += M; }
   /* probe scratch: lives while the contact problem is set up and solved, when C and PA are dead */
   if( pu_alias ) L->PU = L->C; else { L->PU = d; d += nside*npurow*M; }
   L->QL = d; L->QW = d; L->QV = d; L->CR = d;
   if( vert_rigid ){ L->QL = d; d += M*( M+1 )/2; L->QW = d; d += M*M; L->QV = d; d += 5*M + ( vert_rigid == 2 ? 0 : RKFD_WAVE ); L->CR = d; d += 3*M; }
+  L->VD = d; L->VPL = d; L->VPOLY = d; L->VRED = d; L->VQL = d; L->VQW = d; L->VS = d; L->VEV = d; L->VQV = d; L->VLP = d;
+  if( vol_np ){
+    const int n = 6*vol_np, mc = vol_np*( 1+vol_ncp );
+    L->VD = d; d += vol_np*48; L->VPL = d; d += vol_np*vol_ncp*8;
+    /* the scratch of the collision phase and that of the solve share their storage */
+    L->VPOLY = d; L->VRED = d + vol_nf*vol_pv*3;
+    double *e = d;
+    L->VQL = e; e += n*( n+1 )/2; L->VQW = e; e += n*mc; L->VS = e; e += mc*mc; L->VEV = e; e += mc*mc;
+    L->VQV = e; e += 5*n + mc + 64; L->VLP = e; e += 15*pyramid*vol_ncp + 61;
+    d += RKFD_VOL_LDS_COL( vol_nf, vol_pv ) > RKFD_VOL_LDS_SOL( vol_np, vol_ncp, pyramid ) ? RKFD_VOL_LDS_COL( vol_nf, vol_pv ) : RKFD_VOL_LDS_SOL( vol_np, vol_ncp, pyramid );
+  }
   int *ip = (int *)d;
   L->CIp = ip; ip += NC;
-  L->tgt = ip; ip += nside*maxact; L->cnt = ip; ip += NC > 0 ? 8 : 4;
+  L->tgt = ip; ip += nside*maxact; L->cnt = ip; ip += vol_np ? 12 : ( NC > 0 ? 8 : 4 );
+  L->VI = ip; if( vol_np ) ip += 2*vol_np;
   L->LI = ip; ip += NL;
   unsigned short *sp = (unsigned short *)ip;
   L->CHP = sp; sp += NL; L->CFO = sp; sp += NC;
@@ -416,5 +435,6 @@ typedef struct { double min, pivp; int pivt; } rkfdLaneLink;
 #define CNT_SRG 5       /* running sums over the committing evaluations of this launch's steps: rigid contacts, */
 #define CNT_SEL 6       /* elastic contacts, */
 #define CNT_SN  7       /* steps (rkfdBatchContactStats) */
+#define CNT_NVP 8       /* Volume plugin: rigid pairs in collision in this evaluation (twelve counters in that kernel variant) */
 
 #endif /* RKFD_DEV_BASE_H */

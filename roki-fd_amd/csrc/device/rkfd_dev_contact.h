@@ -70,6 +70,8 @@ RKFD_DEV void rkfd_phase_collision(const rkfdDevModel &m, const rkfdLds &L)
         if( sd > smax ){ smax = sd; fbest = f; }
       }
       is_act = fbest >= 0 && smax < RKFD_DEV_TOL;
+      /* under the Volume plugin a rigid pair goes by its intersection volume (rkfd_dev_volume.h), not by contact vertices */
+      if( m.vol_np > 0 && m.ci_type[RKFD_CI_CI( cinf )] == RKFD_CONTACT_RIGID ) is_act = 0;
     }
     /* anchors of the contacts that persist, read at their OLD slots before anything is rewritten */
     double oref[3] = {0,0,0};

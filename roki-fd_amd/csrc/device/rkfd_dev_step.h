@@ -8,7 +8,8 @@
 /* one dynamics evaluation: _rkFDUpdate / _rkFDUpdateRef (reference src/rkfd_sim.c:533-549).
  * Input L.q, L.qd; output L.acc (and contact / pivot state).  Returns nonzero when the model
  * needs a rigid solver that is not available on the device (wave-uniform). */
-template<bool prof, bool vqp, bool pk> RKFD_DEV int rkfd_evaluate(const rkfdDevModel &m, const rkfdLds &L, rkfdLaneLink &ll, bool doUpRef, unsigned long long *pc)
+/* vqp: 0 = PGS only, 1 = also the Vert plugin's QP, 2 = the Volume plugin (kernel variants) */
+template<bool prof, int vqp, bool pk> RKFD_DEV int rkfd_evaluate(const rkfdDevModel &m, const rkfdLds &L, rkfdLaneLink &ll, bool doUpRef, unsigned long long *pc)
 {
   const int lane = LANE();
   int err = 0;
@@ -34,6 +35,11 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV int rkfd_evaluate(const rkfdDevM
     L.cnt[CNT_NRG] = 0; L.cnt[CNT_NEL] = 0;
   }
   SYNC();
+  if( vqp == 2 ){
+    if( m.vol_np > 0 ) rkfd_phase_volcol( m, L );
+    else if( lane == 0 ) L.cnt[CNT_NVP] = 0;
+    SYNC();
+  }
   double bv[6];
   rkfd_phase_bvel( m, L, bv );
   STAMP(1);
@@ -42,13 +48,25 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV int rkfd_evaluate(const rkfdDevM
   STAMP(2);
   rkfd_phase_sweep3<false>( m, L );
   STAMP(3);
-  if( L.cnt[CNT_NRG] > 0 ){
-    if( m.solver == RKFD_SOLVER_MLCP || ( vqp && m.solver == RKFD_SOLVER_VERT && m.vert_rigid ) ){
+  if( vqp == 2 ){
+    if( L.cnt[CNT_NVP] > 0 ){
+      SYNC();
+      const double afree = lane < m.ndof ? L.acc[lane] : 0.0;
+      rkfd_phase_volume( m, L, doUpRef );
+      STAMP(4);
+      rkfd_phase_sweep3<true>( m, L );
+      SYNC();
+      if( lane < m.ndof ) L.acc[lane] += afree;
+      SYNC();
+      STAMP(3);
+    }
+  } else if( L.cnt[CNT_NRG] > 0 ){
+    if( m.solver == RKFD_SOLVER_MLCP || ( vqp == 1 && m.solver == RKFD_SOLVER_VERT && m.vert_rigid ) ){
       /* L.acc shares its LDS with the contact matrix: the free accelerations wait in a register (lane = dof) */
       SYNC();
       const double afree = lane < m.ndof ? L.acc[lane] : 0.0;
       /* contact forces, then their effect on the accelerations (rkChainUpdateCachedABI in the reference) */
-      rkfd_phase_mlcp<prof, vqp, pk>( m, L, bv, doUpRef, pc );
+      rkfd_phase_mlcp<prof, vqp == 1, pk>( m, L, bv, doUpRef, pc );
       STAMP(4);
       rkfd_phase_sweep3<true>( m, L );
       SYNC();
@@ -100,7 +118,7 @@ RKFD_DEV void rkfd_cat_dis(const rkfdDevModel &m, const rkfdLds &L, int dofkind,
 /* the whole step for one instance: load state, nsteps x rkFDUpdate (or a single evaluation),
  * store state.  mode 0: rkFDUpdate x nsteps; mode 1: rkFDUpdateInit (committing evaluation);
  * mode 2: evaluation without commit. */
-template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDevModel &m_, const rkfdDevState &st, int b, void *ldsbase,
+template<bool prof, int vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDevModel &m_, const rkfdDevState &st, int b, void *ldsbase,
                             int mode, int nsteps, int *errflag)
 {
 #ifdef RKFD_SPEC
@@ -122,7 +140,8 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDev
   const int lane = LANE();
   const int ND = m.ndof, NL = m.nlink, NC = m.ncand;
   rkfdLds L;
-  rkfd_lds_carve( &L, ldsbase, NL, ND, NC, 3*m.maxrg, m.nlevel, m.npool, m.nfloat, m.maxact, m.nside, m.pu_alias, m.npurow, m.vert_rigid, m.has_slide, m.ma_size );
+  rkfd_lds_carve( &L, ldsbase, NL, ND, NC, 3*m.maxrg, m.nlevel, m.npool, m.nfloat, m.maxact, m.nside, m.pu_alias, m.npurow, m.vert_rigid, m.has_slide, m.ma_size,
+                  vqp == 2 ? m.vol_np : 0, m.vol_ncp, m.vol_pv, m.vol_nf, m.pyramid );
   if( lane == 0 ){
     L.cnt[CNT_OVF] = 0; L.cnt[CNT_QPF] = 0;
     if( NC > 0 ){ L.cnt[CNT_SRG] = 0; L.cnt[CNT_SEL] = 0; L.cnt[CNT_SN] = 0; }

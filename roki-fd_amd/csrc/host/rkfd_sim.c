@@ -168,11 +168,12 @@ static rkFDSolver *solver_create(rkFDSolver *s, int kind, rkFDSolverCom *com)
 }
 rkFDSolver *rkFDSolverCreate_Vert(rkFDSolver *s){ return solver_create( s, RKFD_SOLVER_VERT, &rkfd_solver_Vert ); }
 rkFDSolver *rkFDSolverCreate_MLCP(rkFDSolver *s){ return solver_create( s, RKFD_SOLVER_MLCP, &rkfd_solver_MLCP ); }
-/* Volume: elastic pairs only on the device (penalty); a rigid pair is reported by the device step (status 1) */
+/* Volume (reference src/rkfd_volume.c): rigid pairs of convex shapes go by their intersection volumes on the device
+ * (csrc/device/rkfd_dev_volume.h); max_rigid counts PAIRS in collision at once here (at most 10) */
 rkFDSolver *rkFDSolverCreate_Volume(rkFDSolver *s)
 {
   rkFDSolver *r = solver_create( s, RKFD_SOLVER_VOLUME, &rkfd_solver_Volume );
-  if( r ) ( (rkFDSolverPrpAMD *)r->prp )->max_rigid = 0;
+  if( r ) ( (rkFDSolverPrpAMD *)r->prp )->max_rigid = 10;
   return r;
 }
 

@@ -37,16 +37,26 @@ name(rkfdDevModel m, rkfdDevState st, int first, int mode, int nsteps, int *errf
   if( b >= st.batch ) return; \
   rkfd_instance<prof, vqp, pk>( m, st, b, lds, mode, nsteps, errflag ); \
 }
-RKFD_KERNEL( rkfd_step_kernel, false, false, false )
+RKFD_KERNEL( rkfd_step_kernel, false, 0, false )
 /* the contact matrix as a packed lower triangle (worlds where that lets one more instance share a CU) */
-RKFD_KERNEL( rkfd_step_kernel_pk, false, false, true )
+RKFD_KERNEL( rkfd_step_kernel_pk, false, 0, true )
 /* the variant that also carries the Vert plugin's QP (worlds with rigid pairs under the Vert plugin);
  * kept apart so that its code and registers do not weigh on the MLCP / penalty kernel */
-RKFD_KERNEL( rkfd_step_kernel_vqp, false, true, false )
+RKFD_KERNEL( rkfd_step_kernel_vqp, false, 1, false )
 /* diagnostic instantiations with in-kernel phase stamps (rkfdBatchProfile) */
-RKFD_KERNEL( rkfd_step_kernel_prof, true, false, false )
-RKFD_KERNEL( rkfd_step_kernel_prof_pk, true, false, true )
-RKFD_KERNEL( rkfd_step_kernel_prof_vqp, true, true, false )
+RKFD_KERNEL( rkfd_step_kernel_prof, true, 0, false )
+RKFD_KERNEL( rkfd_step_kernel_prof_pk, true, 0, true )
+RKFD_KERNEL( rkfd_step_kernel_prof_vqp, true, 1, false )
+/* the variant that carries the Volume plugin (worlds with rigid pairs under it): its geometry and simplex code want more
+ * registers than three waves per SIMD leave, and its LDS block allows few instances per CU anyway */
+extern "C" __global__ void __launch_bounds__(RKFD_WAVE, 1)
+rkfd_step_kernel_vol(rkfdDevModel m, rkfdDevState st, int first, int mode, int nsteps, int *errflag)
+{
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int b = first + (int)blockIdx.x;
+  if( b >= st.batch ) return;
+  rkfd_instance<false, 2, false>( m, st, b, lds, mode, nsteps, errflag );
+}
 
 /* rkfdBatchRestore: one workgroup copies one instance's state rows back from the snapshot */
 extern "C" __global__ void __launch_bounds__(RKFD_WAVE)
@@ -165,6 +175,7 @@ extern "C" rkfdBatch *rkfdBatchCreate(const rkfdModel *m, int batch, int device,
   if( bad ){ rkfdBatchDestroy( b ); return NULL; }
   b->kern = b->dm.vert_rigid ? rkfd_step_kernel_vqp : ( b->dm.ma_packed ? rkfd_step_kernel_pk : rkfd_step_kernel );
   b->kern_prof = b->dm.vert_rigid ? rkfd_step_kernel_prof_vqp : ( b->dm.ma_packed ? rkfd_step_kernel_prof_pk : rkfd_step_kernel_prof );
+  if( b->dm.vol_np > 0 ){ b->kern = rkfd_step_kernel_vol; b->kern_prof = rkfd_step_kernel_vol; }      /* (no phase stamps in this variant) */
   if( b->lds_bytes > 64*1024 ){
     hipError_t e = hipFuncSetAttribute( (const void *)b->kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes );
     if( e == hipSuccess ) e = hipFuncSetAttribute( (const void *)b->kern_prof, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes );
@@ -406,7 +417,7 @@ static std::string spec_source(const rkfdDevModel &d)
     "#define RKFD_SPEC_HAS_SLIDE %d\n#define RKFD_SPEC_MA_SIZE %d\n#define RKFD_SPEC_MA_PACKED %d\n"
     "#define RKFD_SPEC_MAX_ITER %d\n#define RKFD_SPEC_SOLVER %d\n#define RKFD_SPEC_PYRAMID %d\n#define RKFD_SPEC_ANCHOR %d\n#define RKFD_SPEC_MLCP_MFMA %d\n"
     "#include \"rkfd_device.h\"\n"
-    "extern \"C\" __global__ void __launch_bounds__(64, 3)\n"
+    "extern \"C\" __global__ void __launch_bounds__(64, %d)\n"
     "rkfd_step_kernel_spec(rkfdDevModel m, rkfdDevState st, int first, int mode, int nsteps, int *errflag)\n"
     "{\n"
     "  extern __shared__ __attribute__((aligned(16))) char lds[];\n"
@@ -416,7 +427,7 @@ static std::string spec_source(const rkfdDevModel &d)
     "}\n",
     d.nlink, d.ndof, d.ncand, d.nlink_model, d.nlevel, d.nround, d.nsched, d.maxrg, d.npool, d.nfloat, d.maxact, d.nside,
     d.npurow, d.pu_alias, d.vert_rigid, d.qscr_alias, d.has_slide, d.ma_size, d.ma_packed, d.max_iter, d.solver, d.pyramid, d.anchor, d.mlcp_mfma,
-    d.vert_rigid ? "true" : "false", d.ma_packed ? "true" : "false" );
+    d.vol_np > 0 ? 1 : 3, d.vol_np > 0 ? "2" : ( d.vert_rigid ? "1" : "0" ), d.ma_packed ? "true" : "false" );
   return std::string( buf );
 }
 /* hipRTC, bound at run time in a PRIVATE link namespace.  hipRTC finds its compiler (libamd_comgr) by soname, and

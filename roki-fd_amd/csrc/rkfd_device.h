@@ -37,6 +37,7 @@
 #include "device/rkfd_dev_contact.h"
 #include "device/rkfd_dev_vertqp.h"
 #include "device/rkfd_dev_mlcp.h"
+#include "device/rkfd_dev_volume.h"
 #include "device/rkfd_dev_step.h"
 
 #endif /* RKFD_DEVICE_H */

@@ -7,6 +7,8 @@
 #include <string.h>
 #include <stdio.h>
 #include <vector>
+#include <algorithm>
+#include <utility>
 #include "rkfd_model.h"
 #include "rkfd_devmodel.h"
 #include "rkfd_devmodel_host.h"
@@ -296,6 +298,98 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
     if( cci[j] > 63 ) FAIL( "more than 63 contact-info entries" );
     cinfo[j] = RKFD_CI_PACK( cA[j], cB[j], cci[j], cnf[j] );
   }
+  /* Volume plugin: the rigid pairs with the face loops of their (convex) shapes - for every plane of a shape the
+   * vertices lying on it, counter-clockwise seen from outside, in the device link's frame (the oracle builds the same
+   * loops: oracle/rkfd_oracle_volume.h vol_prepare).  A coplanar duplicate of an earlier plane gets no loop. */
+  std::vector<int> vol_pair, vol_loop;
+  std::vector<double> vol_lplane, vol_lvert;
+  int vol_npair = 0, vol_np = 0, vol_ncp = 0, vol_pv = 0, vol_nf = 0;
+  if( m->solver == RKFD_SOLVER_VOLUME ){
+    std::vector<int> sh_l0( m->nshape, -1 ), sh_nl( m->nshape, 0 );
+    int maxloop = 0, maxfaces = 0;
+    for( int pr=0; pr<m->npair; pr++ ){
+      if( m->ci_type[m->pair_ci[pr]] != RKFD_CONTACT_RIGID ) continue;
+      for( int sd=0; sd<2; sd++ ){
+        const int sh = m->pair_shape[2*pr+sd];
+        if( sh_l0[sh] >= 0 ) continue;
+        const double *T = &Trep[12*m->shape_link[sh]];
+        sh_l0[sh] = (int)vol_loop.size()/2;
+        for( int f=m->shape_foff[sh]; f<m->shape_foff[sh+1]; f++ ){
+          const double *pl = &m->planes[4*f];
+          bool dup = false;
+          for( int f2=m->shape_foff[sh]; f2<f; f2++ ){
+            const double *p2 = &m->planes[4*f2];
+            if( fabs( pl[0]-p2[0] ) < 1e-9 && fabs( pl[1]-p2[1] ) < 1e-9 && fabs( pl[2]-p2[2] ) < 1e-9 && fabs( pl[3]-p2[3] ) < 1e-9 ) dup = true;
+          }
+          if( dup ) continue;
+          std::vector<int> idx;
+          for( int v=m->shape_voff[sh]; v<m->shape_voff[sh+1]; v++ ){
+            const double *x = &m->verts[3*v];
+            if( !( fabs( pl[0]*x[0] + pl[1]*x[1] + pl[2]*x[2] - pl[3] ) < 1e-9 ) ) continue;
+            bool same = false;
+            for( size_t i=0; i<idx.size(); i++ ){
+              const double *a = &m->verts[3*idx[i]];
+              if( fabs( a[0]-x[0] ) < 1e-12 && fabs( a[1]-x[1] ) < 1e-12 && fabs( a[2]-x[2] ) < 1e-12 ) same = true;
+            }
+            if( !same ) idx.push_back( v );
+          }
+          if( idx.size() < 3 ) continue;
+          /* order by angle about the centroid in the plane's own basis (tangent 1 = the unit vector of the smallest |component| made
+           * orthogonal to n, tangent 2 = n x t1: the oracle's ortho_space) */
+          double c[3] = {0,0,0}, e[3] = {0,0,0}, t1[3], t2[3];
+          for( size_t i=0; i<idx.size(); i++ ) for( int a=0; a<3; a++ ) c[a] += ( 1.0/idx.size() )*m->verts[3*idx[i]+a];
+          int k = 0;
+          if( fabs( pl[1] ) < fabs( pl[k] ) ) k = 1;
+          if( fabs( pl[2] ) < fabs( pl[k] ) ) k = 2;
+          e[k] = 1.0;
+          const double dd = e[0]*pl[0] + e[1]*pl[1] + e[2]*pl[2];
+          for( int a=0; a<3; a++ ) t1[a] = e[a] - dd*pl[a];
+          const double l = sqrt( t1[0]*t1[0] + t1[1]*t1[1] + t1[2]*t1[2] );
+          for( int a=0; a<3; a++ ) t1[a] /= l;
+          t2[0] = pl[1]*t1[2]-pl[2]*t1[1]; t2[1] = pl[2]*t1[0]-pl[0]*t1[2]; t2[2] = pl[0]*t1[1]-pl[1]*t1[0];
+          std::vector<std::pair<double,int> > ang;
+          for( size_t i=0; i<idx.size(); i++ ){
+            const double *x = &m->verts[3*idx[i]];
+            const double d[3] = { x[0]-c[0], x[1]-c[1], x[2]-c[2] };
+            ang.push_back( std::make_pair( atan2( d[0]*t2[0]+d[1]*t2[1]+d[2]*t2[2], d[0]*t1[0]+d[1]*t1[1]+d[2]*t1[2] ), idx[i] ) );
+          }
+          std::stable_sort( ang.begin(), ang.end(), []( const std::pair<double,int> &a, const std::pair<double,int> &b ){ return a.first < b.first; } );
+          vol_loop.push_back( (int)vol_lvert.size()/3 ); vol_loop.push_back( (int)ang.size() );
+          for( size_t i=0; i<ang.size(); i++ ){
+            const double *x = &m->verts[3*ang[i].second];
+            for( int a=0; a<3; a++ ) vol_lvert.push_back( T[9+a] + T[3*a]*x[0] + T[3*a+1]*x[1] + T[3*a+2]*x[2] );
+          }
+          for( int a=0; a<4; a++ ) vol_lplane.push_back( planes_d[4*f+a] );
+          if( (int)ang.size() > maxloop ) maxloop = (int)ang.size();
+          sh_nl[sh]++;
+        }
+        if( sh_nl[sh] < 4 ) FAIL( "Volume plugin: shape %d of a rigid pair is not a closed convex polyhedron (%d faces found)", sh, sh_nl[sh] );
+      }
+      const int shA = m->pair_shape[2*pr], shB = m->pair_shape[2*pr+1];
+      const int rec[8] = { rep[m->shape_link[shA]], rep[m->shape_link[shB]], m->pair_ci[pr], sh_l0[shA], sh_nl[shA], sh_l0[shB], sh_nl[shB], 0 };
+      vol_pair.insert( vol_pair.end(), rec, rec+8 );
+      vol_npair++;
+      if( sh_nl[shA] + sh_nl[shB] > RKFD_WAVE ) FAIL( "Volume plugin: the two shapes of a rigid pair have %d faces together (one lane per face: at most %d)", sh_nl[shA]+sh_nl[shB], RKFD_WAVE );
+      if( sh_nl[shA] + sh_nl[shB] > maxfaces ) maxfaces = sh_nl[shA] + sh_nl[shB];
+      const int big = sh_nl[shA] > sh_nl[shB] ? sh_nl[shA] : sh_nl[shB];
+      if( maxloop + big > vol_pv ) vol_pv = maxloop + big;
+    }
+    if( vol_npair > 0 ){
+      /* capacities: pairs in collision at once (the caller's max_rigid, at most 10: six unknowns each, one per lane),
+       * contact-plane conditions per pair (every face of the two shapes can give one), constraints <= 64 */
+      vol_np = max_rigid > 0 ? ( max_rigid < vol_npair ? max_rigid : vol_npair ) : 0;
+      if( vol_np > 10 ) vol_np = 10;
+      if( vol_np > 0 ){
+        vol_ncp = maxfaces < 8 ? maxfaces : 8;      /* (the contact polygon of two boxes has at most eight edges; more is reported at run time, status 2) */
+        while( vol_ncp > 4 && vol_np*( 1+vol_ncp ) > RKFD_WAVE ) vol_ncp--;
+        if( vol_np*( 1+vol_ncp ) > RKFD_WAVE ) FAIL( "Volume plugin: %d pairs x ( 1 + %d conditions ) exceed 64 constraints", vol_np, vol_ncp );
+        if( vol_pv < 10 ) vol_pv = 10;
+        vol_nf = maxfaces;
+        if( has_slide ) FAIL( "Volume plugin: cells in slide mode are not supported on the device" );
+      }
+    }
+  }
+  if( vol_np > 0 ) max_rigid = 2*vol_np;      /* six rows per pair in the arrays the MLCP phase sizes by 3*max_rigid */
   /* sweep schedule: one iteration = up to 8 links of one level.  Lane-group slots are kept stable
    * along chains (a link takes the slot of its first child when possible) so that the sweeps can
    * hand data from one iteration to the next in registers:
@@ -408,9 +502,13 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   int maxact = has_elastic ? ( NC < 16 ? NC : 16 ) : 0;
   if( has_rigid && max_rigid > maxact ) maxact = max_rigid < NC ? max_rigid : NC;
   if( NC > 0 && maxact < 1 ) maxact = 1;
+  if( vol_np > maxact ) maxact = vol_np;      /* (the moving sides of the pairs go where those of the contact vertices go) */
   int nside = 1;
   for( int j=0; j<NC; j++ )
     if( m->ci_type[cci[j]] == RKFD_CONTACT_RIGID && !is_static[cA[j]] && !is_static[cB[j]] ) nside = 2;
+  for( int k=0; k<vol_npair; k++ ) if( !is_static[vol_pair[8*k]] && !is_static[vol_pair[8*k+1]] ) nside = 2;
+  dm.vol_npair = vol_np > 0 ? vol_npair : 0; dm.vol_np = vol_np; dm.vol_ncp = vol_ncp; dm.vol_pv = vol_pv; dm.vol_nf = vol_nf;
+  if( vol_np > 0 ){ dm.vert_rigid = 0; dm.qscr_alias = 0; dm.ma_packed = 0; dm.ma_size = 6*vol_np*( 6*vol_np+1 ); }
   dm.maxact = maxact; dm.nside = nside;
   { const char *e = getenv( "RKFD_MLCP_MFMA" ); dm.mlcp_mfma = ( e && atoi( e ) > 0 && 3*max_rigid <= 32 ) ? 1 : 0; }
   const size_t Mrows = 3*(size_t)max_rigid;
@@ -454,6 +552,12 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   dm.has_slide = has_slide;
   PUT( cs_mode, csm.data(), sizeof(int)*csm.size() ); PUT( cs_par, csp.data(), sizeof(double)*csp.size() );
   PUT( planes, planes_d.data(), sizeof(double)*4*nplane );
+  if( vol_pair.empty() ) vol_pair.assign( 8, 0 );
+  if( vol_loop.empty() ) vol_loop.assign( 2, 0 );
+  if( vol_lplane.empty() ) vol_lplane.assign( 4, 0.0 );
+  if( vol_lvert.empty() ) vol_lvert.assign( 3, 0.0 );
+  PUT( vol_pair, vol_pair.data(), sizeof(int)*vol_pair.size() ); PUT( vol_loop, vol_loop.data(), sizeof(int)*vol_loop.size() );
+  PUT( vol_lplane, vol_lplane.data(), sizeof(double)*vol_lplane.size() ); PUT( vol_lvert, vol_lvert.data(), sizeof(double)*vol_lvert.size() );
   PUT( ci_type, m->ci_type, sizeof(int)*m->nci );
   PUT( ci_sf, m->ci_sf, sizeof(double)*m->nci ); PUT( ci_kf, m->ci_kf, sizeof(double)*m->nci );
   PUT( ci_k, m->ci_k, sizeof(double)*m->nci ); PUT( ci_l, m->ci_l, sizeof(double)*m->nci );
@@ -479,7 +583,7 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   for( int pass=0; pass<2; pass++ ){
     if( pass == 1 ){
       const size_t Mr = 3*(size_t)max_rigid;
-      if( dm.vert_rigid || max_rigid <= 0 ) break;
+      if( dm.vert_rigid || max_rigid <= 0 || vol_np > 0 ) break;
       dm.ma_packed = 1; dm.ma_size = (int)( Mr*( Mr+1 )/2 );
     }
     const size_t M = 3*(size_t)max_rigid;
@@ -487,9 +591,10 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
     size_t stage = (size_t)14*NL + pool;                         /* inertia staging + Ia pool ...   */
     if( (size_t)dm.ma_size > stage ) stage = (size_t)dm.ma_size;   /* ... shared with the contact matrix */
     const size_t dbl = (size_t)NL*( 5*6 + 3 ) + stage + (size_t)33*nfloat
-                     + (size_t)maxact*( 21 + ( NC > RKFD_WAVE ? 3 : 0 ) + ( dm.has_slide ? 6 : 0 ) ) + ( dm.vert_rigid ? 2 : 1 )*M + ( dm.pu_alias ? 0 : (size_t)nside*npurow*M )
-                     + ( dm.vert_rigid ? M*M + M*( M+1 )/2 + 5*M + ( dm.qscr_alias ? 0 : RKFD_WAVE ) + 3*M : 0 );   /* Vert QP: QL, QW, QV, CR */
-    const size_t ints = (size_t)NC + (size_t)nside*maxact + ( NC > 0 ? 8 : 4 ) + (size_t)NL;     /* CIp, tgt, cnt, LI */
+                     + (size_t)maxact*( 21 + ( NC > RKFD_WAVE ? 3 : 0 ) + ( dm.has_slide ? 6 : 0 ) ) + ( ( dm.vert_rigid || vol_np > 0 ) ? 2 : 1 )*M + ( dm.pu_alias ? 0 : (size_t)nside*npurow*M )
+                     + ( dm.vert_rigid ? M*M + M*( M+1 )/2 + 5*M + ( dm.qscr_alias ? 0 : RKFD_WAVE ) + 3*M : 0 )   /* Vert QP: QL, QW, QV, CR */
+                     + ( vol_np > 0 ? (size_t)RKFD_VOL_LDS_DOUBLES( vol_np, vol_ncp, vol_pv, vol_nf, dm.pyramid ) : 0 );
+    const size_t ints = (size_t)NC + (size_t)nside*maxact + ( vol_np > 0 ? 12 + 2*vol_np : ( NC > 0 ? 8 : 4 ) ) + (size_t)NL;     /* CIp, tgt, cnt (VI), LI */
     const size_t bytes = (size_t)2*NL + (size_t)5*NC + (size_t)4*maxact + ( dm.vert_rigid ? M : 0 )                                     /* CHP (16 bit), act typ asl (bytes) */
                        + ( max_rigid > 0 ? (size_t)NL*( nlevel+3 ) : 0 );                /* PL */
     out->lds_bytes = dbl*sizeof(double) + ints*sizeof(int) + bytes;
@@ -522,6 +627,7 @@ extern "C" void rkfd_devmodel_rebase(rkfdDevModel *dm, const void *from, const v
   RB(mot_k); RB(mot_admit); RB(mot_vmax); RB(mot_vmin); RB(mot_gear); RB(mot_inertia);
   RB(anc); RB(level_off); RB(level_link); RB(child_off); RB(child_idx); RB(pathlink); RB(linfo); RB(sched); RB(cinfo); RB(pslot); RB(orig); RB(dofkind);
   RB(cand_linkA); RB(cand_linkB); RB(cand_foff); RB(cand_nf); RB(cand_ci); RB(cand_vert); RB(cand_bs); RB(cs_mode); RB(cs_par); RB(planes);
+  RB(vol_pair); RB(vol_loop); RB(vol_lplane); RB(vol_lvert);
   RB(ci_type); RB(ci_sf); RB(ci_kf); RB(ci_k); RB(ci_l); RB(ci_e); RB(ci_v);
 #undef RB
 }

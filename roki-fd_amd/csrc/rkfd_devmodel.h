@@ -35,6 +35,16 @@ typedef struct {
   int maxrg;             /* capacity: rigid contact vertices solved per instance (3*maxrg <= 128) */
   int mlcp_mfma;         /* 1: the contact matrix A = N'N is formed with v_mfma_f64_16x16x4_f64 (worlds with at most 32 rows;
                             measurement switch RKFD_MLCP_MFMA, see DESIGN.md "MFMA") */
+  /* Volume plugin (solver == RKFD_SOLVER_VOLUME and rigid pairs exist; device/rkfd_dev_volume.h) */
+  int vol_npair;         /* rigid pairs of the model */
+  int vol_np;            /* capacity: pairs in collision at once (6 vol_np <= 64 unknowns)                     */
+  int vol_ncp;           /* capacity: contact-plane conditions per pair (vol_np ( 1 + vol_ncp ) <= 64 constraints) */
+  int vol_pv;            /* capacity: vertices of a clipped face polygon                                        */
+  int vol_nf;            /* most faces the two shapes of a rigid pair have together (one lane each, <= 64)      */
+  const int *vol_pair;   /* [vol_npair*8] device link A, B, contact info, first face loop of A, loops of A, first of B, loops of B, 0 */
+  const int *vol_loop;   /* [nloop*2] first vertex, vertices of a face loop (counter-clockwise seen from outside) */
+  const double *vol_lplane; /* [nloop*4] the loop's plane, device link frame                                    */
+  const double *vol_lvert;  /* [nlv*3] loop vertices, device link frame; the loops of one shape are contiguous  */
   double dt, fric_w;
   /* per link */
   const int *parent, *jtype, *dofoff, *mtype, *depth, *is_static;
@@ -100,6 +110,17 @@ typedef struct {
 #define RKFD_CI_CI(x)     ( ( (x) >> 14 ) & 0x3F )
 #define RKFD_CI_NF(x)     ( (int)( (unsigned)(x) >> 20 ) )
 #define RKFD_MAX_ROUND 6
+
+/* doubles of the Volume plugin's LDS block (rkfd_lds_carve and rkfd_devmodel.cpp) */
+/* kept from the collision phase to the solve: per pair 48, per condition 8; then the larger of the collision phase's scratch
+ * (face polygons nf x pv x 3, reduction 16 nf + 16) and the solve's (Q n(n+1)/2, W n mc, S and EV mc^2 each, vectors 5n + mc + 64,
+ * simplex 15 pyr ncp + 61), n = 6 np, mc = np ( 1 + ncp ) */
+#define RKFD_VOL_LDS_COL(nf, pv) ( (nf)*(pv)*3 + 16*(nf) + 16 )
+#define RKFD_VOL_LDS_SOL(np, ncp, pyr) \
+  ( ( 6*(np) )*( 6*(np)+1 )/2 + 6*(np)*(np)*( 1+(ncp) ) + 2*(np)*( 1+(ncp) )*(np)*( 1+(ncp) ) + ( 30*(np) + (np)*( 1+(ncp) ) + 64 ) + ( 15*(pyr)*(ncp) + 61 ) )
+#define RKFD_VOL_LDS_DOUBLES(np, ncp, pv, nf, pyr) \
+  ( (np)*48 + (np)*(ncp)*8 + ( RKFD_VOL_LDS_COL( nf, pv ) > RKFD_VOL_LDS_SOL( np, ncp, pyr ) ? RKFD_VOL_LDS_COL( nf, pv ) : RKFD_VOL_LDS_SOL( np, ncp, pyr ) ) )
+
 
 /* per-batch state arrays, instance-major: x[b*stride + j] */
 typedef struct {

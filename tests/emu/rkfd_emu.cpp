@@ -77,9 +77,10 @@ extern "C" int rkfd_emu_run(const rkfdModel *m, int max_rigid, rkfdDevState *st,
     for( int l=0; l<64; l++ )
       th.emplace_back( [&, l](){ t_lane = l;
         /* the variant the C-ABI would launch: the one carrying the Vert QP only for worlds that need it */
-        if( h.dm.vert_rigid ) rkfd_instance<false, true, false>( h.dm, *st, b, lds.data(), mode, nsteps, &errflag );
-        else if( h.dm.ma_packed ) rkfd_instance<false, false, true>( h.dm, *st, b, lds.data(), mode, nsteps, &errflag );
-        else rkfd_instance<false, false, false>( h.dm, *st, b, lds.data(), mode, nsteps, &errflag ); } );
+        if( h.dm.vol_np > 0 ) rkfd_instance<false, 2, false>( h.dm, *st, b, lds.data(), mode, nsteps, &errflag );
+        else if( h.dm.vert_rigid ) rkfd_instance<false, 1, false>( h.dm, *st, b, lds.data(), mode, nsteps, &errflag );
+        else if( h.dm.ma_packed ) rkfd_instance<false, 0, true>( h.dm, *st, b, lds.data(), mode, nsteps, &errflag );
+        else rkfd_instance<false, 0, false>( h.dm, *st, b, lds.data(), mode, nsteps, &errflag ); } );
     for( auto &t : th ) t.join();
   }
   if( h.ncand > 0 ) rkfd_ref_to_model( &h, st->cv_ref, (size_t)st->batch*h.ncand );

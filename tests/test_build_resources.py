@@ -32,7 +32,7 @@ def _kernels():
 def test_every_kernel_variant_is_reported():
     k = _kernels()
     assert set(k) == {"rkfd_step_kernel", "rkfd_step_kernel_pk", "rkfd_step_kernel_vqp", "rkfd_step_kernel_prof", "rkfd_step_kernel_prof_pk", "rkfd_step_kernel_prof_vqp",
-                      "rkfd_restore_kernel"}
+                      "rkfd_step_kernel_vol", "rkfd_restore_kernel"}
 
 
 @pytest.mark.parametrize("name", ["rkfd_step_kernel", "rkfd_step_kernel_pk", "rkfd_step_kernel_vqp", "rkfd_step_kernel_prof", "rkfd_step_kernel_prof_pk", "rkfd_step_kernel_prof_vqp"])
@@ -44,3 +44,11 @@ def test_kernel_fits_three_waves_per_simd_without_scratch(name):
     assert k["ScratchSize"] <= 32, k
     assert k["VGPRs"] <= 168, k
     assert k["Occupancy"] >= 3, k
+
+
+def test_volume_kernel_does_not_spill_vector_registers():
+    """the Volume plugin's variant is built for one wave per SIMD (its LDS block allows few instances per CU anyway): no vector
+    register may be spilled; the small private segment holds its fixed-size local arrays"""
+    k = _kernels()["rkfd_step_kernel_vol"]
+    assert k["VGPRs Spill"] == 0, k
+    assert k["ScratchSize"] <= 256, k

@@ -203,3 +203,68 @@ def test_emulated_spherical_joints(R, oracle_cls, which):
             seen += int(oact.sum())
     if which == "contact":
         assert seen > 0
+
+
+def _volume_world(R, second=None):
+    import os
+    M = R.scenarios.MODELS
+    w = R.World(solver=R.SOLVER_VOLUME)
+    w.contact_info(os.path.join(M, "contactinfo.ztk"))
+    w.reg_file(os.path.join(M, "box.ztk"))
+    if second:
+        w.reg_file(os.path.join(M, second))
+    w.reg_file(os.path.join(M, "floor.ztk"))
+    return w
+
+
+def _resync_parity(eb, o, nsteps):
+    """every step from the oracle's state: the worst and the median relative deviation after one rkFDUpdate"""
+    errs = []
+    for _ in range(nsteps):
+        od, ov, _a = o.get_state()
+        eb.set_state(od[None, :], ov[None, :]); eb.update_init(); eb.update(1)
+        assert eb.status() == 0
+        assert o.update() == 0
+        d, v, a = eb.get_state(); od, ov, oa = o.get_state()
+        errs.append(max(np.abs(d[0] - od).max(), np.abs(v[0] - ov).max(), np.abs(a[0] - oa).max() / max(1.0, np.abs(oa).max())))
+    return max(errs), float(np.median(errs))
+
+
+@pytest.mark.parametrize("case,nsteps", [("rest", 4), ("slide", 3), ("tilt", 4), ("stack", 3)])
+def test_emulated_volume_plugin_matches_oracle(R, oracle_cls, case, nsteps):
+    """the Volume plugin's device path (csrc/device/rkfd_dev_volume.h) against the oracle's restatement, step by step from
+    the oracle's state: a box resting / sliding (kinetic-friction LP) / dropped tilted (corner and edge contacts, static-friction
+    LP) on the floor (a few steps each here: the emulator's barriers make the simplex and Jacobi loops slow; the GPU tier runs
+    hundreds), and a small box on the box (three rigid pairs, one between two moving bodies).  Typical deviation 1e-13;
+    corner contacts with intersection volumes of 1e-10 m^3 reach 1e-7 (the 6-D QP is solved through a Cholesky factor here
+    and through a pseudo-inverse of the KKT matrix there; two roundings of the oracle itself stay within 1e-11 there)."""
+    w = _volume_world(R, "box_small.ztk" if case == "stack" else None)
+    n = w.model.contents.ndof
+    dis = np.zeros(n); vel = np.zeros(n)
+    dis[2] = 0.0499
+    if case == "slide":
+        vel[0] = 0.5
+    if case == "tilt":
+        dis[:6] = R.scenarios.config1_rigid(batch=1)["dis"][0]; dis[:3] = (0, 0, 0.06)
+    if case == "stack":
+        dis[6:9] = (0.01, 0.02, 0.1 - 1e-4 + 0.025 - 1e-4); dis[11] = 0.4; vel[6] = 0.2
+    eb = EmuBatch(w, 1, max_rigid=4)
+    o = oracle_cls(w.model); o.set_state(dis, vel); o.update_init()
+    if case == "tilt":
+        o.update_n(361)         # down to the corner contacts (intersection volumes of 1e-9 .. 1e-11 m^3)
+    if case == "stack":
+        assert len(o.volume_pairs()) == 2
+    worst, med = _resync_parity(eb, o, nsteps)
+    assert worst < (1e-6 if case == "tilt" else 1e-9), (worst, med)
+
+
+def test_emulated_volume_trajectory(R, oracle_cls):
+    """free-running (no re-synchronisation): the box dropped flat from 1 mm lands the same way on both sides"""
+    w = _volume_world(R)
+    dis = np.zeros((1, 6)); dis[0, 2] = 0.051
+    eb = EmuBatch(w, 1, max_rigid=4)
+    eb.set_state(dis, np.zeros((1, 6))); eb.update_init(); eb.update(12)
+    assert eb.status() == 0
+    o = oracle_cls(w.model); o.set_state(dis[0], np.zeros(6)); o.update_init(); o.update_n(12)
+    d, v, a = eb.get_state(); od, ov, oa = o.get_state()
+    assert np.abs(d[0] - od).max() < 1e-9 and np.abs(v[0] - ov).max() < 1e-8
