@@ -4,7 +4,7 @@
  * by fixed ones so that the run is reproducible.  Every rkFDUpdate runs on the GPU.
  *
  * build: gcc -O2 -Iinclude examples/boxdrop_hardsoft.c -Lroki-fd_amd -lrkfd_amd -Wl,-rpath,$PWD/roki-fd_amd -o boxdrop
- * usage: ./boxdrop [nbox] [steps] [model dir]
+ * usage: ./boxdrop [nbox] [steps] [model dir] [mlcp|vert|volume]
  */
 #include <stdlib.h>
 #include <string.h>
@@ -51,6 +51,7 @@ int main(int argc, char *argv[])
   /* rkFDCreate selects the Vert plugin (reference src/rkfd_sim.c:52); the reference's drivers switch
    * with rkFDSetSolver( &fd, MLCP ) / ( &fd, Vert ) - the fourth argument picks one here */
   if( argc > 4 && strcmp( argv[4], "vert" ) == 0 ) rkFDSetSolver( &fd, Vert );
+  else if( argc > 4 && strcmp( argv[4], "volume" ) == 0 ) rkFDSetSolver( &fd, Volume );      /* what the reference's own driver selects */
   else rkFDSetSolver( &fd, MLCP );
 
   rkFDUpdateInit( &fd );
