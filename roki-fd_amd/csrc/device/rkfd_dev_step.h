@@ -134,6 +134,7 @@ template<bool prof, int vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDevM
   m.has_slide = RKFD_SPEC_HAS_SLIDE; m.ma_size = RKFD_SPEC_MA_SIZE; m.ma_packed = RKFD_SPEC_MA_PACKED;
   m.max_iter = RKFD_SPEC_MAX_ITER; m.solver = RKFD_SPEC_SOLVER; m.pyramid = RKFD_SPEC_PYRAMID; m.anchor = RKFD_SPEC_ANCHOR;
   m.mlcp_mfma = RKFD_SPEC_MLCP_MFMA;
+  m.vol_npair = RKFD_SPEC_VOL_NPAIR; m.vol_np = RKFD_SPEC_VOL_NP; m.vol_ncp = RKFD_SPEC_VOL_NCP; m.vol_pv = RKFD_SPEC_VOL_PV; m.vol_nf = RKFD_SPEC_VOL_NF;
 #else
   const rkfdDevModel &m = m_;
 #endif
@@ -228,7 +229,8 @@ template<bool prof, int vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDevM
       const bool doUp = mode == 0 ? stage == 4 : mode == 1;
       err |= rkfd_evaluate<prof, vqp, pk>( m, L, ll, doUp, pc );
       if( NC > 0 && mode == 0 && stage == 4 && lane == 0 ){     /* contact statistics of the step just committed */
-        L.cnt[CNT_SRG] += L.cnt[CNT_NRG]; L.cnt[CNT_SEL] += L.cnt[CNT_NEL]; L.cnt[CNT_SN] += 1;
+        /* (the Volume plugin's rigid "contacts" are pairs in volumetric contact) */
+        L.cnt[CNT_SRG] += vqp == 2 ? L.cnt[CNT_NVP] : L.cnt[CNT_NRG]; L.cnt[CNT_SEL] += L.cnt[CNT_NEL]; L.cnt[CNT_SN] += 1;
       }
       const double a = on ? L.acc[lane] : 0.0;
       if( stage == 0 ){ Fv = xv; Fa = a; Tv = xv; Ta = a; Pv = c21*xv; Pa = c21*a; }

@@ -407,7 +407,7 @@ static int launch(rkfdBatch *b, int mode, int nsteps, void *stream)
 /* source of the specialised kernel: the dimensions of the world as literals in front of the same device code */
 static std::string spec_source(const rkfdDevModel &d)
 {
-  char buf[2048];
+  char buf[4096];
   snprintf( buf, sizeof(buf),
     "#define RKFD_SPEC 1\n"
     "#define RKFD_SPEC_NLINK %d\n#define RKFD_SPEC_NDOF %d\n#define RKFD_SPEC_NCAND %d\n#define RKFD_SPEC_NLINK_MODEL %d\n"
@@ -416,6 +416,7 @@ static std::string spec_source(const rkfdDevModel &d)
     "#define RKFD_SPEC_NPUROW %d\n#define RKFD_SPEC_PU_ALIAS %d\n#define RKFD_SPEC_VERT_RIGID %d\n#define RKFD_SPEC_QSCR_ALIAS %d\n"
     "#define RKFD_SPEC_HAS_SLIDE %d\n#define RKFD_SPEC_MA_SIZE %d\n#define RKFD_SPEC_MA_PACKED %d\n"
     "#define RKFD_SPEC_MAX_ITER %d\n#define RKFD_SPEC_SOLVER %d\n#define RKFD_SPEC_PYRAMID %d\n#define RKFD_SPEC_ANCHOR %d\n#define RKFD_SPEC_MLCP_MFMA %d\n"
+    "#define RKFD_SPEC_VOL_NPAIR %d\n#define RKFD_SPEC_VOL_NP %d\n#define RKFD_SPEC_VOL_NCP %d\n#define RKFD_SPEC_VOL_PV %d\n#define RKFD_SPEC_VOL_NF %d\n"
     "#include \"rkfd_device.h\"\n"
     "extern \"C\" __global__ void __launch_bounds__(64, %d)\n"
     "rkfd_step_kernel_spec(rkfdDevModel m, rkfdDevState st, int first, int mode, int nsteps, int *errflag)\n"
@@ -427,6 +428,7 @@ static std::string spec_source(const rkfdDevModel &d)
     "}\n",
     d.nlink, d.ndof, d.ncand, d.nlink_model, d.nlevel, d.nround, d.nsched, d.maxrg, d.npool, d.nfloat, d.maxact, d.nside,
     d.npurow, d.pu_alias, d.vert_rigid, d.qscr_alias, d.has_slide, d.ma_size, d.ma_packed, d.max_iter, d.solver, d.pyramid, d.anchor, d.mlcp_mfma,
+    d.vol_npair, d.vol_np, d.vol_ncp, d.vol_pv, d.vol_nf,
     d.vol_np > 0 ? 1 : 3, d.vol_np > 0 ? "2" : ( d.vert_rigid ? "1" : "0" ), d.ma_packed ? "true" : "false" );
   return std::string( buf );
 }
@@ -540,7 +542,7 @@ extern "C" int rkfdBatchSpecialize(rkfdBatch *b)
     hipFuncGetAttribute( &regs, HIP_FUNC_ATTRIBUTE_NUM_REGS, b->spec_fn );
     hipFuncGetAttribute( &scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, b->spec_fn );
     if( getenv( "RKFD_SPEC_DEBUG" ) ) fprintf( stderr, "rkfdBatchSpecialize: %d VGPRs, %d bytes of scratch per lane, %zu bytes of LDS\n", regs, scratch, b->lds_bytes );
-    if( scratch > 64 ){
+    if( scratch > ( b->dm.vol_np > 0 ? 256 : 64 ) ){      /* (the Volume variant keeps small fixed-size arrays in its private segment: 80 bytes) */
       (void)hipModuleUnload( b->spec_mod ); b->spec_mod = NULL; b->spec_fn = NULL;
       SETERR( "rkfdBatchSpecialize: the compiler hipRTC resolved to in this process produced a spilling kernel (%d VGPRs, %d bytes of scratch per lane); "
               "point RKFD_ROCM_LIBDIR at the ROCm libraries this library was built with; the generic kernel stays in use", regs, scratch );

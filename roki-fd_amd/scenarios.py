@@ -355,5 +355,21 @@ def arm_spher(batch=4, contact=False, seed=0x5EED00C1):
     return dict(name="arm_spher" + ("_contact" if contact else ""), world=w, dis=dis, vel=vel, max_rigid=8, steps=200)
 
 
-CONFIGS = {"config1": config1, "config1b": config1_rigid, "config2": config2, "config3": config3, "config4": config4, "config4v": config4_vert, "config5": config5,
+def config1_volume(batch=4096, first=0, seed=0x5EED00D1):
+    """the reference's own boxdrop scene under the plugin its drivers select (rkFDSetSolver( &fd, Volume )): a box lying on
+    the rigid half of floor_hardsoft (seated SEAT_DEPTH deep, random yaw and position), pushed sideways - one rigid pair in
+    volumetric contact in every evaluation: the 6-D wrench QP, then the static or the kinetic friction LP"""
+    w = B.World(solver=B.SOLVER_VOLUME)
+    w.contact_info(_m("contactinfo.ztk"))
+    w.reg_file(_m("box.ztk"))
+    w.reg_file(_m("floor_hardsoft.ztk"))
+    u = splitmix64_uniform(seed, 6 * batch, start=6 * first).reshape(batch, 6)
+    dis = np.zeros((batch, 6)); vel = np.zeros((batch, 6))
+    dis[:, 0] = -0.5 + u[:, 0]; dis[:, 1] = 0.6 + 0.8 * u[:, 1]; dis[:, 2] = 0.05 - SEAT_DEPTH
+    dis[:, 5] = np.pi * (u[:, 2] - 0.5)
+    vel[:, 0] = 0.4 * (u[:, 3] - 0.5); vel[:, 1] = 0.4 * (u[:, 4] - 0.5); vel[:, 5] = 2.0 * (u[:, 5] - 0.5)
+    return dict(name="config1v_box_hard_volume", world=w, dis=dis, vel=vel, max_rigid=1, steps=2000)
+
+
+CONFIGS = {"config1": config1, "config1_volume": config1_volume, "config1b": config1_rigid, "config2": config2, "config3": config3, "config4": config4, "config4v": config4_vert, "config5": config5,
            "config3_26": config3_26, "config4_26": config4_26, "config4_shell": config4_shell}
