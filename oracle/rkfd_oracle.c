@@ -170,6 +170,16 @@ rkfdOracle *rkfdOracleCreate(const rkfdModel *m)
 
   for( i=0; i<nl; i++ )      /* joint types the loader reads but this restatement (like the device path) does not cover */
     if( m->jtype[i] == RKFD_JOINT_BRFLOAT ) return NULL;
+  if( m->solver == RKFD_SOLVER_VOLUME )      /* the Volume plugin's intersection volumes are formed by clipping CONVEX shapes */
+    for( i=0; i<m->npair; i++ ){
+      if( m->ci_type[m->pair_ci[i]] != RKFD_CONTACT_RIGID ) continue;
+      for( k=0; k<2; k++ ){
+        int sh = m->pair_shape[2*i+k], f, v;
+        for( f=m->shape_foff[sh]; f<m->shape_foff[sh+1]; f++ )
+          for( v=m->shape_voff[sh]; v<m->shape_voff[sh+1]; v++ )
+            if( v3_dot( &m->planes[4*f], &m->verts[3*v] ) - m->planes[4*f+3] > 1e-9 ) return NULL;
+      }
+    }
   o = (rkfdOracle *)zalloc( sizeof(rkfdOracle) );
 
   o->m = m; o->nl = nl; o->n = n; o->ncand = nc;

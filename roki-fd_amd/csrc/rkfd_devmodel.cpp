@@ -313,6 +313,12 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
         const int sh = m->pair_shape[2*pr+sd];
         if( sh_l0[sh] >= 0 ) continue;
         const double *T = &Trep[12*m->shape_link[sh]];
+        for( int f=m->shape_foff[sh]; f<m->shape_foff[sh+1]; f++ )
+          for( int v=m->shape_voff[sh]; v<m->shape_voff[sh+1]; v++ ){
+            const double *pl = &m->planes[4*f], *x = &m->verts[3*v];
+            if( pl[0]*x[0] + pl[1]*x[1] + pl[2]*x[2] - pl[3] > 1e-9 )
+              FAIL( "Volume plugin: shape %d of a rigid pair is not convex (the intersection volume is formed by clipping convex shapes)", sh );
+          }
         sh_l0[sh] = (int)vol_loop.size()/2;
         for( int f=m->shape_foff[sh]; f<m->shape_foff[sh+1]; f++ ){
           const double *pl = &m->planes[4*f];

@@ -371,5 +371,12 @@ def config1_volume(batch=4096, first=0, seed=0x5EED00D1):
     return dict(name="config1v_box_hard_volume", world=w, dis=dis, vel=vel, max_rigid=1, steps=2000)
 
 
-CONFIGS = {"config1": config1, "config1_volume": config1_volume, "config1b": config1_rigid, "config2": config2, "config3": config3, "config4": config4, "config4v": config4_vert, "config5": config5,
+def config4_volume(batch=4096, model="humanoid30.ztk", first=0):
+    """the standing humanoid of config 4 under the Volume plugin (what the reference's drivers select): each sole and the
+    floor are one rigid pair in volumetric contact - two 6-D wrenches, twelve unknowns"""
+    w, dis, vel = _humanoid(batch, "contact_rigid.ztk", B.SOLVER_VOLUME, 0x5EED0004, model, first)
+    return dict(name="config4vol_humanoid_rigid_volume", world=w, dis=dis, vel=vel, max_rigid=2, steps=2000)
+
+
+CONFIGS = {"config1": config1, "config1_volume": config1_volume, "config4_volume": config4_volume, "config1b": config1_rigid, "config2": config2, "config3": config3, "config4": config4, "config4v": config4_vert, "config5": config5,
            "config3_26": config3_26, "config4_26": config4_26, "config4_shell": config4_shell}

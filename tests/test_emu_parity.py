@@ -268,3 +268,15 @@ def test_emulated_volume_trajectory(R, oracle_cls):
     o = oracle_cls(w.model); o.set_state(dis[0], np.zeros(6)); o.update_init(); o.update_n(12)
     d, v, a = eb.get_state(); od, ov, oa = o.get_state()
     assert np.abs(d[0] - od).max() < 1e-9 and np.abs(v[0] - ov).max() < 1e-8
+
+
+def test_emulated_volume_humanoid(R, oracle_cls):
+    """the standing humanoid under the Volume plugin: two sole - floor pairs, probe paths through the legs to the float base"""
+    sc = R.scenarios.config4_volume(batch=1)
+    eb = EmuBatch(sc["world"], 1, max_rigid=sc["max_rigid"])
+    eb.set_state(sc["dis"], sc["vel"]); eb.update_init(); eb.update(2)
+    assert eb.status() == 0
+    o = oracle_cls(sc["world"].model); o.set_state(sc["dis"][0], sc["vel"][0]); o.update_init(); o.update_n(2)
+    assert len(o.volume_pairs()) == 2
+    d, v, a = eb.get_state(); od, ov, oa = o.get_state()
+    assert np.abs(d[0] - od).max() < 1e-12 and np.abs(v[0] - ov).max() < 1e-10 and np.abs(a[0] - oa).max() / np.abs(oa).max() < 1e-8

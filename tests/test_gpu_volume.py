@@ -119,3 +119,19 @@ def test_volume_pair_capacity_overflow_is_reported(R):
     bt = R.Batch(w, 1, max_rigid=1)
     bt.set_state(dis2, np.zeros((1, 12))); bt.update_init()
     assert bt.status() == 2
+
+
+def test_volume_humanoid_standing_on_two_soles(R, oracle_cls):
+    """the 30-DoF humanoid of config 4 under the Volume plugin: two rigid pairs (sole - floor), twelve unknowns, probe paths
+    through the legs to the float base; 60 free-running steps of 6 instances against the oracle"""
+    sc = R.scenarios.config4_volume(batch=6)
+    bt = R.Batch(sc["world"], 6, max_rigid=sc["max_rigid"])
+    bt.set_state(sc["dis"], sc["vel"]); bt.update_init(); bt.update(60)
+    assert bt.status() == 0, R.last_error()
+    d, v, a = bt.get_state()
+    for b in range(6):
+        o = oracle_cls(sc["world"].model); o.set_state(sc["dis"][b], sc["vel"][b]); o.update_init(); o.update_n(60)
+        od, ov, oa = o.get_state()
+        assert len(o.volume_pairs()) == 2
+        assert np.abs(d[b] - od).max() < 1e-9 and np.abs(v[b] - ov).max() < 1e-7, (b, np.abs(d[b] - od).max(), np.abs(v[b] - ov).max())
+        assert np.abs(a[b] - oa).max() / max(1.0, np.abs(oa).max()) < 1e-5
