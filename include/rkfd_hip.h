@@ -32,7 +32,9 @@ const char *rkfdHipLastError(void);
  * (reference src/rkfd_sim.c:32-54,188-235,552-558; rkFDCDUpdateInit src/rkfd_cd.c:22-31;
  * plugin _init src/rkfd_mlcp.c:312-325, src/rkfd_vert.c:350-368).  max_rigid = capacity of rigid
  * contact vertices solved per instance (MLCP plugin: 3*max_rigid <= 128; Vert plugin: one pyramid
- * face per lane, pyramid*max_rigid <= 64); exceeding it at run time is reported as an error by
+ * face per lane, pyramid*max_rigid <= 64; Volume plugin: rigid PAIRS in collision at once, at most 10 -
+ * the shapes of a rigid pair must be convex polyhedra with at most 64 faces together, else create fails
+ * with a message); exceeding it at run time is reported as an error by
  * rkfdBatchStatus. */
 rkfdBatch *rkfdBatchCreate(const rkfdModel *m, int batch, int device, int max_rigid);
 void rkfdBatchDestroy(rkfdBatch *b);
@@ -90,8 +92,9 @@ int rkfdBatchTimeLaunches(rkfdBatch *b, int on);
 int rkfdBatchLaunchTiming(rkfdBatch *b, int *launches, double *total_ms);
 
 /* waits for the stream-ordered work, then reports device-side conditions:
- * 0 ok, 1 rigid contact met without a rigid solver set up (Volume plugin, or max_rigid = 0),
- * 2 contact capacity exceeded - more rigid contact vertices than max_rigid, or more rigid + elastic contact
+ * 0 ok, 1 rigid contact met without a rigid solver set up (max_rigid = 0),
+ * 2 contact capacity exceeded - more rigid contact vertices (Volume plugin: pairs in collision, or contact-plane
+ * conditions of a pair: 8) than max_rigid, or more rigid + elastic contact
  * vertices than the active-contact slots (max_rigid when the world has no elastic pairs, else max(max_rigid, 16)
  * capped by the candidate count); the vertices beyond the capacity were dropped -, 3 the Vert plugin's QP ran
  * out of iterations (256) or of basis history (64); negative: HIP error.  rkfdHipLastError() describes a

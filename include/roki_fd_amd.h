@@ -109,9 +109,10 @@ void rkFDSolverDestroy(rkFDSolver *solver);
 #define rkFDSolverUpdateDestroy(s)           (s)->com->_destroy(s)
 /* plugins with a device path.  Vert (the reference's default): penalty (ELASTIC) contacts + the rigid branch with
  * friction pyramids and the active-set QP (reference src/rkfd_vert.c:258-336); MLCP: penalty + rigid PGS.
- * Volume: the table exists so that rkFDSetSolver( &fd, Volume ) compiles as in the reference's drivers; elastic pairs
- * run through the shared penalty path, a RIGID pair has no device path under it and is reported by rkFDUpdate
- * (status 1, message on stderr) - nothing is approximated silently.
+ * Volume (what the reference's drivers select; reference src/rkfd_volume.c): penalty + rigid pairs of CONVEX shapes by their
+ * intersection volumes - a 6-D wrench per pair from the active-set QP, centre-of-normal-force and friction fix-ups with
+ * the simplex LPs (csrc/device/rkfd_dev_volume.h).  A world whose rigid pairs are not convex polyhedra with at most 64
+ * faces together is refused by rkFDUpdateInit with a message - nothing is approximated silently.
  * The table is the reference's (same six entries, same call protocol); what differs: `fd` stands where the reference
  * has `rkFDChainArray chains`, _colchk / _update_ref do nothing (collision detection and the previous driving
  * torque are part of the device step) and rkFDUpdate launches the fused device step instead of walking the table per

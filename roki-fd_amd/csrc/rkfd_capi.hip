@@ -631,7 +631,7 @@ extern "C" int rkfdBatchStatus(rkfdBatch *b, void *stream)
   HIPCHK( hipStreamSynchronize( (hipStream_t)stream ), -1 );
   int e = 0;
   HIPCHK( hipMemcpy( &e, b->d_err, sizeof(int), hipMemcpyDeviceToHost ), -1 );
-  if( e == 1 ) SETERR( "a rigid contact occurred but no rigid solver is set up on the device for this world (Volume plugin, or max_rigid = 0)" );
+  if( e == 1 ) SETERR( "a rigid contact occurred but no rigid solver is set up on the device for this world (max_rigid = 0)" );
   if( e == 2 ) SETERR( "contact capacity exceeded in at least one instance: more rigid contact vertices than max_rigid (%d), or more "
                        "rigid + elastic contact vertices than the %d active-contact slots; contacts beyond the capacity were dropped", b->dm.maxrg, b->dm.maxact );
   if( e == 3 ) SETERR( "the Vert plugin's QP ran out of iterations (256) or of basis history (64) in at least one instance" );

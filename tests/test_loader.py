@@ -104,8 +104,9 @@ def test_reference_drivers_compile_and_link_unmodified(R, tmp_path):
     """the reference's five example drivers (read where they lie, not copied) compile with -Werror=implicit-function-declaration
     against include/roki_fd/roki_fd.h and link against librkfd_amd.so as they are - #include <roki_fd/roki_fd.h>,
     rkFDODE2Assign( &fd, Regular ), rkFDSetSolver( &fd, Volume ), zVecFreeAtOnce, rkCDPairChainUnreg and all.
-    (They select the Volume plugin, whose rigid branch has no device path: run on a GPU they report that and stop
-    short of contact forces; with their commented-out rkFDSetSolver( &fd, MLCP ) line they run.)"""
+    (They select the Volume plugin, which has a device path for pairs of convex shapes: the boxdrop drivers run as they are;
+    the ones that load mighty.ztk with its non-convex body meshes are refused by rkFDUpdateInit with a message and run under
+    their commented-out rkFDSetSolver( &fd, MLCP ) line.)"""
     import glob
     import subprocess
     root = os.path.join(os.path.dirname(__file__), "..")
