@@ -36,7 +36,7 @@ template<bool prof, int vqp, bool pk> RKFD_DEV int rkfd_evaluate(const rkfdDevMo
   }
   SYNC();
   if( vqp == 2 ){
-    if( m.vol_np > 0 ) rkfd_phase_volcol( m, L );
+    if( m.vol_np > 0 ) rkfd_phase_volcol<prof>( m, L, pc );
     else if( lane == 0 ) L.cnt[CNT_NVP] = 0;
     SYNC();
   }
@@ -52,7 +52,7 @@ template<bool prof, int vqp, bool pk> RKFD_DEV int rkfd_evaluate(const rkfdDevMo
     if( L.cnt[CNT_NVP] > 0 ){
       SYNC();
       const double afree = lane < m.ndof ? L.acc[lane] : 0.0;
-      rkfd_phase_volume( m, L, doUpRef );
+      rkfd_phase_volume<prof>( m, L, doUpRef, pc );
       STAMP(4);
       rkfd_phase_sweep3<true>( m, L );
       SYNC();

@@ -240,8 +240,10 @@ RKFD_DEV void d_vol_triangle(const double *tri, const double *fnorm, const doubl
 /* per contact-plane condition, in L.VPL (stride 8): point 3, inward normal 3, tangential velocity there 2 */
 
 /* ------------------------------------------------------------------------ */
-RKFD_DEV void rkfd_phase_volcol(const rkfdDevModel &m, const rkfdLds &L)
+template<bool prof> RKFD_DEV void rkfd_phase_volcol(const rkfdDevModel &m, const rkfdLds &L, unsigned long long *pc)
 {
+  unsigned long long q0 = prof ? RKFD_CLOCK() : 0ull, q1;
+#define VCT(k) do{ if( prof ){ q1 = RKFD_CLOCK(); pc[k] += q1 - q0; q0 = q1; } }while(0)
   const int lane = LANE();
   const int PV = m.vol_pv, NCP = m.vol_ncp;
   const int F = m.vol_nf;
@@ -278,6 +280,7 @@ RKFD_DEV void rkfd_phase_volcol(const rkfdDevModel &m, const rkfdLds &L)
         if( BALLOT( in ) != 0ull ) hit = 1;
       }
     }
+    VCT(28);
     if( !hit ) continue;
     if( nvp >= m.vol_np ){ if( lane == 0 ) L.cnt[CNT_OVF] = 1; continue; }
     /* faces of A inside B, faces of B inside A: lane = face */
@@ -346,6 +349,7 @@ RKFD_DEV void rkfd_phase_volcol(const rkfdDevModel &m, const rkfdLds &L)
       d_ortho_space( ax, ax+3, ax+6 );
     }
     SYNC();
+    VCT(29);
     if( !ok ) continue;
     /* area integrals and the faces' own contact-plane conditions */
     rkfdVolCP cp; cp.has = 0;
@@ -373,6 +377,7 @@ RKFD_DEV void rkfd_phase_volcol(const rkfdDevModel &m, const rkfdLds &L)
       if( lane < 6 ) vd[RKFD_VD_W+lane] = 0.0;
     }
     SYNC();
+    VCT(30);
     /* gather the conditions in face order, merge identical ones, sort by angle (:350-395, :490): one lane, a handful of entries */
     {
       double *cv = scr;          /* [F][7]: has, v, n per face; then [F] angles */
@@ -461,10 +466,12 @@ RKFD_DEV void rkfd_phase_volcol(const rkfdDevModel &m, const rkfdLds &L)
       }
     }
     SYNC();
+    VCT(31);
     nvp++;
   }
   if( lane == 0 ) L.cnt[CNT_NVP] = nvp;
   SYNC();
+#undef VCT
 }
 
 /* ------------------------------------------------------------------------ */
@@ -816,8 +823,10 @@ RKFD_DEV int rkfd_vol_static(const rkfdDevModel &m, const rkfdLds &L, int k, int
 
 /* ------------------------------------------------------------------------ */
 /* the rigid branch proper (_rkFDSolverVolume, :939-957).  Preconditions as for rkfd_phase_mlcp. */
-RKFD_DEV void rkfd_phase_volume(const rkfdDevModel &m, const rkfdLds &L, bool doUpRef)
+template<bool prof> RKFD_DEV void rkfd_phase_volume(const rkfdDevModel &m, const rkfdLds &L, bool doUpRef, unsigned long long *pc)
 {
+  unsigned long long q0 = prof ? RKFD_CLOCK() : 0ull, q1;
+#define VST(k) do{ if( prof ){ q1 = RKFD_CLOCK(); pc[k] += q1 - q0; q0 = q1; } }while(0)
   const int lane = LANE();
   const int np = L.cnt[CNT_NVP], n = 6*np, M = n, ld = n+1;
   const int NCP = m.vol_ncp;
@@ -858,6 +867,7 @@ RKFD_DEV void rkfd_phase_volume(const rkfdDevModel &m, const rkfdLds &L, bool do
     if( RKFD_JT_IS1( jt ) ) L.MS[3*lane+2] = sqrt( L.MS[3*lane+0] );
   }
   SYNC();
+  VST(14);
   /* probes (reference :176-211): lane = column 6 c + i, a unit world force (i < 3) or torque at the centre of pair c, + on
    * cell[0], - on cell[1]; the walk is the one of the MLCP phase */
   if( lane < n ){
@@ -904,6 +914,7 @@ RKFD_DEV void rkfd_phase_volume(const rkfdDevModel &m, const rkfdLds &L, bool do
     }
   }
   SYNC();
+  VST(15);
   /* A(r,k) = sum over the joints common to both paths of nu_r nu_k (no relaxation here: it enters the QP) */
   for( int e0=0; e0<n*n; e0+=RKFD_WAVE ){
     const int e = e0 + lane;
@@ -929,6 +940,7 @@ RKFD_DEV void rkfd_phase_volume(const rkfdDevModel &m, const rkfdLds &L, bool do
     }
   }
   SYNC();
+  VST(6);
   /* _rkFDSolverQPCreate (:496-528): Q = sum_p A_p' qv A_p + l, c = sum_p A_p' ( qv b_p + cv ); qv from the accumulated
    * integrals: [ s 1, -[pc x] ; [pc x], -mm ] */
   double *cvq = L.VQV;
@@ -989,7 +1001,9 @@ RKFD_DEV void rkfd_phase_volume(const rkfdDevModel &m, const rkfdLds &L, bool do
   double init = 0;
   if( lane < n ){ const int c = lane/6, i = lane - 6*c; init = i < 3 ? L.VD[RKFD_VD*c + RKFD_VD_AX + i] : 0.0; }
   SYNC();
+  VST(24);
   rkfd_vol_qp( m, L, n, mc, g, gp, init );
+  VST(25);
   /* _rkFDSolverQP (:547), _rkFDSolverSetForce (:552-568; the offset stays behind a pair without conditions, as in the reference) */
   {
     const double *ans = L.VQV + 2*n;
@@ -1055,6 +1069,7 @@ RKFD_DEV void rkfd_phase_volume(const rkfdDevModel &m, const rkfdLds &L, bool do
     }
   }
   SYNC();
+  VST(26);
   /* _rkFDSolverModifyWrench (:869-916), pair by pair (the simplex runs on the whole wave) */
   for( int p=0; p<np; p++ ){
     double *vd = &L.VD[RKFD_VD*p];
@@ -1107,6 +1122,7 @@ RKFD_DEV void rkfd_phase_volume(const rkfdDevModel &m, const rkfdLds &L, bool do
     SYNC();
   }
   SYNC();
+  VST(27);
   /* the forces in the order of the probe columns, then the inputs of the delta sweep as in the MLCP phase */
   if( lane < n ) L.MF[lane] = L.VD[RKFD_VD*( lane/6 ) + RKFD_VD_W + lane%6];
   SYNC();
@@ -1138,6 +1154,8 @@ RKFD_DEV void rkfd_phase_volume(const rkfdDevModel &m, const rkfdLds &L, bool do
     }
   }
   SYNC();
+  VST(23);
+#undef VST
 }
 
 #endif /* RKFD_DEV_VOLUME_H */

@@ -57,6 +57,14 @@ rkfd_step_kernel_vol(rkfdDevModel m, rkfdDevState st, int first, int mode, int n
   if( b >= st.batch ) return;
   rkfd_instance<false, 2, false>( m, st, b, lds, mode, nsteps, errflag );
 }
+extern "C" __global__ void __launch_bounds__(RKFD_WAVE, 1)
+rkfd_step_kernel_prof_vol(rkfdDevModel m, rkfdDevState st, int first, int mode, int nsteps, int *errflag)
+{
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int b = first + (int)blockIdx.x;
+  if( b >= st.batch ) return;
+  rkfd_instance<true, 2, false>( m, st, b, lds, mode, nsteps, errflag );
+}
 
 /* rkfdBatchRestore: one workgroup copies one instance's state rows back from the snapshot */
 extern "C" __global__ void __launch_bounds__(RKFD_WAVE)
@@ -175,7 +183,7 @@ extern "C" rkfdBatch *rkfdBatchCreate(const rkfdModel *m, int batch, int device,
   if( bad ){ rkfdBatchDestroy( b ); return NULL; }
   b->kern = b->dm.vert_rigid ? rkfd_step_kernel_vqp : ( b->dm.ma_packed ? rkfd_step_kernel_pk : rkfd_step_kernel );
   b->kern_prof = b->dm.vert_rigid ? rkfd_step_kernel_prof_vqp : ( b->dm.ma_packed ? rkfd_step_kernel_prof_pk : rkfd_step_kernel_prof );
-  if( b->dm.vol_np > 0 ){ b->kern = rkfd_step_kernel_vol; b->kern_prof = rkfd_step_kernel_vol; }      /* (no phase stamps in this variant) */
+  if( b->dm.vol_np > 0 ){ b->kern = rkfd_step_kernel_vol; b->kern_prof = rkfd_step_kernel_prof_vol; }
   if( b->lds_bytes > 64*1024 ){
     hipError_t e = hipFuncSetAttribute( (const void *)b->kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes );
     if( e == hipSuccess ) e = hipFuncSetAttribute( (const void *)b->kern_prof, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes );

@@ -257,13 +257,13 @@ def config5(batch=4096, max_rigid=24, first=0):
     return dict(name="config5_humanoid_clutter_mlcp", world=w, dis=dis, vel=vel, max_rigid=max_rigid, steps=1000)
 
 
-def arm_press(batch=8, root="fixed", with_box=True, seed=0x5EED00A1):
+def arm_press(batch=8, root="fixed", with_box=True, seed=0x5EED00A1, solver=B.SOLVER_MLCP):
     """TEST scenario (not one of BASELINE's configs): a 4-joint arm (yaw with DC motor and joint friction,
     shoulder pitch with torque motor, telescopic forearm, wrist roll) presses its box-shaped hand onto a
     free box lying on the rigid floor (or onto the floor itself), MLCP plugin.  Contact paths end at a
     fixed root / at a 1-DoF root, one rigid pair has two moving sides, joints are prismatic as well as
     revolute, motor inputs are non-zero - the branches the humanoid workloads do not take."""
-    w = B.World(solver=B.SOLVER_MLCP)
+    w = B.World(solver=solver)
     w.contact_info(_m("contactinfo.ztk"))
     a = w.reg_file(_m("arm_fixedroot.ztk" if root == "fixed" else "arm_revroot.ztk"))
     bx = w.reg_file(_m("box.ztk")) if with_box else None

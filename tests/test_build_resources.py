@@ -32,7 +32,7 @@ def _kernels():
 def test_every_kernel_variant_is_reported():
     k = _kernels()
     assert set(k) == {"rkfd_step_kernel", "rkfd_step_kernel_pk", "rkfd_step_kernel_vqp", "rkfd_step_kernel_prof", "rkfd_step_kernel_prof_pk", "rkfd_step_kernel_prof_vqp",
-                      "rkfd_step_kernel_vol", "rkfd_restore_kernel"}
+                      "rkfd_step_kernel_vol", "rkfd_step_kernel_prof_vol", "rkfd_restore_kernel"}
 
 
 @pytest.mark.parametrize("name", ["rkfd_step_kernel", "rkfd_step_kernel_pk", "rkfd_step_kernel_vqp", "rkfd_step_kernel_prof", "rkfd_step_kernel_prof_pk", "rkfd_step_kernel_prof_vqp"])

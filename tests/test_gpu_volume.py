@@ -135,3 +135,24 @@ def test_volume_humanoid_standing_on_two_soles(R, oracle_cls):
         assert len(o.volume_pairs()) == 2
         assert np.abs(d[b] - od).max() < 1e-9 and np.abs(v[b] - ov).max() < 1e-7, (b, np.abs(d[b] - od).max(), np.abs(v[b] - ov).max())
         assert np.abs(a[b] - oa).max() / max(1.0, np.abs(oa).max()) < 1e-5
+
+
+@pytest.mark.parametrize("root", ["fixed", "revolute"])
+def test_volume_arm_presses_a_box(R, oracle_cls, root):
+    """scenarios.arm_press under the Volume plugin: the hand of a 4-joint arm (DC motor with joint friction, torque motor,
+    prismatic forearm) on a free box on the floor - probe paths that end at a fixed root / a 1-DoF root, a rigid pair
+    between two moving bodies, driven motors.  40 free-running steps of 4 instances."""
+    sc = R.scenarios.arm_press(batch=4, root=root, solver=R.SOLVER_VOLUME)
+    bt = R.Batch(sc["world"], 4, max_rigid=6)
+    bt.set_state(sc["dis"], sc["vel"]); bt.set_motor_input(sc["motor_in"]); bt.update_init(); bt.update(40)
+    assert bt.status() == 0, R.last_error()
+    d, v, a = bt.get_state()
+    seen = 0
+    for b in range(4):
+        o = oracle_cls(sc["world"].model); o.set_state(sc["dis"][b], sc["vel"][b]); o.set_motor_input(sc["motor_in"][b]); o.update_init()
+        for _ in range(40):
+            assert o.update() == 0
+            seen += len(o.volume_pairs()) >= 2
+        od, ov, oa = o.get_state()
+        assert np.abs(d[b] - od).max() < 1e-8 and np.abs(v[b] - ov).max() < 1e-6, (b, np.abs(d[b] - od).max(), np.abs(v[b] - ov).max())
+    assert seen > 40
