@@ -12,7 +12,8 @@
  *     the direction that pushes cell[0] out of cell[1]; axis = ( norm, the orthonormal complement as in the vertex
  *     path ).  The contact-plane list is rebuilt on every evaluation.
  *   zLPSolveSimplex / zLPFeasibleBase (ZM zm_opt; :685,837,839) - min c'x s.t. Ax = b, x >= 0 by the two-phase
- *     tableau simplex method with Bland's rule; false when infeasible or unbounded.
+ *     tableau simplex method (entering column: most negative reduced cost, Bland's rule after 64 pivots; leaving row:
+ *     minimum ratio, lowest basic index among equals); false when infeasible or unbounded.
  *   zList order - zListInsertHead appends at the end zListForEach reaches last; rkCDPlaneListQuickSort leaves the
  *     list ascending in the order zListForEach visits it.
  *   zMat6D - e[row block][column block]; _zVec3DOuterProdToMat3D(p) = [p x], _zVec3DTripleProdToMat3D(a,b) = [a x][b x].
@@ -438,8 +439,7 @@ static void vol_constraint(rkfdOracle *o, VolPair *vp, double *q, double *c)
 }
 
 /* ------------------------------------------------------------------------ */
-/* zLPSolveSimplex [UNVERIFIED-DEP]: min c'x s.t. Ax = b (m rows), x >= 0 (n columns): two-phase tableau simplex with
- * Bland's rule.  c == NULL: phase 1 only (zLPFeasibleBase).  Returns 1 when an optimal (feasible) vertex was found. */
+/* zLPSolveSimplex [UNVERIFIED-DEP]: min c'x s.t. Ax = b (m rows), x >= 0 (n columns): two-phase tableau simplex.  c == NULL: phase 1 only (zLPFeasibleBase).  Returns 1 when an optimal (feasible) vertex was found. */
 #define LP_EPS 1e-10
 static int vol_lp(int mr, int n, const double *A, const double *b, const double *c, double *x)
 {
@@ -469,7 +469,13 @@ static int vol_lp(int mr, int n, const double *A, const double *b, const double 
     }
     for( it=0; it<10000; it++ ){
       int col = -1, row = -1; double best = 0;
-      for( j=0; j<ncol; j++ ) if( cost[j] < -LP_EPS ){ col = j; break; }       /* Bland: the first improving column */
+      /* entering column: the most negative reduced cost (lowest index among equals); after 64 pivots of a phase Bland's
+       * rule (the first improving column), which cannot cycle */
+      if( it < 64 ){
+        double cm = -LP_EPS;
+        for( j=0; j<ncol; j++ ) if( cost[j] < cm ){ cm = cost[j]; col = j; }
+      } else
+        for( j=0; j<ncol; j++ ) if( cost[j] < -LP_EPS ){ col = j; break; }
       if( col < 0 ) break;
       for( i=0; i<mr; i++ )
         if( T[ld*i+col] > LP_EPS ){

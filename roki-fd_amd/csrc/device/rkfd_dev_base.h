@@ -22,6 +22,10 @@
 #  define RKFD_SCHED_BARRIER() do{}while(0)
 #  define BCAST(x,l)    rkfd_emu_bcast(x,l)
 #  define BALLOT(p)     rkfd_emu_ballot(p)
+   double rkfd_emu_wsum(double x);
+   double rkfd_emu_wmin(double x);
+#  define WSUM(x)       rkfd_emu_wsum(x)
+#  define WMIN(x)       rkfd_emu_wmin(x)
 #  define ROWBC_FMAC(C,acc,x,a) ( (acc) = fma( rkfd_emu_bcast( (x), ( rkfd_emu_lane() & ~15 ) | (C) ), (a), (acc) ) )
 #else
 #  define RKFD_DEV __device__ __forceinline__
@@ -116,6 +120,28 @@ template<int C> RKFD_DEV void rkfd_rowbc_fmac(double &acc, double x, double a)
 #  define RKFD_SCHED_BARRIER() __builtin_amdgcn_sched_barrier( 0 )
 #  define BCAST(x,l)    rkfd_bcast(x,l)
 #  define BALLOT(p)     __ballot(p)
+/* sum / minimum over the whole wave in registers, the same value in every lane: the 8-lane DPP butterfly, then the eight
+ * group results through v_readlane (no LDS, no barrier: ~100 cycles where a tree through LDS takes ~2000) */
+RKFD_DEV double rkfd_wave_sum(double x)
+{
+  x = rkfd_g8sum( x );
+  double r = rkfd_bcast( x, 0 );
+#pragma unroll
+  for( int g=1; g<8; g++ ) r += rkfd_bcast( x, 8*g );
+  return r;
+}
+RKFD_DEV double rkfd_wave_min(double x)
+{
+  x = fmin( x, rkfd_dpp_xor1( x ) );
+  x = fmin( x, rkfd_dpp_xor2( x ) );
+  x = fmin( x, rkfd_dpp_hmirror( x ) );
+  double r = rkfd_bcast( x, 0 );
+#pragma unroll
+  for( int g=1; g<8; g++ ) r = fmin( r, rkfd_bcast( x, 8*g ) );
+  return r;
+}
+#  define WSUM(x)       rkfd_wave_sum(x)
+#  define WMIN(x)       rkfd_wave_min(x)
 #endif
 
 #define RKFD_DEV_TOL RKFD_TOL
@@ -385,7 +411,7 @@ RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int
     L->VPOLY = d; L->VRED = d + vol_nf*vol_pv*3;
     double *e = d;
     L->VQL = e; e += n*( n+1 )/2; L->VQW = e; e += n*mc; L->VS = e; e += mc*mc; L->VEV = e; e += mc*mc;
-    L->VQV = e; e += 5*n + mc + 64; L->VLP = e; e += 15*pyramid*vol_ncp + 61;
+    L->VQV = e; e += 5*n + mc + 64; L->VLP = e; e += 8*pyramid*vol_ncp + 6;
     d += RKFD_VOL_LDS_COL( vol_nf, vol_pv ) > RKFD_VOL_LDS_SOL( vol_np, vol_ncp, pyramid ) ? RKFD_VOL_LDS_COL( vol_nf, vol_pv ) : RKFD_VOL_LDS_SOL( vol_np, vol_ncp, pyramid );
   }
   int *ip = (int *)d;

@@ -17,7 +17,7 @@
 #ifndef RKFD_DEV_VOLUME_H
 #define RKFD_DEV_VOLUME_H
 
-#define RKFD_VOL_NRED 28
+#define RKFD_VOL_NRED 16
 /* sum NV values of the first F lanes, in lane order: scr holds [NV][F] + [NV] doubles; the sums are left in scr[NV*F ..] */
 template<int NV> RKFD_DEV void rkfd_vol_reduce(double *scr, const double *val, int F)
 {
@@ -287,9 +287,17 @@ template<bool prof> RKFD_DEV void rkfd_phase_volcol(const rkfdDevModel &m, const
     const bool onf = lane < na+nb;
     const bool isA = lane < na;
     const int f = onf ? ( isA ? a0+lane : b0+lane-na ) : 0;
-    const double *Rs = isA ? RA : RB, *ps = isA ? pA : pB, *Ro = isA ? RB : RA, *po = isA ? pB : pA;
+    const double *Rs = isA ? RA : RB, *ps = isA ? pA : pB;
     int n = 0;
     double nw[3] = {0,0,0};
+    /* every face's plane in world coordinates, staged in LDS: the clipping loops below read the other shape's planes from there */
+    double *stg = L.VRED;
+    if( onf ){
+      const double *pl = &RELOAD( m.vol_lplane )[4*f];
+      d_mulv( Rs, pl, nw );
+      stg[4*lane] = nw[0]; stg[4*lane+1] = nw[1]; stg[4*lane+2] = nw[2]; stg[4*lane+3] = pl[3] + d_dot( nw, ps );
+    }
+    SYNC();
     if( onf ){
       const int v0 = RELOAD( m.vol_loop )[2*f];
       n = RELOAD( m.vol_loop )[2*f+1];
@@ -298,14 +306,8 @@ template<bool prof> RKFD_DEV void rkfd_phase_volcol(const rkfdDevModel &m, const
         d_mulv( Rs, &RELOAD( m.vol_lvert )[3*( v0+i )], x );
         P[3*i] = x[0]+ps[0]; P[3*i+1] = x[1]+ps[1]; P[3*i+2] = x[2]+ps[2];
       }
-      d_mulv( Rs, &RELOAD( m.vol_lplane )[4*f], nw );
-      const int g0 = isA ? b0 : a0, ng = isA ? nb : na;
-      for( int g=g0; g<g0+ng && n>=3; g++ ){
-        const double *pl = &RELOAD( m.vol_lplane )[4*g];
-        double gw[3];
-        d_mulv( Ro, pl, gw );
-        n = d_vol_clip( P, n, PV, gw, pl[3] + d_dot( gw, po ) );
-      }
+      const int g0 = isA ? na : 0, ng = isA ? nb : na;      /* the other shape's faces are lanes g0 .. g0+ng-1 */
+      for( int g=g0; g<g0+ng && n>=3; g++ ) n = d_vol_clip( P, n, PV, &stg[4*g], stg[4*g+3] );
       if( n < 3 ) n = 0;
     }
     /* reference point of the signed tetrahedra: the first vertex of the first face that survived (a point ON the volume: with
@@ -481,6 +483,12 @@ template<bool prof> RKFD_DEV void rkfd_phase_volcol(const rkfdDevModel &m, const
 RKFD_DEV double rkfd_vol_pinv(double *S, double *EV, double *vec, int ld, int r, double rhs_i, double *scr)
 {
   const int lane = LANE();
+  if( r == 0 ) return 0.0;
+  if( r == 1 ){
+    /* one active row: x = rhs / s unless s is (numerically) zero */
+    const double s00 = S[0], r0 = BCAST( rhs_i, 0 );
+    return ( lane == 0 && fabs( s00 ) > 0.0 ) ? r0/s00 : 0.0;
+  }
   if( lane < r ) for( int j=0; j<r; j++ ) EV[lane*ld+j] = lane == j ? 1.0 : 0.0;
   SYNC();
   for( int sweep=0; sweep<60; sweep++ ){
@@ -489,7 +497,7 @@ RKFD_DEV double rkfd_vol_pinv(double *S, double *EV, double *vec, int ld, int r,
       dg = S[lane*ld+lane]*S[lane*ld+lane];
       for( int j=lane+1; j<r; j++ ) off += S[lane*ld+j]*S[lane*ld+j];
     }
-    const double soff = rkfd_w_sum( off, scr ), sdg = rkfd_w_sum( dg, scr );
+    const double soff = WSUM( off ), sdg = WSUM( dg );
     if( soff <= 1e-30*( sdg + soff ) || soff == 0 ) break;
     for( int i=0; i<r-1; i++ )
       for( int j=i+1; j<r; j++ ){
@@ -514,7 +522,7 @@ RKFD_DEV double rkfd_vol_pinv(double *S, double *EV, double *vec, int ld, int r,
       }
   }
   SYNC();
-  const double wmax = -rkfd_w_min( lane < r ? -fabs( S[lane*ld+lane] ) : 0.0, scr );
+  const double wmax = -WMIN( lane < r ? -fabs( S[lane*ld+lane] ) : 0.0 );
   if( lane < r ) vec[lane] = rhs_i;
   SYNC();
   double y = 0;
@@ -603,7 +611,7 @@ RKFD_DEV void rkfd_vol_qp(const rkfdDevModel &m, const rkfdLds &L, int n, int mc
       const double y = ( onc && act ) ? lam[rho] : 0.0;
       SYNC();
       if( BALLOT( onc && act && y < 0 ) == 0ull ) break;
-      const double ymin = rkfd_w_min( ( onc && act ) ? y : HUGE_VAL, scr );
+      const double ymin = WMIN( ( onc && act ) ? y : HUGE_VAL );
       if( onc && act && fabs( y - ymin ) < RKFD_QP_ASM_TOL ) act = 0;
       continue;
     }
@@ -614,7 +622,7 @@ RKFD_DEV void rkfd_vol_qp(const rkfdDevModel &m, const rkfdLds &L, int n, int mc
       const double gd = RKFD_VOL_COND( dv );
       if( gd < 0 ) tq = ( 0.0 - RKFD_VOL_COND( ans ) )/gd;
     }
-    double tmin = rkfd_w_min( tq, scr );
+    double tmin = WMIN( tq );
     if( !( tmin < 1.0 ) ) tmin = 1.0;
     if( lane < n ) ans[lane] += tmin*dv[lane];
     SYNC();
@@ -625,7 +633,7 @@ RKFD_DEV void rkfd_vol_qp(const rkfdDevModel &m, const rkfdLds &L, int n, int mc
       for( int j=lane+1; j<n; j++ ) u = fma( Q[RKFD_QI( j, lane )], ans[j], u );
       part = 0.5*u*u + cv[lane]*ans[lane];
     }
-    const double objv = rkfd_w_sum( part, scr );
+    const double objv = WSUM( part );
     const unsigned long long nmask = BALLOT( act );
     const bool seen = lane < nhist && hmask == nmask && !( fabs( hobj/objv - 1.0 ) > RKFD_QP_ASM_TOL );
     if( BALLOT( seen ) != 0ull ) break;
@@ -641,104 +649,140 @@ RKFD_DEV void rkfd_vol_qp(const rkfdDevModel &m, const rkfdLds &L, int n, int mc
 
 /* ------------------------------------------------------------------------ */
 /* zLPSolveSimplex / zLPFeasibleBase as restated in the oracle (vol_lp): min c'x s.t. Ax = b, x >= 0; two-phase tableau,
- * Bland's rule; lane = column (strided).  A (mr x n, row-major) , b (mr), c (n; phase 2 only when has_c) are in L.VLP's
- * input area; result x (n) there too.  Layout of L.VLP: T [(mr) x ld], cost [ld], A [mr x n], b [mr], c [n], x [n], bas [mr]. */
+ * entering column by the most negative reduced cost (Bland's rule after 64 pivots).  The tableau lives in REGISTERS: lane = column (columns lane and lane + 64: n + mr + 1 <= 128), six rows and the
+ * reduced cost per column; the pivot column and the right-hand side reach every lane through v_readlane, the ratio test is
+ * scalar, a pivot is ~40 vector instructions - no LDS traffic and no barrier inside the iteration.  A (mr x n, row-major),
+ * b (mr), c (n; phase 2 only when has_c) are read from LDS once; the result x (n) is written there. */
 #define RKFD_LP_EPS 1e-10
-RKFD_DEV int rkfd_vol_lp(double *T, double *cost, double *basd, const double *A, const double *b, const double *c, double *x, int mr, int n, bool has_c)
+#define RKFD_LP_SEL(t0, t1, hi) ( (hi) ? (t1) : (t0) )
+RKFD_DEV int rkfd_vol_lp(const double *A, const double *b, const double *c, double *x, int mr, int n, bool has_c)
 {
   const int lane = LANE();
-  const int nt = n + mr, ld = nt + 1;
+  const int nt = n + mr;                       /* column of the right-hand side */
+  const int rl = nt & 63, rh = nt >> 6;
+  double T0[6], T1[6], c0 = 0, c1 = 0;
+  int bas[6];
   double scale = 0;
-  for( int i=0; i<mr; i++ ){
-    const double sg = b[i] < 0 ? -1.0 : 1.0;
-    for( int j=lane; j<=nt; j+=RKFD_WAVE )
-      T[ld*i+j] = j < n ? sg*A[n*i+j] : ( j < nt ? ( j-n == i ? 1.0 : 0.0 ) : sg*b[i] );
-    if( lane == 0 ) basd[i] = (double)( n+i );
-    if( fabs( b[i] ) > scale ) scale = fabs( b[i] );
+#pragma unroll
+  for( int i=0; i<6; i++ ){
+    T0[i] = 0; T1[i] = 0; bas[i] = n+i;
+    if( i < mr ){
+      const double bi = b[i], sg = bi < 0 ? -1.0 : 1.0;
+      const int j0 = lane, j1 = lane + 64;
+      T0[i] = j0 < n ? sg*A[n*i+j0] : ( j0 < nt ? ( j0-n == i ? 1.0 : 0.0 ) : ( j0 == nt ? sg*bi : 0.0 ) );
+      T1[i] = j1 < n ? sg*A[n*i+j1] : ( j1 < nt ? ( j1-n == i ? 1.0 : 0.0 ) : ( j1 == nt ? sg*bi : 0.0 ) );
+      if( fabs( bi ) > scale ) scale = fabs( bi );
+    }
   }
-  SYNC();
   int ok = 1;
   for( int ph=1; ph<=2 && ok; ph++ ){
     const int ncol = ph == 1 ? nt : n;
     if( ph == 2 && !has_c ) break;
-    for( int j=lane; j<=nt; j+=RKFD_WAVE ){
-      double r = ph == 1 ? ( j >= n && j < nt ? 1.0 : 0.0 ) : ( j < n ? c[j] : 0.0 );
-      for( int i=0; i<mr; i++ ){
-        const int bi = (int)basd[i];
-        const double cb = ph == 1 ? ( bi >= n ? 1.0 : 0.0 ) : ( bi < n ? c[bi] : 0.0 );
-        r -= cb*T[ld*i+j];
-      }
-      cost[j] = r;
+    {
+      /* reduced costs of this phase */
+      const int j0 = lane, j1 = lane + 64;
+      double r0 = ph == 1 ? ( j0 >= n && j0 < nt ? 1.0 : 0.0 ) : ( j0 < n ? c[j0] : 0.0 );
+      double r1 = ph == 1 ? ( j1 >= n && j1 < nt ? 1.0 : 0.0 ) : ( j1 < n ? c[j1] : 0.0 );
+#pragma unroll
+      for( int i=0; i<6; i++ )
+        if( i < mr ){
+          const double cb = ph == 1 ? ( bas[i] >= n ? 1.0 : 0.0 ) : ( bas[i] < n ? c[bas[i]] : 0.0 );
+          r0 -= cb*T0[i]; r1 -= cb*T1[i];
+        }
+      c0 = r0; c1 = r1;
     }
-    SYNC();
     int it;
     for( it=0; it<10000; it++ ){
       int col = -1;
-      for( int j0=0; j0<ncol && col<0; j0+=RKFD_WAVE ){
-        const int j = j0 + lane;
-        const unsigned long long mk = BALLOT( j < ncol && cost[j] < -RKFD_LP_EPS );
-        if( mk ) col = j0 + __builtin_ctzll( mk );
+      {
+        /* entering column: the most negative reduced cost, lowest index among equals; Bland's rule after 64 pivots (as the oracle) */
+        const bool v0 = lane < ncol && c0 < -RKFD_LP_EPS, v1 = lane + 64 < ncol && c1 < -RKFD_LP_EPS;
+        double cm = 0;
+        if( it < 64 ) cm = WMIN( fmin( v0 ? c0 : 0.0, v1 ? c1 : 0.0 ) );
+        const unsigned long long m0 = BALLOT( v0 && ( it >= 64 || c0 == cm ) );
+        if( m0 ) col = __builtin_ctzll( m0 );
+        else {
+          const unsigned long long m1 = BALLOT( v1 && ( it >= 64 || c1 == cm ) );
+          if( m1 ) col = 64 + __builtin_ctzll( m1 );
+        }
       }
       if( col < 0 ) break;
-      int row = -1; double best = 0;
-      for( int i=0; i<mr; i++ )
-        if( T[ld*i+col] > RKFD_LP_EPS ){
-          const double r = T[ld*i+nt]/T[ld*i+col];
-          if( row < 0 || r < best - 1e-15 || ( !( r > best + 1e-15 ) && basd[i] < basd[row] ) ){ row = i; best = r; }
+      const int cl = col & 63, ch = col >> 6;
+      double pc[6], rr[6];
+#pragma unroll
+      for( int i=0; i<6; i++ ){
+        pc[i] = BCAST( RKFD_LP_SEL( T0[i], T1[i], ch ), cl );
+        rr[i] = BCAST( RKFD_LP_SEL( T0[i], T1[i], rh ), rl );
+      }
+      int row = -1, brow = 0; double best = 0;
+#pragma unroll
+      for( int i=0; i<6; i++ )
+        if( i < mr && pc[i] > RKFD_LP_EPS ){
+          const double r = rr[i]/pc[i];
+          if( row < 0 || r < best - 1e-15 || ( !( r > best + 1e-15 ) && bas[i] < brow ) ){ row = i; best = r; brow = bas[i]; }
         }
       if( row < 0 ){ ok = 0; break; }
       {
-        const double pv = 1.0/T[ld*row+col], fcost = cost[col];
-        double fct[6];
+        double pv = 0, t0 = 0, t1 = 0;
 #pragma unroll
-        for( int i=0; i<6; i++ ) fct[i] = ( i < mr && i != row ) ? T[ld*i+col] : 0.0;
-        SYNC();
-        for( int j=lane; j<=nt; j+=RKFD_WAVE ){
-          const double tr = T[ld*row+j]*pv;
-          T[ld*row+j] = tr;
+        for( int i=0; i<6; i++ ) if( i == row ){ pv = 1.0/pc[i]; t0 = T0[i]; t1 = T1[i]; }
+        t0 *= pv; t1 *= pv;
+        const double fc = BCAST( RKFD_LP_SEL( c0, c1, ch ), cl );
 #pragma unroll
-          for( int i=0; i<6; i++ ) if( i < mr && i != row && fct[i] != 0.0 ) T[ld*i+j] -= fct[i]*tr;
-          cost[j] -= fcost*tr;
+        for( int i=0; i<6; i++ ){
+          if( i == row ){ T0[i] = t0; T1[i] = t1; bas[i] = col; }
+          else if( i < mr && pc[i] != 0.0 ){ T0[i] -= pc[i]*t0; T1[i] -= pc[i]*t1; }
         }
-        if( lane == 0 ) basd[row] = (double)col;
-        SYNC();
+        c0 -= fc*t0; c1 -= fc*t1;
       }
     }
     if( it == 10000 ) ok = 0;
     if( ph == 1 && ok ){
       double art = 0;
-      for( int i=0; i<mr; i++ ) if( (int)basd[i] >= n ) art += T[ld*i+nt];
+#pragma unroll
+      for( int i=0; i<6; i++ ){
+        const double ri = BCAST( RKFD_LP_SEL( T0[i], T1[i], rh ), rl );
+        if( i < mr && bas[i] >= n ) art += ri;
+      }
       if( art > 1e-9*( 1.0 + scale ) ) ok = 0;
-      else
-        for( int i=0; i<mr; i++ )
-          if( (int)basd[i] >= n ){
-            int jc = -1;
-            for( int j0=0; j0<n && jc<0; j0+=RKFD_WAVE ){
-              const int j = j0 + lane;
-              const unsigned long long mk = BALLOT( j < n && fabs( T[ld*i+j] ) > 1e-9 );
-              if( mk ) jc = j0 + __builtin_ctzll( mk );
-            }
-            if( jc < 0 ) continue;
-            const double pv = 1.0/T[ld*i+jc];
-            double fct[6];
+      else {
 #pragma unroll
-            for( int k=0; k<6; k++ ) fct[k] = ( k < mr && k != i ) ? T[ld*k+jc] : 0.0;
-            SYNC();
-            for( int j=lane; j<=nt; j+=RKFD_WAVE ){
-              const double tr = T[ld*i+j]*pv;
-              T[ld*i+j] = tr;
-#pragma unroll
-              for( int k=0; k<6; k++ ) if( k < mr && k != i && fct[k] != 0.0 ) T[ld*k+j] -= fct[k]*tr;
+        for( int i=0; i<6; i++ ){
+          /* an artificial left in the base at zero: pivot it out on the first structural column with an entry in its row */
+          const bool need = i < mr && bas[i] >= n;       /* (wave-uniform) */
+          int jc = -1;
+          if( need ){
+            const unsigned long long m0 = BALLOT( need && lane < n && fabs( T0[i] ) > 1e-9 );
+            if( m0 ) jc = __builtin_ctzll( m0 );
+            else {
+              const unsigned long long m1 = BALLOT( need && lane + 64 < n && fabs( T1[i] ) > 1e-9 );
+              if( m1 ) jc = 64 + __builtin_ctzll( m1 );
             }
-            if( lane == 0 ) basd[i] = (double)jc;
-            SYNC();
           }
+          if( jc >= 0 ){
+            double pc[6];
+#pragma unroll
+            for( int k=0; k<6; k++ ) pc[k] = BCAST( RKFD_LP_SEL( T0[k], T1[k], jc >= 64 ), jc & 63 );
+            const double pv = 1.0/pc[i];
+            const double t0 = T0[i]*pv, t1 = T1[i]*pv;
+#pragma unroll
+            for( int k=0; k<6; k++ ){
+              if( k == i ){ T0[k] = t0; T1[k] = t1; bas[k] = jc; }
+              else if( k < mr && pc[k] != 0.0 ){ T0[k] -= pc[k]*t0; T1[k] -= pc[k]*t1; }
+            }
+          }
+        }
+      }
     }
   }
   if( ok ){
     for( int j=lane; j<n; j+=RKFD_WAVE ) x[j] = 0;
     SYNC();
-    if( lane < mr && (int)basd[lane] < n ) x[(int)basd[lane]] = T[ld*lane+nt];
+#pragma unroll
+    for( int i=0; i<6; i++ ){
+      const double ri = BCAST( RKFD_LP_SEL( T0[i], T1[i], rh ), rl );
+      if( i < mr && bas[i] < n && lane == 0 ) x[bas[i]] = ri;
+    }
   }
   SYNC();
   return ok;
@@ -753,9 +797,8 @@ RKFD_DEV void rkfd_vol_kinetic(const rkfdDevModel &m, const rkfdLds &L, int k, i
   const int NCP = m.vol_ncp, n = L.VI[2*k];
   const double *pl = &L.VPL[8*NCP*k], *vd = &L.VD[RKFD_VD*k];
   const double *ax = vd + RKFD_VD_AX;
-  double *lp = L.VLP;
-  const int ntmax = m.pyramid*NCP + 6, ldmax = ntmax + 1;
-  double *T = lp, *cost = lp + 6*ldmax, *A = cost + ldmax, *b = A + 6*( ntmax-6 ), *c = b + 6, *x = c + ( ntmax-6 ), *bas = x + ( ntmax-6 );
+  const int PN = m.pyramid*NCP;
+  double *A = L.VLP, *b = A + 6*PN, *c = b + 6, *x = c + PN;      /* layout of L.VLP: A [6 x PN], b [6], c [PN], x [PN] */
   double r0 = 0, r1 = 0, sx = 0, sy = 0;
   if( lane < n ){
     const double *c2 = &pl[8*lane];
@@ -775,7 +818,7 @@ RKFD_DEV void rkfd_vol_kinetic(const rkfdDevModel &m, const rkfdLds &L, int k, i
   }
   if( lane == 0 ){ b[0] = w[0]; b[1] = w[4]; b[2] = w[5]; }
   SYNC();
-  if( !rkfd_vol_lp( T, cost, bas, A, b, c, x, 3, n, true ) ){
+  if( !rkfd_vol_lp( A, b, c, x, 3, n, true ) ){
     if( lane < n ){
       double wn[2];
 #pragma unroll
@@ -783,10 +826,10 @@ RKFD_DEV void rkfd_vol_kinetic(const rkfdDevModel &m, const rkfdLds &L, int k, i
       c[lane] += wn[0]*r0 - wn[1]*r1;
     }
     SYNC();
-    rkfd_vol_lp( T, cost, bas, A, b, c, x, 1, n, true );
+    rkfd_vol_lp( A, b, c, x, 1, n, true );
   }
   /* _rkFDSolverModifyWrenchKineticTotalWrench (:814-828): lane order = list order */
-  double *red = cost;
+  double *red = A;       /* (the constraint matrix is dead) */
   if( lane < n ){ const double fx = sx*x[lane], fy = sy*x[lane]; red[3*lane] = fx; red[3*lane+1] = fy; red[3*lane+2] = r0*fy - r1*fx; }
   SYNC();
   double a1 = 0, a2 = 0, a3 = 0;
@@ -801,9 +844,8 @@ RKFD_DEV int rkfd_vol_static(const rkfdDevModel &m, const rkfdLds &L, int k, int
   const int NCP = m.vol_ncp, ncp = L.VI[2*k], P = m.pyramid, n = P*ncp;
   const double *pl = &L.VPL[8*NCP*k], *vd = &L.VD[RKFD_VD*k];
   const double *ax = vd + RKFD_VD_AX;
-  double *lp = L.VLP;
-  const int ntmax = P*NCP + 6, ldmax = ntmax + 1;
-  double *T = lp, *cost = lp + 6*ldmax, *A = cost + ldmax, *b = A + 6*( ntmax-6 ), *c = b + 6, *x = c + ( ntmax-6 ), *bas = x + ( ntmax-6 );
+  const int PN = P*NCP;
+  double *A = L.VLP, *b = A + 6*PN, *c = b + 6, *x = c + PN;
   const double mu = m.ci_sf[ci];
   for( int j=lane; j<n; j+=RKFD_WAVE ){
     const int kk = j/P, i = j - kk*P;
@@ -818,7 +860,7 @@ RKFD_DEV int rkfd_vol_static(const rkfdDevModel &m, const rkfdLds &L, int k, int
   }
   if( lane == 0 ){ b[0] = w[0]; b[1] = w[4]; b[2] = w[5]; b[3] = w[1]; b[4] = w[2]; b[5] = w[3]; }
   SYNC();
-  return rkfd_vol_lp( T, cost, bas, A, b, c, x, 6, n, false );
+  return rkfd_vol_lp( A, b, c, x, 6, n, false );
 }
 
 /* ------------------------------------------------------------------------ */

@@ -47,9 +47,11 @@ RKFD_KERNEL( rkfd_step_kernel_vqp, false, 1, false )
 RKFD_KERNEL( rkfd_step_kernel_prof, true, 0, false )
 RKFD_KERNEL( rkfd_step_kernel_prof_pk, true, 0, true )
 RKFD_KERNEL( rkfd_step_kernel_prof_vqp, true, 1, false )
-/* the variant that carries the Volume plugin (worlds with rigid pairs under it): its geometry and simplex code want more
- * registers than three waves per SIMD leave, and its LDS block allows few instances per CU anyway */
-extern "C" __global__ void __launch_bounds__(RKFD_WAVE, 1)
+/* the variant that carries the Volume plugin (worlds with rigid pairs under it).  Built for two waves per SIMD: the phase is
+ * latency-bound (a dozen lanes at work, dependent LDS / readlane chains), so a second wave per SIMD is worth more than the
+ * ~90 vector registers it spills (measured, box on the floor / humanoid on two soles, M steps/s: one wave 2.33 / 1.49, two
+ * 4.55 / 1.68, three 4.47 / 1.41 - the humanoid's 32 KB of LDS allow five instances per CU either way) */
+extern "C" __global__ void __launch_bounds__(RKFD_WAVE, 2)
 rkfd_step_kernel_vol(rkfdDevModel m, rkfdDevState st, int first, int mode, int nsteps, int *errflag)
 {
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -57,7 +59,7 @@ rkfd_step_kernel_vol(rkfdDevModel m, rkfdDevState st, int first, int mode, int n
   if( b >= st.batch ) return;
   rkfd_instance<false, 2, false>( m, st, b, lds, mode, nsteps, errflag );
 }
-extern "C" __global__ void __launch_bounds__(RKFD_WAVE, 1)
+extern "C" __global__ void __launch_bounds__(RKFD_WAVE, 2)
 rkfd_step_kernel_prof_vol(rkfdDevModel m, rkfdDevState st, int first, int mode, int nsteps, int *errflag)
 {
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -437,7 +439,7 @@ static std::string spec_source(const rkfdDevModel &d)
     d.nlink, d.ndof, d.ncand, d.nlink_model, d.nlevel, d.nround, d.nsched, d.maxrg, d.npool, d.nfloat, d.maxact, d.nside,
     d.npurow, d.pu_alias, d.vert_rigid, d.qscr_alias, d.has_slide, d.ma_size, d.ma_packed, d.max_iter, d.solver, d.pyramid, d.anchor, d.mlcp_mfma,
     d.vol_npair, d.vol_np, d.vol_ncp, d.vol_pv, d.vol_nf,
-    d.vol_np > 0 ? 1 : 3, d.vol_np > 0 ? "2" : ( d.vert_rigid ? "1" : "0" ), d.ma_packed ? "true" : "false" );
+    d.vol_np > 0 ? 2 : 3, d.vol_np > 0 ? "2" : ( d.vert_rigid ? "1" : "0" ), d.ma_packed ? "true" : "false" );
   return std::string( buf );
 }
 /* hipRTC, bound at run time in a PRIVATE link namespace.  hipRTC finds its compiler (libamd_comgr) by soname, and
@@ -550,7 +552,7 @@ extern "C" int rkfdBatchSpecialize(rkfdBatch *b)
     hipFuncGetAttribute( &regs, HIP_FUNC_ATTRIBUTE_NUM_REGS, b->spec_fn );
     hipFuncGetAttribute( &scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, b->spec_fn );
     if( getenv( "RKFD_SPEC_DEBUG" ) ) fprintf( stderr, "rkfdBatchSpecialize: %d VGPRs, %d bytes of scratch per lane, %zu bytes of LDS\n", regs, scratch, b->lds_bytes );
-    if( scratch > ( b->dm.vol_np > 0 ? 256 : 64 ) ){      /* (the Volume variant keeps small fixed-size arrays in its private segment: 80 bytes) */
+    if( scratch > ( b->dm.vol_np > 0 ? 512 : 64 ) ){      /* (the Volume variant is built for two waves per SIMD and spills a few registers on purpose) */
       (void)hipModuleUnload( b->spec_mod ); b->spec_mod = NULL; b->spec_fn = NULL;
       SETERR( "rkfdBatchSpecialize: the compiler hipRTC resolved to in this process produced a spilling kernel (%d VGPRs, %d bytes of scratch per lane); "
               "point RKFD_ROCM_LIBDIR at the ROCm libraries this library was built with; the generic kernel stays in use", regs, scratch );

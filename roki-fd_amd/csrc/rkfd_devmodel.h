@@ -114,10 +114,10 @@ typedef struct {
 /* doubles of the Volume plugin's LDS block (rkfd_lds_carve and rkfd_devmodel.cpp) */
 /* kept from the collision phase to the solve: per pair 48, per condition 8; then the larger of the collision phase's scratch
  * (face polygons nf x pv x 3, reduction 16 nf + 16) and the solve's (Q n(n+1)/2, W n mc, S and EV mc^2 each, vectors 5n + mc + 64,
- * simplex 15 pyr ncp + 61), n = 6 np, mc = np ( 1 + ncp ) */
+ * simplex 8 pyr ncp + 6), n = 6 np, mc = np ( 1 + ncp ) */
 #define RKFD_VOL_LDS_COL(nf, pv) ( (nf)*(pv)*3 + 16*(nf) + 16 )
 #define RKFD_VOL_LDS_SOL(np, ncp, pyr) \
-  ( ( 6*(np) )*( 6*(np)+1 )/2 + 6*(np)*(np)*( 1+(ncp) ) + 2*(np)*( 1+(ncp) )*(np)*( 1+(ncp) ) + ( 30*(np) + (np)*( 1+(ncp) ) + 64 ) + ( 15*(pyr)*(ncp) + 61 ) )
+  ( ( 6*(np) )*( 6*(np)+1 )/2 + 6*(np)*(np)*( 1+(ncp) ) + 2*(np)*( 1+(ncp) )*(np)*( 1+(ncp) ) + ( 30*(np) + (np)*( 1+(ncp) ) + 64 ) + ( 8*(pyr)*(ncp) + 6 ) )
 #define RKFD_VOL_LDS_DOUBLES(np, ncp, pv, nf, pyr) \
   ( (np)*48 + (np)*(ncp)*8 + ( RKFD_VOL_LDS_COL( nf, pv ) > RKFD_VOL_LDS_SOL( np, ncp, pyr ) ? RKFD_VOL_LDS_COL( nf, pv ) : RKFD_VOL_LDS_SOL( np, ncp, pyr ) ) )
 

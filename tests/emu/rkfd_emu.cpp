@@ -47,6 +47,30 @@ double rkfd_emu_bcast(double x, int src)
   g_bar->arrive_and_wait();
   return r;
 }
+/* sum / minimum over the wave, the same in every lane; the sum in the association of the device code: the 8-lane butterfly
+ * of rkfd_emu_g8sum as lane 0 of each group sees it, then the eight groups in order */
+double rkfd_emu_wsum(double x)
+{
+  g_xd[t_lane] = x;
+  g_bar->arrive_and_wait();
+  double r = 0;
+  for( int b=0; b<64; b+=8 ){
+    auto q = [&](int k){ int base = k & ~3; double s[4]; for( int i=0; i<4; i++ ) s[i] = g_xd[b+base+i];
+                         int j = k & 3; double p1 = s[j] + s[j^1]; double p2 = s[j^2] + s[(j^2)^1]; return p1 + p2; };
+    r += q( 0 ) + q( 7 );
+  }
+  g_bar->arrive_and_wait();
+  return r;
+}
+double rkfd_emu_wmin(double x)
+{
+  g_xd[t_lane] = x;
+  g_bar->arrive_and_wait();
+  double r = g_xd[0];
+  for( int i=1; i<64; i++ ) if( g_xd[i] < r ) r = g_xd[i];
+  g_bar->arrive_and_wait();
+  return r;
+}
 unsigned long long rkfd_emu_ballot(int pred)
 {
   g_xb[t_lane] = pred ? 1ull : 0ull;

@@ -46,9 +46,9 @@ def test_kernel_fits_three_waves_per_simd_without_scratch(name):
     assert k["Occupancy"] >= 3, k
 
 
-def test_volume_kernel_does_not_spill_vector_registers():
-    """the Volume plugin's variant is built for one wave per SIMD (its LDS block allows few instances per CU anyway): no vector
-    register may be spilled; the small private segment holds its fixed-size local arrays"""
+def test_volume_kernel_resources():
+    """the Volume plugin's variant is built for two waves per SIMD on purpose (rkfd_capi.hip: latency-bound, the second wave
+    is worth more than the registers it spills); keep the spill count from growing unnoticed"""
     k = _kernels()["rkfd_step_kernel_vol"]
-    assert k["VGPRs Spill"] == 0, k
-    assert k["ScratchSize"] <= 256, k
+    assert k["Occupancy"] >= 2, k
+    assert k["VGPRs Spill"] <= 128 and k["ScratchSize"] <= 512, k
