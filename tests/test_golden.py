@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["config1", "config1b", "config2", "config3", "config4", "config5"]
+CASES = ["config1", "config1b", "config2", "config3", "config4", "config5", "config1_volume", "config4_volume"]
 
 
 def load(cfg):
@@ -36,3 +36,7 @@ def test_oracle_reproduces_golden(R, oracle_cls, cfg):
             if len(act):
                 assert (act == np.asarray(exp["active"])).all()
                 assert np.allclose(f, np.asarray(exp["f"]).reshape(-1, 3), rtol=1e-8, atol=1e-8)
+            if "wrenches" in exp:       # Volume plugin: the 6-D wrench of every pair in volumetric contact
+                got = [[p["pair"]] + p["wrench"].tolist() for p in o.volume_pairs()]
+                assert len(got) == len(exp["wrenches"]) > 0
+                assert np.allclose(np.asarray(got), np.asarray(exp["wrenches"]), rtol=1e-7, atol=1e-7)

@@ -156,3 +156,31 @@ def test_volume_arm_presses_a_box(R, oracle_cls, root):
         od, ov, oa = o.get_state()
         assert np.abs(d[b] - od).max() < 1e-8 and np.abs(v[b] - ov).max() < 1e-6, (b, np.abs(d[b] - od).max(), np.abs(v[b] - ov).max())
     assert seen > 40
+
+
+@pytest.mark.parametrize("cfg", ["config1_volume", "config4_volume"])
+def test_volume_gpu_reproduces_golden(R, cfg):
+    """the committed golden vectors of the Volume workloads (self-generated by the oracle, tests/golden/make_golden.py): states
+    after 1 and 20 steps; no oracle needed at run time"""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = json.load(open(os.path.join(root, "tests", "golden", cfg + ".json")))
+    B = len(g["instances"])
+    sc = R.scenarios.CONFIGS[cfg](batch=B)
+    b = R.Batch(sc["world"], B, device=0, max_rigid=sc["max_rigid"])
+    b.set_state(np.asarray(g["dis0"]), np.asarray(g["vel0"]))
+    b.update_init()
+    assert b.status() == 0
+    acc0 = b.get_state()[2]
+    for i, rec in enumerate(g["instances"]):
+        assert np.allclose(acc0[i], rec["acc_init"], rtol=1e-8, atol=1e-8)
+    n = 0
+    for cp in sorted(int(k) for k in g["instances"][0]["steps"]):
+        b.update(cp - n); n = cp
+        assert b.status() == 0
+        d, v, a = b.get_state()
+        for i, rec in enumerate(g["instances"]):
+            exp = rec["steps"][str(cp)]
+            assert len(exp["wrenches"]) > 0
+            assert np.allclose(d[i], exp["dis"], rtol=1e-8, atol=1e-8)
+            assert np.allclose(v[i], exp["vel"], rtol=1e-6, atol=1e-6)

@@ -27,6 +27,11 @@ python3 bench.py --workload config5 --steps 100 --warmup 20 --horizon 0 --no-cpu
 python3 bench.py --workload config4v --steps 100 --fuse 25 > gpurun_out/bench_config4v.json 2> gpurun_out/bench_config4v.log
 python3 bench.py --workload config3_26 --no-cpu-baseline > gpurun_out/bench_config3_26.json 2> gpurun_out/bench_config3_26.log
 python3 bench.py --workload config4_26 --no-cpu-baseline > gpurun_out/bench_config4_26.json 2> gpurun_out/bench_config4_26.log
+# the Volume plugin (the one the reference's drivers select): bench lines, kernel trace of the humanoid workload, phase cycles
+python3 bench.py --workload config1_volume > gpurun_out/bench_config1_volume.json 2> gpurun_out/bench_config1_volume.log
+python3 bench.py --workload config4_volume > gpurun_out/bench_config4_volume.json 2> gpurun_out/bench_config4_volume.log
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_config4_volume/trace -- python3 bench.py --workload config4_volume --no-cpu-baseline > gpurun_out/prof_${TAG}_config4_volume.bench.json 2> gpurun_out/prof_${TAG}_config4_volume.trace.log || true
+WARM=10 python3 tools/prof_phases.py config1_volume config4_volume > gpurun_out/phase_cycles_volume.txt 2>&1
 echo "benches done"
 tools/ubench/pgs 11 > gpurun_out/ubench_pgs.txt 2>&1
 python3 tools/parity_report.py 1000 16 > gpurun_out/parity_report.txt 2>&1

@@ -70,3 +70,16 @@ for w in ("config5", "config4v"):
     line = open(f"gpurun_out/bench_{w}.json").read().strip().splitlines()[-1]
     open(f"profiles/{tag}_bench_{w}.json", "w").write(line + "\n"); d = json.loads(line)
     print(w, "%.3g steps/s" % d["value"], "ms %.3f" % d["ms_per_step"], "cpu", d.get("cpu_baseline", {}).get("value"), d.get("cpu_baseline_all_cores", {}).get("value"))
+
+# Volume plugin
+for w in ("config1_volume", "config4_volume"):
+    try:
+        shutil.copy(f"gpurun_out/bench_{w}.json", f"profiles/{tag}_bench_{w}.json")
+    except OSError as e:
+        print("missing", e)
+try:
+    ks = sorted(glob.glob(f"gpurun_out/prof_{tag}_config4_volume/trace/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)[-1]
+    shutil.copy(ks, f"profiles/{tag}_config4_volume_kernel_stats.csv")
+    shutil.copy("gpurun_out/phase_cycles_volume.txt", f"profiles/{tag}_phase_cycles_volume.txt")
+except (OSError, IndexError) as e:
+    print("missing", e)
