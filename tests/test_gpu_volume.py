@@ -184,3 +184,40 @@ def test_volume_gpu_reproduces_golden(R, cfg):
             assert len(exp["wrenches"]) > 0
             assert np.allclose(d[i], exp["dis"], rtol=1e-8, atol=1e-8)
             assert np.allclose(v[i], exp["vel"], rtol=1e-6, atol=1e-6)
+
+
+def test_volume_rolling_cylinder(R, oracle_cls):
+    """a 16-sided cylinder (models/cylinder.ztk: a curved primitive tessellated by the reader, 18 faces) pushed along the floor
+    with half the spin of rolling: it slips (kinetic friction), then rolls from facet to facet (static friction, v = omega r
+    within the polygon's bumps).  300 steps of 4 cylinders, every step started from the oracle's state."""
+    M = R.scenarios.MODELS
+    w = R.World(solver=R.SOLVER_VOLUME)
+    w.contact_info(os.path.join(M, "contactinfo.ztk"))
+    w.reg_file(os.path.join(M, "cylinder.ztk")); w.reg_file(os.path.join(M, "floor.ztk"))
+    B = 4
+    dis = np.zeros((B, 6)); vel = np.zeros((B, 6))
+    for b in range(B):
+        dis[b, 2] = 0.04 - 1e-5; dis[b, 5] = 0.3 * b; vel[b, 0] = 0.3 * np.cos(0.3 * b); vel[b, 1] = 0.3 * np.sin(0.3 * b)
+        vel[b, 3] = -0.5 * 7.5 * np.sin(0.3 * b); vel[b, 4] = 0.5 * 7.5 * np.cos(0.3 * b)
+    bt = R.Batch(w, B, max_rigid=1)
+    os_ = []
+    for b in range(B):
+        o = oracle_cls(w.model); o.set_state(dis[b], vel[b]); o.update_init(); os_.append(o)
+    errs = []; types = set()
+    for k in range(300):
+        sd = np.array([o.get_state()[0] for o in os_]); sv = np.array([o.get_state()[1] for o in os_])
+        bt.set_state(sd, sv); bt.update_init(); bt.update(1)
+        assert bt.status() == 0, R.last_error()
+        d, v, a = bt.get_state()
+        for b, o in enumerate(os_):
+            assert o.update() == 0
+            od, ov, oa = o.get_state()
+            errs.append(max(np.abs(d[b] - od).max(), np.abs(v[b] - ov).max(), np.abs(a[b] - oa).max() / max(1.0, np.abs(oa).max())))
+            for p in o.volume_pairs():
+                if np.abs(p["wrench"]).max() > 0:
+                    types.add(p["type"])
+    errs = np.array(errs)
+    assert types == {R.SF, R.KF}
+    o = os_[0]; v = o.get_state()[1]
+    assert abs(v[0] - v[4] * 0.04) < 0.02 * abs(v[0]) + 1e-3            # rolling
+    assert np.median(errs) < 1e-11 and errs.max() < 1e-6, (np.median(errs), errs.max())
