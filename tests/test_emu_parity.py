@@ -1,6 +1,8 @@
 """Kernel LOGIC check without a GPU: the device code of roki-fd_amd/csrc/rkfd_device.h run under
 the 64-thread lane emulator (tests/emu) against the oracle.  The GPU tier repeats this on real
 hardware through the C ABI (tests/test_gpu_parity.py)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -281,3 +283,24 @@ def test_emulated_volume_humanoid(R, oracle_cls):
     assert len(o.volume_pairs()) == 2
     d, v, a = eb.get_state(); od, ov, oa = o.get_state()
     assert np.abs(d[0] - od).max() < 1e-12 and np.abs(v[0] - ov).max() < 1e-10 and np.abs(a[0] - oa).max() / np.abs(oa).max() < 1e-8
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/example/model"), reason="reference checkout not present (it never is on the GPU box)")
+def test_emulated_reference_arm_box_world_under_volume(R, oracle_cls):
+    """the world of the reference's arm_box_test.c as that driver sets it up - arm_2DoF.ztk (boxes as polyhedra, two cylinders,
+    a DC motor), box.ztk, floor.ztk read where they lie, rkFDSetSolver( &fd, Volume ): 11 rigid pairs, cylinder - box pairs with
+    40 faces; the device tables build and two steps agree with the oracle"""
+    M = "/root/reference/example/model"
+    w = R.World(solver=R.SOLVER_VOLUME)
+    w.contact_info(os.path.join(M, "contactinfo.ztk"))
+    w.reg_file(os.path.join(M, "arm_2DoF.ztk")); b = w.reg_file(os.path.join(M, "box.ztk")); w.reg_file(os.path.join(M, "floor.ztk"))
+    m = w.model.contents
+    assert m.npair == 11
+    dis = np.zeros(m.ndof); off = w.dof_offset(b); dis[off:off + 3] = (0.3, 0.0, 0.05 - 1e-5)
+    eb = EmuBatch(w, 1, max_rigid=6)
+    eb.set_state(dis[None, :], np.zeros((1, m.ndof))); eb.update_init(); eb.update(2)
+    assert eb.status() == 0
+    o = oracle_cls(w.model); o.set_state(dis, np.zeros(m.ndof)); o.update_init(); o.update_n(2)
+    assert len(o.volume_pairs()) >= 1
+    d, v, a = eb.get_state(); od, ov, oa = o.get_state()
+    assert np.abs(d[0] - od).max() < 1e-12 and np.abs(v[0] - ov).max() < 1e-10 and np.abs(a[0] - oa).max() < 1e-8

@@ -104,9 +104,8 @@ def test_reference_drivers_compile_and_link_unmodified(R, tmp_path):
     """the reference's five example drivers (read where they lie, not copied) compile with -Werror=implicit-function-declaration
     against include/roki_fd/roki_fd.h and link against librkfd_amd.so as they are - #include <roki_fd/roki_fd.h>,
     rkFDODE2Assign( &fd, Regular ), rkFDSetSolver( &fd, Volume ), zVecFreeAtOnce, rkCDPairChainUnreg and all.
-    (They select the Volume plugin, which has a device path for pairs of convex shapes: the boxdrop drivers run as they are;
-    the ones that load mighty.ztk with its non-convex body meshes are refused by rkFDUpdateInit with a message and run under
-    their commented-out rkFDSetSolver( &fd, MLCP ) line.)"""
+    (They select the Volume plugin, which has a device path for pairs of convex shapes: the worlds of the boxdrop and arm_box
+    drivers are within its limits; arm_wall_test loads wall.ztk, whose breakable-float joint is refused with a message.)"""
     import glob
     import subprocess
     root = os.path.join(os.path.dirname(__file__), "..")
