@@ -649,70 +649,79 @@ RKFD_DEV void rkfd_vol_qp(const rkfdDevModel &m, const rkfdLds &L, int n, int mc
 
 /* ------------------------------------------------------------------------ */
 /* zLPSolveSimplex / zLPFeasibleBase as restated in the oracle (vol_lp): min c'x s.t. Ax = b, x >= 0; two-phase tableau,
- * entering column by the most negative reduced cost (Bland's rule after 64 pivots).  The tableau lives in REGISTERS: lane = column (columns lane and lane + 64: n + mr + 1 <= 128), six rows and the
- * reduced cost per column; the pivot column and the right-hand side reach every lane through v_readlane, the ratio test is
- * scalar, a pivot is ~40 vector instructions - no LDS traffic and no barrier inside the iteration.  A (mr x n, row-major),
- * b (mr), c (n; phase 2 only when has_c) are read from LDS once; the result x (n) is written there. */
+ * entering column by the most negative reduced cost (Bland's rule after 64 pivots).  The tableau lives in REGISTERS: lane =
+ * column (columns lane, lane + 64, lane + 128: n + mr + 1 <= 192), six rows and the reduced cost per column; the pivot column and
+ * the right-hand side reach every lane through v_readlane, the ratio test is scalar, a pivot is a few dozen vector
+ * instructions - no LDS traffic and no barrier inside the iteration.  A (mr x n, row-major), b (mr), c (n; phase 2 only when
+ * has_c) are read from LDS once; the result x (n) is written there. */
 #define RKFD_LP_EPS 1e-10
-#define RKFD_LP_SEL(t0, t1, hi) ( (hi) ? (t1) : (t0) )
-RKFD_DEV int rkfd_vol_lp(const double *A, const double *b, const double *c, double *x, int mr, int n, bool has_c)
+#define RKFD_LP_SEL(t, i, h) ( (h) == 0 ? t[0][i] : ( ( RKFD_LP_NS < 3 || (h) == 1 ) ? t[1][i] : t[RKFD_LP_NS-1][i] ) )
+#define RKFD_LP_SELC(cc, h) ( (h) == 0 ? cc[0] : ( ( RKFD_LP_NS < 3 || (h) == 1 ) ? cc[1] : cc[RKFD_LP_NS-1] ) )
+/* RKFD_LP_NS = column slots per lane: 2 (up to 128 columns: every pair of boxes) or 3 (up to 192: round shapes with up to 16
+ * contact-plane conditions) */
+template<int RKFD_LP_NS> RKFD_DEV int rkfd_vol_lp_n(const double *A, const double *b, const double *c, double *x, int mr, int n, bool has_c)
 {
   const int lane = LANE();
   const int nt = n + mr;                       /* column of the right-hand side */
   const int rl = nt & 63, rh = nt >> 6;
-  double T0[6], T1[6], c0 = 0, c1 = 0;
+  double T[RKFD_LP_NS][6], cc[RKFD_LP_NS];
   int bas[6];
   double scale = 0;
 #pragma unroll
   for( int i=0; i<6; i++ ){
-    T0[i] = 0; T1[i] = 0; bas[i] = n+i;
-    if( i < mr ){
-      const double bi = b[i], sg = bi < 0 ? -1.0 : 1.0;
-      const int j0 = lane, j1 = lane + 64;
-      T0[i] = j0 < n ? sg*A[n*i+j0] : ( j0 < nt ? ( j0-n == i ? 1.0 : 0.0 ) : ( j0 == nt ? sg*bi : 0.0 ) );
-      T1[i] = j1 < n ? sg*A[n*i+j1] : ( j1 < nt ? ( j1-n == i ? 1.0 : 0.0 ) : ( j1 == nt ? sg*bi : 0.0 ) );
-      if( fabs( bi ) > scale ) scale = fabs( bi );
+    bas[i] = n+i;
+    const double bi = i < mr ? b[i] : 0.0, sg = bi < 0 ? -1.0 : 1.0;
+#pragma unroll
+    for( int h=0; h<RKFD_LP_NS; h++ ){
+      const int j = lane + 64*h;
+      T[h][i] = i < mr ? ( j < n ? sg*A[n*i+j] : ( j < nt ? ( j-n == i ? 1.0 : 0.0 ) : ( j == nt ? sg*bi : 0.0 ) ) ) : 0.0;
     }
+    if( fabs( bi ) > scale ) scale = fabs( bi );
   }
+#pragma unroll
+  for( int h=0; h<RKFD_LP_NS; h++ ) cc[h] = 0;
   int ok = 1;
   for( int ph=1; ph<=2 && ok; ph++ ){
     const int ncol = ph == 1 ? nt : n;
     if( ph == 2 && !has_c ) break;
-    {
-      /* reduced costs of this phase */
-      const int j0 = lane, j1 = lane + 64;
-      double r0 = ph == 1 ? ( j0 >= n && j0 < nt ? 1.0 : 0.0 ) : ( j0 < n ? c[j0] : 0.0 );
-      double r1 = ph == 1 ? ( j1 >= n && j1 < nt ? 1.0 : 0.0 ) : ( j1 < n ? c[j1] : 0.0 );
+    /* reduced costs of this phase */
+#pragma unroll
+    for( int h=0; h<RKFD_LP_NS; h++ ){
+      const int j = lane + 64*h;
+      double r = ph == 1 ? ( j >= n && j < nt ? 1.0 : 0.0 ) : ( j < n ? c[j] : 0.0 );
 #pragma unroll
       for( int i=0; i<6; i++ )
         if( i < mr ){
           const double cb = ph == 1 ? ( bas[i] >= n ? 1.0 : 0.0 ) : ( bas[i] < n ? c[bas[i]] : 0.0 );
-          r0 -= cb*T0[i]; r1 -= cb*T1[i];
+          r -= cb*T[h][i];
         }
-      c0 = r0; c1 = r1;
+      cc[h] = r;
     }
     int it;
     for( it=0; it<10000; it++ ){
       int col = -1;
       {
         /* entering column: the most negative reduced cost, lowest index among equals; Bland's rule after 64 pivots (as the oracle) */
-        const bool v0 = lane < ncol && c0 < -RKFD_LP_EPS, v1 = lane + 64 < ncol && c1 < -RKFD_LP_EPS;
+        bool v[RKFD_LP_NS];
+        double lm = 0;
+#pragma unroll
+        for( int h=0; h<RKFD_LP_NS; h++ ){ v[h] = lane + 64*h < ncol && cc[h] < -RKFD_LP_EPS; if( v[h] ) lm = fmin( lm, cc[h] ); }
         double cm = 0;
-        if( it < 64 ) cm = WMIN( fmin( v0 ? c0 : 0.0, v1 ? c1 : 0.0 ) );
-        const unsigned long long m0 = BALLOT( v0 && ( it >= 64 || c0 == cm ) );
-        if( m0 ) col = __builtin_ctzll( m0 );
-        else {
-          const unsigned long long m1 = BALLOT( v1 && ( it >= 64 || c1 == cm ) );
-          if( m1 ) col = 64 + __builtin_ctzll( m1 );
-        }
+        if( it < 64 ) cm = WMIN( lm );
+#pragma unroll
+        for( int h=0; h<RKFD_LP_NS; h++ )
+          if( col < 0 && 64*h < ncol ){
+            const unsigned long long mk = BALLOT( v[h] && ( it >= 64 || cc[h] == cm ) );
+            if( mk ) col = 64*h + __builtin_ctzll( mk );
+          }
       }
       if( col < 0 ) break;
       const int cl = col & 63, ch = col >> 6;
       double pc[6], rr[6];
 #pragma unroll
       for( int i=0; i<6; i++ ){
-        pc[i] = BCAST( RKFD_LP_SEL( T0[i], T1[i], ch ), cl );
-        rr[i] = BCAST( RKFD_LP_SEL( T0[i], T1[i], rh ), rl );
+        pc[i] = BCAST( RKFD_LP_SEL( T, i, ch ), cl );
+        rr[i] = BCAST( RKFD_LP_SEL( T, i, rh ), rl );
       }
       int row = -1, brow = 0; double best = 0;
 #pragma unroll
@@ -723,17 +732,25 @@ RKFD_DEV int rkfd_vol_lp(const double *A, const double *b, const double *c, doub
         }
       if( row < 0 ){ ok = 0; break; }
       {
-        double pv = 0, t0 = 0, t1 = 0;
+        double pv = 0;
 #pragma unroll
-        for( int i=0; i<6; i++ ) if( i == row ){ pv = 1.0/pc[i]; t0 = T0[i]; t1 = T1[i]; }
-        t0 *= pv; t1 *= pv;
-        const double fc = BCAST( RKFD_LP_SEL( c0, c1, ch ), cl );
+        for( int i=0; i<6; i++ ) if( i == row ) pv = 1.0/pc[i];
+        const double fc = BCAST( RKFD_LP_SELC( cc, ch ), cl );
 #pragma unroll
-        for( int i=0; i<6; i++ ){
-          if( i == row ){ T0[i] = t0; T1[i] = t1; bas[i] = col; }
-          else if( i < mr && pc[i] != 0.0 ){ T0[i] -= pc[i]*t0; T1[i] -= pc[i]*t1; }
+        for( int h=0; h<RKFD_LP_NS; h++ ){
+          double t = 0;
+#pragma unroll
+          for( int i=0; i<6; i++ ) if( i == row ) t = T[h][i];
+          t *= pv;
+#pragma unroll
+          for( int i=0; i<6; i++ ){
+            if( i == row ) T[h][i] = t;
+            else if( i < mr && pc[i] != 0.0 ) T[h][i] -= pc[i]*t;
+          }
+          cc[h] -= fc*t;
         }
-        c0 -= fc*t0; c1 -= fc*t1;
+#pragma unroll
+        for( int i=0; i<6; i++ ) if( i == row ) bas[i] = col;
       }
     }
     if( it == 10000 ) ok = 0;
@@ -741,7 +758,7 @@ RKFD_DEV int rkfd_vol_lp(const double *A, const double *b, const double *c, doub
       double art = 0;
 #pragma unroll
       for( int i=0; i<6; i++ ){
-        const double ri = BCAST( RKFD_LP_SEL( T0[i], T1[i], rh ), rl );
+        const double ri = BCAST( RKFD_LP_SEL( T, i, rh ), rl );
         if( i < mr && bas[i] >= n ) art += ri;
       }
       if( art > 1e-9*( 1.0 + scale ) ) ok = 0;
@@ -752,24 +769,28 @@ RKFD_DEV int rkfd_vol_lp(const double *A, const double *b, const double *c, doub
           const bool need = i < mr && bas[i] >= n;       /* (wave-uniform) */
           int jc = -1;
           if( need ){
-            const unsigned long long m0 = BALLOT( need && lane < n && fabs( T0[i] ) > 1e-9 );
-            if( m0 ) jc = __builtin_ctzll( m0 );
-            else {
-              const unsigned long long m1 = BALLOT( need && lane + 64 < n && fabs( T1[i] ) > 1e-9 );
-              if( m1 ) jc = 64 + __builtin_ctzll( m1 );
-            }
+#pragma unroll
+            for( int h=0; h<RKFD_LP_NS; h++ )
+              if( jc < 0 && 64*h < n ){
+                const unsigned long long mk = BALLOT( lane + 64*h < n && fabs( T[h][i] ) > 1e-9 );
+                if( mk ) jc = 64*h + __builtin_ctzll( mk );
+              }
           }
           if( jc >= 0 ){
             double pc[6];
 #pragma unroll
-            for( int k=0; k<6; k++ ) pc[k] = BCAST( RKFD_LP_SEL( T0[k], T1[k], jc >= 64 ), jc & 63 );
+            for( int k=0; k<6; k++ ) pc[k] = BCAST( RKFD_LP_SEL( T, k, jc >> 6 ), jc & 63 );
             const double pv = 1.0/pc[i];
-            const double t0 = T0[i]*pv, t1 = T1[i]*pv;
 #pragma unroll
-            for( int k=0; k<6; k++ ){
-              if( k == i ){ T0[k] = t0; T1[k] = t1; bas[k] = jc; }
-              else if( k < mr && pc[k] != 0.0 ){ T0[k] -= pc[k]*t0; T1[k] -= pc[k]*t1; }
+            for( int h=0; h<RKFD_LP_NS; h++ ){
+              const double t = T[h][i]*pv;
+#pragma unroll
+              for( int k=0; k<6; k++ ){
+                if( k == i ) T[h][k] = t;
+                else if( k < mr && pc[k] != 0.0 ) T[h][k] -= pc[k]*t;
+              }
             }
+            bas[i] = jc;
           }
         }
       }
@@ -780,12 +801,18 @@ RKFD_DEV int rkfd_vol_lp(const double *A, const double *b, const double *c, doub
     SYNC();
 #pragma unroll
     for( int i=0; i<6; i++ ){
-      const double ri = BCAST( RKFD_LP_SEL( T0[i], T1[i], rh ), rl );
+      const double ri = BCAST( RKFD_LP_SEL( T, i, rh ), rl );
       if( i < mr && bas[i] < n && lane == 0 ) x[bas[i]] = ri;
     }
   }
   SYNC();
   return ok;
+}
+RKFD_DEV int rkfd_vol_lp(const double *A, const double *b, const double *c, double *x, int mr, int n, bool has_c, int maxcol)
+{
+  /* (maxcol: the most columns this world's LPs can have - a property of the world, so the branch is the same for every call) */
+  if( maxcol <= 128 ) return rkfd_vol_lp_n<2>( A, b, c, x, mr, n, has_c );
+  return rkfd_vol_lp_n<3>( A, b, c, x, mr, n, has_c );
 }
 
 /* ------------------------------------------------------------------------ */
@@ -818,7 +845,7 @@ RKFD_DEV void rkfd_vol_kinetic(const rkfdDevModel &m, const rkfdLds &L, int k, i
   }
   if( lane == 0 ){ b[0] = w[0]; b[1] = w[4]; b[2] = w[5]; }
   SYNC();
-  if( !rkfd_vol_lp( A, b, c, x, 3, n, true ) ){
+  if( !rkfd_vol_lp( A, b, c, x, 3, n, true, PN + 7 ) ){
     if( lane < n ){
       double wn[2];
 #pragma unroll
@@ -826,7 +853,7 @@ RKFD_DEV void rkfd_vol_kinetic(const rkfdDevModel &m, const rkfdLds &L, int k, i
       c[lane] += wn[0]*r0 - wn[1]*r1;
     }
     SYNC();
-    rkfd_vol_lp( A, b, c, x, 1, n, true );
+    rkfd_vol_lp( A, b, c, x, 1, n, true, PN + 7 );
   }
   /* _rkFDSolverModifyWrenchKineticTotalWrench (:814-828): lane order = list order */
   double *red = A;       /* (the constraint matrix is dead) */
@@ -860,7 +887,7 @@ RKFD_DEV int rkfd_vol_static(const rkfdDevModel &m, const rkfdLds &L, int k, int
   }
   if( lane == 0 ){ b[0] = w[0]; b[1] = w[4]; b[2] = w[5]; b[3] = w[1]; b[4] = w[2]; b[5] = w[3]; }
   SYNC();
-  return rkfd_vol_lp( A, b, c, x, 6, n, false );
+  return rkfd_vol_lp( A, b, c, x, 6, n, false, PN + 7 );
 }
 
 /* ------------------------------------------------------------------------ */

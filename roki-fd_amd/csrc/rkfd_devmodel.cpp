@@ -386,8 +386,15 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
       vol_np = max_rigid > 0 ? ( max_rigid < vol_npair ? max_rigid : vol_npair ) : 0;
       if( vol_np > 10 ) vol_np = 10;
       if( vol_np > 0 ){
-        vol_ncp = maxfaces < 8 ? maxfaces : 8;      /* (the contact polygon of two boxes has at most eight edges; more is reported at run time, status 2) */
-        while( vol_ncp > 4 && vol_np*( 1+vol_ncp ) > RKFD_WAVE ) vol_ncp--;
+        /* contact-plane conditions per pair: the contact polygon of two boxes (12 faces together) has at most eight edges;
+         * rounder shapes (a cylinder on its end: one edge per side, one more when it tilts) get one per face of the pair - as far
+         * as the simplex's 192 register-resident columns (pyramid x conditions + 7), the QP's 64 constraints and the LDS of the
+         * solve's workspace (24 KB) allow: 23 for one pair of a 16-sided cylinder and a box.
+         * More at run time is reported (status 2). */
+        const int pyr = m->pyramid > 0 ? m->pyramid : 8;
+        vol_ncp = maxfaces <= 12 ? ( maxfaces < 8 ? maxfaces : 8 ) : maxfaces;
+        while( vol_ncp > 4 && ( vol_np*( 1+vol_ncp ) > RKFD_WAVE || pyr*vol_ncp + 7 > 192 ) ) vol_ncp--;
+        while( vol_ncp > 8 && RKFD_VOL_LDS_SOL( vol_np, vol_ncp, pyr ) > 3072 ) vol_ncp--;
         if( vol_np*( 1+vol_ncp ) > RKFD_WAVE ) FAIL( "Volume plugin: %d pairs x ( 1 + %d conditions ) exceed 64 constraints", vol_np, vol_ncp );
         if( vol_pv < 10 ) vol_pv = 10;
         vol_nf = maxfaces;

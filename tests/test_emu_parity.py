@@ -304,3 +304,20 @@ def test_emulated_reference_arm_box_world_under_volume(R, oracle_cls):
     assert len(o.volume_pairs()) >= 1
     d, v, a = eb.get_state(); od, ov, oa = o.get_state()
     assert np.abs(d[0] - od).max() < 1e-12 and np.abs(v[0] - ov).max() < 1e-10 and np.abs(a[0] - oa).max() < 1e-8
+
+
+def test_emulated_volume_sixteen_conditions(R, oracle_cls):
+    """a 16-sided cylinder on its end: 16 contact-plane conditions, the static-friction LP with three columns per lane"""
+    M = R.scenarios.MODELS
+    w = R.World(solver=R.SOLVER_VOLUME)
+    w.contact_info(os.path.join(M, "contactinfo.ztk"))
+    w.reg_file(os.path.join(M, "cylinder.ztk")); w.reg_file(os.path.join(M, "floor.ztk"))
+    dis = np.zeros(6); dis[3] = np.pi / 2; dis[2] = 0.06 - 1e-5
+    vel = np.zeros(6); vel[0] = 0.05
+    eb = EmuBatch(w, 1, max_rigid=1); eb.set_state(dis[None, :], vel[None, :]); eb.update_init(); eb.update(2)
+    assert eb.status() == 0
+    o = oracle_cls(w.model); o.set_state(dis, vel); o.update_init()
+    assert len(o.volume_pairs()[0]["planes"]) == 16
+    o.update_n(2)
+    d, v, a = eb.get_state(); od, ov, oa = o.get_state()
+    assert np.abs(d[0] - od).max() < 1e-12 and np.abs(v[0] - ov).max() < 1e-10 and np.abs(a[0] - oa).max() < 1e-7

@@ -227,3 +227,37 @@ def test_volume_rolling_cylinder(R, oracle_cls):
     flipped = int((errs > 1e-6).sum())
     assert flipped <= len(errs) // 100, flipped
     assert np.median(errs) < 1e-11 and np.sort(errs)[len(errs) - 1 - flipped] < 1e-6, (np.median(errs), flipped)
+
+
+def test_volume_cylinder_on_its_end_sixteen_conditions(R, oracle_cls):
+    """the 16-sided cylinder standing on its end: a contact polygon with 16 edges (17 QP constraints, a static-friction LP with
+    128 + 6 columns: the three-columns-per-lane tableau); at rest, pushed (it tilts onto an edge of its end face) and twisted.
+    100 steps, every step from the oracle's state; knife-edge steps are counted as in the rolling test."""
+    M = R.scenarios.MODELS
+    w = R.World(solver=R.SOLVER_VOLUME)
+    w.contact_info(os.path.join(M, "contactinfo.ztk"))
+    w.reg_file(os.path.join(M, "cylinder.ztk")); w.reg_file(os.path.join(M, "floor.ztk"))
+    B = 3
+    dis = np.zeros((B, 6)); vel = np.zeros((B, 6))
+    dis[:, 3] = np.pi / 2; dis[:, 2] = 0.06 - 1e-5
+    vel[1, 0] = 0.2; vel[2, 5] = 3.0
+    bt = R.Batch(w, B, max_rigid=1)
+    os_ = []
+    for b in range(B):
+        o = oracle_cls(w.model); o.set_state(dis[b], vel[b]); o.update_init(); os_.append(o)
+        assert len(o.volume_pairs()[0]["planes"]) == 16
+    errs = []; n16 = 0
+    for k in range(100):
+        sd = np.array([o.get_state()[0] for o in os_]); sv = np.array([o.get_state()[1] for o in os_])
+        bt.set_state(sd, sv); bt.update_init(); bt.update(1)
+        assert bt.status() == 0, R.last_error()
+        d, v, a = bt.get_state()
+        for b, o in enumerate(os_):
+            assert o.update() == 0
+            od, ov, oa = o.get_state()
+            errs.append(max(np.abs(d[b] - od).max(), np.abs(v[b] - ov).max(), np.abs(a[b] - oa).max() / max(1.0, np.abs(oa).max())))
+            n16 += any(len(p["planes"]) >= 16 for p in o.volume_pairs())
+    errs = np.array(errs)
+    flipped = int((errs > 1e-6).sum())
+    assert n16 > 100 and flipped <= 3, (n16, flipped)
+    assert np.median(errs) < 1e-10 and np.sort(errs)[len(errs) - 1 - flipped] < 1e-6, (np.median(errs), flipped)
