@@ -57,7 +57,7 @@ RKFD_DEV int d_vol_clip(double *P, int n, int cap, const double *pl, double d)
     if( i+1 < n ){ n0 = P[3*i+3]; n1 = P[3*i+4]; n2 = P[3*i+5]; sn = pl[0]*n0 + pl[1]*n1 + pl[2]*n2 - d; }
     if( sc <= 0 && k < cap ){ P[3*k] = c0; P[3*k+1] = c1; P[3*k+2] = c2; k++; }
     if( ( ( sc < 0 && sn > 0 ) || ( sc > 0 && sn < 0 ) ) && k < cap ){
-      const double t = sc/( sc - sn );
+      const double t = sc*RKFD_RCP( sc - sn );
       P[3*k] = c0 + t*( n0-c0 ); P[3*k+1] = c1 + t*( n1-c1 ); P[3*k+2] = c2 + t*( n2-c2 );
       k++;
     }
@@ -98,7 +98,7 @@ RKFD_DEV void d_vol_inner(const double *p1, const double *p2, double h1, double 
   if( fabs( h1 ) < RKFD_DEV_TOL ){ pp[0] = p1[0]; pp[1] = p1[1]; pp[2] = p1[2]; return; }
   if( fabs( h2 ) < RKFD_DEV_TOL ){ pp[0] = p2[0]; pp[1] = p2[1]; pp[2] = p2[2]; return; }
   if( fabs( h2 - h1 ) < RKFD_DEV_TOL ){ pp[0] = 0.5*( p1[0]+p2[0] ); pp[1] = 0.5*( p1[1]+p2[1] ); pp[2] = 0.5*( p1[2]+p2[2] ); return; }
-  const double a = h2/( h2 - h1 ), b = h1/( h1 - h2 );
+  const double a = h2*RKFD_RCP( h2 - h1 ), b = h1*RKFD_RCP( h1 - h2 );
   pp[0] = a*p1[0]; pp[1] = a*p1[1]; pp[2] = a*p1[2];
   pp[0] += b*p2[0]; pp[1] += b*p2[1]; pp[2] += b*p2[2];
 }
@@ -678,123 +678,117 @@ template<int RKFD_LP_NS> RKFD_DEV int rkfd_vol_lp_n(const double *A, const doubl
     }
     if( fabs( bi ) > scale ) scale = fabs( bi );
   }
+  /* one loop, one copy of the pivot code.  mode 1: iterations of phase 1 (cost = sum of the artificials); mode 2: artificials left
+   * in the base at zero are pivoted out on the first structural column with an entry in their row; mode 3: iterations of phase 2 */
+  int ok = 1, mode = 1, it = 0, dstart = 0;
+  bool newcost = true;
+  for(;;){
+    if( newcost ){
+      /* reduced costs of the phase that starts */
 #pragma unroll
-  for( int h=0; h<RKFD_LP_NS; h++ ) cc[h] = 0;
-  int ok = 1;
-  for( int ph=1; ph<=2 && ok; ph++ ){
-    const int ncol = ph == 1 ? nt : n;
-    if( ph == 2 && !has_c ) break;
-    /* reduced costs of this phase */
+      for( int h=0; h<RKFD_LP_NS; h++ ){
+        const int j = lane + 64*h;
+        double r = mode == 1 ? ( j >= n && j < nt ? 1.0 : 0.0 ) : ( j < n ? c[j] : 0.0 );
 #pragma unroll
-    for( int h=0; h<RKFD_LP_NS; h++ ){
-      const int j = lane + 64*h;
-      double r = ph == 1 ? ( j >= n && j < nt ? 1.0 : 0.0 ) : ( j < n ? c[j] : 0.0 );
-#pragma unroll
-      for( int i=0; i<6; i++ )
-        if( i < mr ){
-          const double cb = ph == 1 ? ( bas[i] >= n ? 1.0 : 0.0 ) : ( bas[i] < n ? c[bas[i]] : 0.0 );
-          r -= cb*T[h][i];
-        }
-      cc[h] = r;
-    }
-    int it;
-    for( it=0; it<10000; it++ ){
-      int col = -1;
-      {
-        /* entering column: the most negative reduced cost, lowest index among equals; Bland's rule after 64 pivots (as the oracle) */
-        bool v[RKFD_LP_NS];
-        double lm = 0;
-#pragma unroll
-        for( int h=0; h<RKFD_LP_NS; h++ ){ v[h] = lane + 64*h < ncol && cc[h] < -RKFD_LP_EPS; if( v[h] ) lm = fmin( lm, cc[h] ); }
-        double cm = 0;
-        if( it < 64 ) cm = WMIN( lm );
-#pragma unroll
-        for( int h=0; h<RKFD_LP_NS; h++ )
-          if( col < 0 && 64*h < ncol ){
-            const unsigned long long mk = BALLOT( v[h] && ( it >= 64 || cc[h] == cm ) );
-            if( mk ) col = 64*h + __builtin_ctzll( mk );
+        for( int i=0; i<6; i++ )
+          if( i < mr ){
+            const double cb = mode == 1 ? ( bas[i] >= n ? 1.0 : 0.0 ) : ( bas[i] < n ? c[bas[i]] : 0.0 );
+            r -= cb*T[h][i];
           }
+        cc[h] = r;
       }
-      if( col < 0 ) break;
-      const int cl = col & 63, ch = col >> 6;
-      double pc[6], rr[6];
+      newcost = false; it = 0;
+    }
+    int col = -1, row = -1;
+    if( mode != 2 ){
+      if( it >= 10000 ){ ok = 0; break; }
+      const int ncol = mode == 1 ? nt : n;
+      /* entering column: the most negative reduced cost, lowest index among equals; Bland's rule after 64 pivots (as the oracle) */
+      bool v[RKFD_LP_NS];
+      double lm = 0;
 #pragma unroll
-      for( int i=0; i<6; i++ ){
-        pc[i] = BCAST( RKFD_LP_SEL( T, i, ch ), cl );
-        rr[i] = BCAST( RKFD_LP_SEL( T, i, rh ), rl );
+      for( int h=0; h<RKFD_LP_NS; h++ ){ v[h] = lane + 64*h < ncol && cc[h] < -RKFD_LP_EPS; if( v[h] ) lm = fmin( lm, cc[h] ); }
+      double cm = 0;
+      if( it < 64 ) cm = WMIN( lm );
+#pragma unroll
+      for( int h=0; h<RKFD_LP_NS; h++ )
+        if( col < 0 && 64*h < ncol ){
+          const unsigned long long mk = BALLOT( v[h] && ( it >= 64 || cc[h] == cm ) );
+          if( mk ) col = 64*h + __builtin_ctzll( mk );
+        }
+      if( col < 0 ){
+        if( mode == 3 ) break;                      /* optimal */
+        /* end of phase 1: feasible when the artificials are (numerically) zero */
+        double art = 0;
+#pragma unroll
+        for( int i=0; i<6; i++ ){
+          const double ri = BCAST( RKFD_LP_SEL( T, i, rh ), rl );
+          if( i < mr && bas[i] >= n ) art += ri;
+        }
+        if( art > 1e-9*( 1.0 + scale ) ){ ok = 0; break; }
+        mode = 2; dstart = 0;
+        continue;
       }
-      int row = -1, brow = 0; double best = 0;
+    } else {
+#pragma unroll
+      for( int i=0; i<6; i++ ) if( row < 0 && i >= dstart && i < mr && bas[i] >= n ) row = i;
+      if( row < 0 ){
+        if( !has_c ) break;
+        mode = 3; newcost = true;
+        continue;
+      }
+      dstart = row + 1;
+#pragma unroll
+      for( int h=0; h<RKFD_LP_NS; h++ )
+        if( col < 0 && 64*h < n ){
+          double tr = 0;
+#pragma unroll
+          for( int i=0; i<6; i++ ) if( i == row ) tr = T[h][i];
+          const unsigned long long mk = BALLOT( lane + 64*h < n && fabs( tr ) > 1e-9 );
+          if( mk ) col = 64*h + __builtin_ctzll( mk );
+        }
+      if( col < 0 ) continue;                        /* a redundant row: the artificial stays, at zero */
+    }
+    const int cl = col & 63, ch = col >> 6;
+    double pc[6], rr[6];
+#pragma unroll
+    for( int i=0; i<6; i++ ){
+      pc[i] = BCAST( RKFD_LP_SEL( T, i, ch ), cl );
+      rr[i] = BCAST( RKFD_LP_SEL( T, i, rh ), rl );
+    }
+    if( mode != 2 ){
+      /* leaving row: minimum ratio, lowest basic index among equals */
+      int brow = 0; double best = 0;
 #pragma unroll
       for( int i=0; i<6; i++ )
         if( i < mr && pc[i] > RKFD_LP_EPS ){
-          const double r = rr[i]/pc[i];
+          const double r = rr[i]*RKFD_RCP( pc[i] );
           if( row < 0 || r < best - 1e-15 || ( !( r > best + 1e-15 ) && bas[i] < brow ) ){ row = i; best = r; brow = bas[i]; }
         }
-      if( row < 0 ){ ok = 0; break; }
-      {
-        double pv = 0;
-#pragma unroll
-        for( int i=0; i<6; i++ ) if( i == row ) pv = 1.0/pc[i];
-        const double fc = BCAST( RKFD_LP_SELC( cc, ch ), cl );
-#pragma unroll
-        for( int h=0; h<RKFD_LP_NS; h++ ){
-          double t = 0;
-#pragma unroll
-          for( int i=0; i<6; i++ ) if( i == row ) t = T[h][i];
-          t *= pv;
-#pragma unroll
-          for( int i=0; i<6; i++ ){
-            if( i == row ) T[h][i] = t;
-            else if( i < mr && pc[i] != 0.0 ) T[h][i] -= pc[i]*t;
-          }
-          cc[h] -= fc*t;
-        }
-#pragma unroll
-        for( int i=0; i<6; i++ ) if( i == row ) bas[i] = col;
-      }
+      if( row < 0 ){ ok = 0; break; }               /* unbounded */
     }
-    if( it == 10000 ) ok = 0;
-    if( ph == 1 && ok ){
-      double art = 0;
+    {
+      double pv = 0;
 #pragma unroll
-      for( int i=0; i<6; i++ ){
-        const double ri = BCAST( RKFD_LP_SEL( T, i, rh ), rl );
-        if( i < mr && bas[i] >= n ) art += ri;
-      }
-      if( art > 1e-9*( 1.0 + scale ) ) ok = 0;
-      else {
+      for( int i=0; i<6; i++ ) if( i == row ) pv = RKFD_RCP( pc[i] );
+      const double fc = BCAST( RKFD_LP_SELC( cc, ch ), cl );
+#pragma unroll
+      for( int h=0; h<RKFD_LP_NS; h++ ){
+        double t = 0;
+#pragma unroll
+        for( int i=0; i<6; i++ ) if( i == row ) t = T[h][i];
+        t *= pv;
 #pragma unroll
         for( int i=0; i<6; i++ ){
-          /* an artificial left in the base at zero: pivot it out on the first structural column with an entry in its row */
-          const bool need = i < mr && bas[i] >= n;       /* (wave-uniform) */
-          int jc = -1;
-          if( need ){
-#pragma unroll
-            for( int h=0; h<RKFD_LP_NS; h++ )
-              if( jc < 0 && 64*h < n ){
-                const unsigned long long mk = BALLOT( lane + 64*h < n && fabs( T[h][i] ) > 1e-9 );
-                if( mk ) jc = 64*h + __builtin_ctzll( mk );
-              }
-          }
-          if( jc >= 0 ){
-            double pc[6];
-#pragma unroll
-            for( int k=0; k<6; k++ ) pc[k] = BCAST( RKFD_LP_SEL( T, k, jc >> 6 ), jc & 63 );
-            const double pv = 1.0/pc[i];
-#pragma unroll
-            for( int h=0; h<RKFD_LP_NS; h++ ){
-              const double t = T[h][i]*pv;
-#pragma unroll
-              for( int k=0; k<6; k++ ){
-                if( k == i ) T[h][k] = t;
-                else if( k < mr && pc[k] != 0.0 ) T[h][k] -= pc[k]*t;
-              }
-            }
-            bas[i] = jc;
-          }
+          if( i == row ) T[h][i] = t;
+          else if( i < mr && pc[i] != 0.0 ) T[h][i] -= pc[i]*t;
         }
+        cc[h] -= fc*t;
       }
+#pragma unroll
+      for( int i=0; i<6; i++ ) if( i == row ) bas[i] = col;
     }
+    it++;
   }
   if( ok ){
     for( int j=lane; j<n; j+=RKFD_WAVE ) x[j] = 0;
@@ -816,18 +810,26 @@ RKFD_DEV int rkfd_vol_lp(const double *A, const double *b, const double *c, doub
 }
 
 /* ------------------------------------------------------------------------ */
-/* _rkFDSolverModifyWrenchKinetic (:830-843) for pair k: w = wrench in the pair frame; w[1], w[2], w[3] are replaced.
- * All lanes call it with the same w. */
-RKFD_DEV void rkfd_vol_kinetic(const rkfdDevModel &m, const rkfdLds &L, int k, int ci, double *w)
+/* The friction fix-up of one pair (_rkFDSolverModifyWrenchStatic :677-688, ...Kinetic :830-843) as a small state machine
+ * around ONE call site of the simplex (its code is large; inlined at five places it made the kernel 186 KB, three times the
+ * instruction cache two CUs share):
+ *   stage 1  static: can the wrench be written as forces inside the friction pyramids at the polygon's corners?  yes -> the
+ *            wrench stays; no -> stage 2
+ *   stage 2  kinetic: the normal force spread over the corners (resultant and centre kept), every corner sliding its own way,
+ *            cost = -w / |w| . friction; infeasible -> stage 3
+ *   stage 3  "safety": only the resultant is kept (one equality row), the cost gets the reference's extra term (:795-812)
+ * w = wrench in the pair frame ( f.axis[0..2], n.axis[0..2] ); a kinetic outcome replaces w[1], w[2], w[3].  Returns 1 when the
+ * wrench was replaced (kinetic), 0 when it stays (static).  All lanes call it with the same arguments. */
+RKFD_DEV int rkfd_vol_friction(const rkfdDevModel &m, const rkfdLds &L, int k, int ci, double *w, int stage)
 {
   const int lane = LANE();
-  const int NCP = m.vol_ncp, n = L.VI[2*k];
+  const int NCP = m.vol_ncp, ncp = L.VI[2*k], P = m.pyramid;
   const double *pl = &L.VPL[8*NCP*k], *vd = &L.VD[RKFD_VD*k];
   const double *ax = vd + RKFD_VD_AX;
-  const int PN = m.pyramid*NCP;
+  const int PN = P*NCP;
   double *A = L.VLP, *b = A + 6*PN, *c = b + 6, *x = c + PN;      /* layout of L.VLP: A [6 x PN], b [6], c [PN], x [PN] */
-  double r0 = 0, r1 = 0, sx = 0, sy = 0;
-  if( lane < n ){
+  double r0 = 0, r1 = 0, sx = 0, sy = 0;                           /* lane = corner (kinetic stages) */
+  if( lane < ncp ){
     const double *c2 = &pl[8*lane];
     r0 = d_dot( c2, ax+3 ); r1 = d_dot( c2, ax+6 );
     /* _rkFDSolverPlaneVertSlideDir (:759-776) */
@@ -836,58 +838,62 @@ RKFD_DEV void rkfd_vol_kinetic(const rkfdDevModel &m, const rkfdLds &L, int k, i
       const double ww = ( 1.0 - exp( -1.0*m.fric_w*nv ) )*m.ci_kf[ci]/nv;
       sx = -ww*t1; sy = -ww*t2;
     }
-    A[lane] = 1.0; A[n+lane] = r1; A[2*n+lane] = -r0;
-    double wn[3];
-#pragma unroll
-    for( int i=0; i<3; i++ ) wn[i] = fabs( w[i+1] ) < RKFD_DEV_TOL ? 0.0 : 1.0/w[i+1];
-    c[lane] = -wn[0]*sx - wn[1]*sy - wn[2]*( r0*sy - r1*sx );
-    x[lane] = 0;
   }
-  if( lane == 0 ){ b[0] = w[0]; b[1] = w[4]; b[2] = w[5]; }
-  SYNC();
-  if( !rkfd_vol_lp( A, b, c, x, 3, n, true, PN + 7 ) ){
-    if( lane < n ){
-      double wn[2];
+  for(;;){
+    int mr, n;
+    if( stage == 1 ){
+      /* _rkFDSolverModifyWrenchStaticConstraint (:652-675) */
+      const double mu = m.ci_sf[ci];
+      mr = 6; n = P*ncp;
+      for( int j=lane; j<n; j+=RKFD_WAVE ){
+        const int kk = j/P, i = j - kk*P;
+        const double *c2 = &pl[8*kk];
+        const double q0 = d_dot( c2, ax+3 ), q1 = d_dot( c2, ax+6 );
+        const double PI = 3.14159265358979323846;
+        double th = 0.0, sn, cs;
+        for( int q=0; q<i; q++ ) th += 2.0*PI/P;
+        d_sincos( th + 0.0, &sn, &cs );
+        const double a1 = q1, a2 = -q0, a3 = mu*cs, a4 = mu*sn;
+        A[j] = 1.0; A[n+j] = a1; A[2*n+j] = a2; A[3*n+j] = a3; A[4*n+j] = a4; A[5*n+j] = -( a2*a4 + a1*a3 );
+      }
+      if( lane == 0 ){ b[0] = w[0]; b[1] = w[4]; b[2] = w[5]; b[3] = w[1]; b[4] = w[2]; b[5] = w[3]; }
+    } else if( stage == 2 ){
+      /* _rkFDSolverModifyWrenchKineticConstraint / ...EvalFunc (:743-793) */
+      mr = 3; n = ncp;
+      if( lane < n ){
+        A[lane] = 1.0; A[n+lane] = r1; A[2*n+lane] = -r0;
+        double wn[3];
 #pragma unroll
-      for( int i=0; i<2; i++ ) wn[i] = fabs( w[i+3] ) < RKFD_DEV_TOL ? 0.0 : 1.0/w[i+3];
-      c[lane] += wn[0]*r0 - wn[1]*r1;
+        for( int i=0; i<3; i++ ) wn[i] = fabs( w[i+1] ) < RKFD_DEV_TOL ? 0.0 : 1.0/w[i+1];
+        c[lane] = -wn[0]*sx - wn[1]*sy - wn[2]*( r0*sy - r1*sx );
+      }
+      if( lane == 0 ){ b[0] = w[0]; b[1] = w[4]; b[2] = w[5]; }
+    } else {
+      /* _rkFDSolverModifyWrenchKineticEvalFuncSafety (:795-812): the first row of A and b, the cost of stage 2 plus a term */
+      mr = 1; n = ncp;
+      if( lane < n ){
+        double wn[2];
+#pragma unroll
+        for( int i=0; i<2; i++ ) wn[i] = fabs( w[i+3] ) < RKFD_DEV_TOL ? 0.0 : 1.0/w[i+3];
+        c[lane] += wn[0]*r0 - wn[1]*r1;
+      }
     }
+    if( lane < n && stage != 1 ) x[lane] = 0;
     SYNC();
-    rkfd_vol_lp( A, b, c, x, 1, n, true, PN + 7 );
+    const int ok = rkfd_vol_lp( A, b, c, x, mr, n, stage != 1, PN + 7 );
+    if( stage == 1 ){ if( ok ) return 0; stage = 2; continue; }
+    if( stage == 2 && !ok ){ stage = 3; continue; }
+    break;
   }
   /* _rkFDSolverModifyWrenchKineticTotalWrench (:814-828): lane order = list order */
   double *red = A;       /* (the constraint matrix is dead) */
-  if( lane < n ){ const double fx = sx*x[lane], fy = sy*x[lane]; red[3*lane] = fx; red[3*lane+1] = fy; red[3*lane+2] = r0*fy - r1*fx; }
+  if( lane < ncp ){ const double fx = sx*x[lane], fy = sy*x[lane]; red[3*lane] = fx; red[3*lane+1] = fy; red[3*lane+2] = r0*fy - r1*fx; }
   SYNC();
   double a1 = 0, a2 = 0, a3 = 0;
-  for( int i=0; i<n; i++ ){ a1 += red[3*i]; a2 += red[3*i+1]; a3 += red[3*i+2]; }
+  for( int i=0; i<ncp; i++ ){ a1 += red[3*i]; a2 += red[3*i+1]; a3 += red[3*i+2]; }
   w[1] = a1; w[2] = a2; w[3] = a3;
   SYNC();
-}
-/* _rkFDSolverModifyWrenchStatic (:677-688) */
-RKFD_DEV int rkfd_vol_static(const rkfdDevModel &m, const rkfdLds &L, int k, int ci, const double *w)
-{
-  const int lane = LANE();
-  const int NCP = m.vol_ncp, ncp = L.VI[2*k], P = m.pyramid, n = P*ncp;
-  const double *pl = &L.VPL[8*NCP*k], *vd = &L.VD[RKFD_VD*k];
-  const double *ax = vd + RKFD_VD_AX;
-  const int PN = P*NCP;
-  double *A = L.VLP, *b = A + 6*PN, *c = b + 6, *x = c + PN;
-  const double mu = m.ci_sf[ci];
-  for( int j=lane; j<n; j+=RKFD_WAVE ){
-    const int kk = j/P, i = j - kk*P;
-    const double *c2 = &pl[8*kk];
-    const double r0 = d_dot( c2, ax+3 ), r1 = d_dot( c2, ax+6 );
-    const double PI = 3.14159265358979323846;
-    double th = 0.0, sn, cs;
-    for( int q=0; q<i; q++ ) th += 2.0*PI/P;
-    d_sincos( th + 0.0, &sn, &cs );
-    const double a1 = r1, a2 = -r0, a3 = mu*cs, a4 = mu*sn;
-    A[j] = 1.0; A[n+j] = a1; A[2*n+j] = a2; A[3*n+j] = a3; A[4*n+j] = a4; A[5*n+j] = -( a2*a4 + a1*a3 );
-  }
-  if( lane == 0 ){ b[0] = w[0]; b[1] = w[4]; b[2] = w[5]; b[3] = w[1]; b[4] = w[2]; b[5] = w[3]; }
-  SYNC();
-  return rkfd_vol_lp( A, b, c, x, 6, n, false, PN + 7 );
+  return 1;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -1173,14 +1179,11 @@ template<bool prof> RKFD_DEV void rkfd_phase_volume(const rkfdDevModel &m, const
         }
         kin = 1;
       }
-    } else if( ( !( fabs( fs ) < RKFD_DEV_TOL ) && fs > sf*fn ) || fabs( w[3] ) > tl*w[0] ){
-      rkfd_vol_kinetic( m, L, p, ci, w );
-      kin = 1;
-    } else if( rkfd_vol_static( m, L, p, ci, w ) ){
-      setf = 0;
     } else {
-      rkfd_vol_kinetic( m, L, p, ci, w );
-      kin = 1;
+      /* kinetic straight away when the friction limit or the twisting limit is passed, else the static test first (:899-914) */
+      const int stage = ( ( !( fabs( fs ) < RKFD_DEV_TOL ) && fs > sf*fn ) || fabs( w[3] ) > tl*w[0] ) ? 2 : 1;
+      kin = rkfd_vol_friction( m, L, p, ci, w, stage );
+      setf = kin;
     }
     if( setf && lane < 6 ){
       /* _rkFDSolverModifyWrenchSetForce (:858-867) */
