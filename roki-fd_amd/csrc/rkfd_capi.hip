@@ -642,9 +642,14 @@ extern "C" int rkfdBatchStatus(rkfdBatch *b, void *stream)
   int e = 0;
   HIPCHK( hipMemcpy( &e, b->d_err, sizeof(int), hipMemcpyDeviceToHost ), -1 );
   if( e == 1 ) SETERR( "a rigid contact occurred but no rigid solver is set up on the device for this world (max_rigid = 0)" );
-  if( e == 2 ) SETERR( "contact capacity exceeded in at least one instance: more rigid contact vertices than max_rigid (%d), or more "
-                       "rigid + elastic contact vertices than the %d active-contact slots; contacts beyond the capacity were dropped", b->dm.maxrg, b->dm.maxact );
-  if( e == 3 ) SETERR( "the Vert plugin's QP ran out of iterations (256) or of basis history (64) in at least one instance" );
+  if( e == 2 && b->dm.vol_np > 0 )
+    SETERR( "contact capacity exceeded in at least one instance: more rigid pairs in volumetric contact than %d, more than %d contact-plane "
+            "conditions in one pair, or more elastic contact vertices than the %d active-contact slots; what was beyond the capacity was dropped",
+            b->dm.vol_np, b->dm.vol_ncp, b->dm.maxact );
+  else if( e == 2 )
+    SETERR( "contact capacity exceeded in at least one instance: more rigid contact vertices than max_rigid (%d), or more "
+            "rigid + elastic contact vertices than the %d active-contact slots; contacts beyond the capacity were dropped", b->dm.maxrg, b->dm.maxact );
+  if( e == 3 ) SETERR( "the %s plugin's QP ran out of iterations (256) or of basis history (64) in at least one instance", b->dm.vol_np > 0 ? "Volume" : "Vert" );
   if( e != 0 ){
     /* the condition is reported once: the flag is cleared, so a later status describes what happened after this call */
     const int zero = 0;
