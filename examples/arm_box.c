@@ -4,7 +4,7 @@
  * the GPU; the controller runs on the host between steps, as in the reference.
  *
  * build: gcc -O2 -Iinclude examples/arm_box.c -Lroki-fd_amd -lrkfd_amd -Wl,-rpath,$PWD/roki-fd_amd -o arm_box
- * usage: ./arm_box [steps] [model dir]
+ * usage: ./arm_box [steps] [model dir] [mlcp|volume]      (the reference's driver selects Volume)
  */
 #include <stdlib.h>
 #include <string.h>
@@ -65,7 +65,8 @@ int main(int argc, char *argv[])
   rkFDODE2Assign( &fd, Regular );
   rkFDODE2AssignRegular( &fd, RKG );
   rkFDPrpSetDT( &fd, DT );
-  rkFDSetSolver( &fd, MLCP );
+  if( argc > 3 && strcmp( argv[3], "volume" ) == 0 ) rkFDSetSolver( &fd, Volume );
+  else rkFDSetSolver( &fd, MLCP );
 
   rkFDUpdateInit( &fd );
   if( rkFDStatus( &fd ) != 0 ) return 2;
