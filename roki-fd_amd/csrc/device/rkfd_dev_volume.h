@@ -49,6 +49,16 @@ RKFD_DEV void d_vol_frame(const rkfdLds &L, int i, double *R, double *p)
 RKFD_DEV int d_vol_clip(double *P, int n, int cap, const double *pl, double d)
 {
   if( n < 1 ) return 0;
+  /* most planes of the other shape do not touch a given face: look first, rewrite the polygon only when the plane cuts it */
+  {
+    bool out = false, in = false;
+    for( int i=0; i<n; i++ ){
+      const double si = pl[0]*P[3*i] + pl[1]*P[3*i+1] + pl[2]*P[3*i+2] - d;
+      out = out || si > 0; in = in || si <= 0;
+    }
+    if( !out ) return n;
+    if( !in ) return 0;
+  }
   const double f0 = P[0], f1 = P[1], f2 = P[2], sf = pl[0]*f0 + pl[1]*f1 + pl[2]*f2 - d;
   double c0 = f0, c1 = f1, c2 = f2, sc = sf;
   int k = 0;
@@ -160,61 +170,76 @@ RKFD_DEV void d_vol_triangle(const double *tri, const double *fnorm, const doubl
     else if( h[j] < -RKFD_DEV_TOL ){ st += 1 << ( j*2+1 ); s2 = j; }
     else s0 = j;
   }
-  double sgn = 0;       /* what the straddling cases add on top: +-2 x the cut-off triangle */
-  int a_ = 0, b_ = 0;   /* pp[0] = p[a_], pp[1] = p[b_] after the cut */
-  switch( st ){
-  case 0x01: case 0x04: case 0x10: case 0x05: case 0x11: case 0x14:
-    d_vol_set_plane( cp, &pf[3*s0], fnorm, norm );
-    /* fall through */
-  case 0x15:
+  /* The reference's switch (:422-475) indexes the vertices by their roles; with run-time indices the arrays would live in the
+   * private segment (scratch memory).  Here the triangle is ROTATED (a cyclic shift keeps its orientation) so that the vertex
+   * with the special role comes first; the roles of the other two are then fixed positions:
+   *   one on the plane, one above, one below  (0x24 0x12 0x09 | 0x06 0x21 0x18): on-plane vertex first -> ( on, above, below ) | ( on, below, above )
+   *   two above, one below (0x16 0x19 0x25): the one below first;   two below, one above (0x1a 0x26 0x29): the one above first */
+  const int nab = ( st & 0x15 ) ? __builtin_popcount( st & 0x15 ) : 0, nbl = __builtin_popcount( st & 0x2a );
+  if( nab + nbl == 0 ) return;                                         /* all on the plane */
+  if( nbl == 0 || nab == 0 ){
+    /* one side only: the faces' conditions where a vertex lies on the plane; c +- cc */
+    if( nab + nbl < 3 ){
+      const double q[3] = { s0 == 0 ? pf[0] : ( s0 == 1 ? pf[3] : pf[6] ), s0 == 0 ? pf[1] : ( s0 == 1 ? pf[4] : pf[7] ), s0 == 0 ? pf[2] : ( s0 == 1 ? pf[5] : pf[8] ) };
+      d_vol_set_plane( cp, q, fnorm, norm );
+    }
+    const double sg = nbl == 0 ? 1.0 : -1.0;
 #pragma unroll
-    for( int k=0; k<6; k++ ) acc[10+k] += cc[k];
-    return;
-  case 0x02: case 0x08: case 0x20: case 0x0a: case 0x22: case 0x28:
-    d_vol_set_plane( cp, &pf[3*s0], fnorm, norm );
-    /* fall through */
-  case 0x2a:
-#pragma unroll
-    for( int k=0; k<6; k++ ) acc[10+k] -= cc[k];
-    return;
-  case 0x24: case 0x12: case 0x09:
-#pragma unroll
-    for( int k=0; k<6; k++ ) acc[10+k] += cc[k];
-    d_vol_inner( &pf[3*s1], &pf[3*s2], h[s1], h[s2], &p[3*s1] );
-    h[s1] = 0.0; a_ = s0; b_ = s1; sgn = -2.0;
-    break;
-  case 0x06: case 0x21: case 0x18:
-#pragma unroll
-    for( int k=0; k<6; k++ ) acc[10+k] += cc[k];
-    d_vol_inner( &pf[3*s1], &pf[3*s2], h[s1], h[s2], &p[3*s2] );
-    h[s2] = 0.0; a_ = s2; b_ = s0; sgn = -2.0;
-    break;
-  case 0x16: case 0x19: case 0x25:
-    s0 = ( s2+1 ) % 3; s1 = ( s0+1 ) % 3;
-#pragma unroll
-    for( int k=0; k<6; k++ ) acc[10+k] += cc[k];
-    d_vol_inner( &pf[3*s2], &pf[3*s0], h[s2], h[s0], &p[3*s0] );
-    d_vol_inner( &pf[3*s2], &pf[3*s1], h[s2], h[s1], &p[3*s1] );
-    h[s0] = h[s1] = 0.0; a_ = s0; b_ = s1; sgn = -2.0;
-    break;
-  case 0x1a: case 0x26: case 0x29:
-    s0 = ( s1+1 ) % 3; s2 = ( s0+1 ) % 3;
-#pragma unroll
-    for( int k=0; k<6; k++ ) acc[10+k] -= cc[k];
-    d_vol_inner( &pf[3*s1], &pf[3*s0], h[s1], h[s0], &p[3*s0] );
-    d_vol_inner( &pf[3*s1], &pf[3*s2], h[s1], h[s2], &p[3*s2] );
-    h[s0] = h[s2] = 0.0; a_ = s2; b_ = s0; sgn = 2.0;
-    break;
-  default:
+    for( int k=0; k<6; k++ ) acc[10+k] += sg*cc[k];
     return;
   }
-  (void)b_;
-  const double pp0[3] = { p[3*a_], p[3*a_+1], p[3*a_+2] };
-  s = d_vol_area( p );
-  d_vol_mid( p, pm );
-  d_vol_depth( pm, h, K, s, norm, cc );
+  /* straddling: c +- cc, then -+ 2 x the part cut off */
+  const bool ab = nab == 1 && nbl == 1;                 /* one on, one above, one below */
+  const bool dd = !ab && nbl == 2;                      /* two below, one above */
+  const int rot = ab ? s0 : ( dd ? s1 : s2 );
+  {
+    const double sg = dd ? -1.0 : 1.0;
 #pragma unroll
-  for( int k=0; k<6; k++ ) acc[10+k] += sgn*cc[k];
+    for( int k=0; k<6; k++ ) acc[10+k] += sg*cc[k];
+  }
+  double qf[9], qp[9], qh[3];
+#pragma unroll
+  for( int j=0; j<3; j++ ){
+    /* position j of the rotated triangle = vertex ( rot + j ) % 3 */
+#pragma unroll
+    for( int k=0; k<3; k++ ){
+      const double f0 = pf[3*j+k], f1 = pf[3*( ( j+1 )%3 )+k], f2 = pf[3*( ( j+2 )%3 )+k];
+      const double p0 = p[3*j+k], p1 = p[3*( ( j+1 )%3 )+k], p2 = p[3*( ( j+2 )%3 )+k];
+      qf[3*j+k] = rot == 0 ? f0 : ( rot == 1 ? f1 : f2 );
+      qp[3*j+k] = rot == 0 ? p0 : ( rot == 1 ? p1 : p2 );
+    }
+    const double h0 = h[j], h1 = h[( j+1 )%3], h2 = h[( j+2 )%3];
+    qh[j] = rot == 0 ? h0 : ( rot == 1 ? h1 : h2 );
+  }
+  double pp0[3];
+  if( ab ){
+    /* ( on, above, below ): the cut replaces the ABOVE vertex (position 1) and the part kept is the one below;
+     * ( on, below, above ): the cut replaces the BELOW vertex (position 1 again) and the part kept is the one above - as written
+     * in the reference (:435-452); both take the cut point between the vertex above and the vertex below, in that order */
+    const bool bt = qh[1] < 0;
+    double u[3], v[3];
+#pragma unroll
+    for( int k=0; k<3; k++ ){ u[k] = bt ? qf[6+k] : qf[3+k]; v[k] = bt ? qf[3+k] : qf[6+k]; }
+    d_vol_inner( u, v, bt ? qh[2] : qh[1], bt ? qh[1] : qh[2], &qp[3] );
+    qh[1] = 0.0;
+#pragma unroll
+    for( int k=0; k<3; k++ ) pp0[k] = bt ? qp[3+k] : qp[k];
+  } else {
+    /* the lone vertex first: both others are replaced by the cut points of its edges */
+    d_vol_inner( qf, &qf[3], qh[0], qh[1], &qp[3] );
+    d_vol_inner( qf, &qf[6], qh[0], qh[2], &qp[6] );
+    qh[1] = qh[2] = 0.0;
+#pragma unroll
+    for( int k=0; k<3; k++ ) pp0[k] = dd ? qp[6+k] : qp[3+k];
+  }
+  s = d_vol_area( qp );
+  d_vol_mid( qp, pm );
+  d_vol_depth( pm, qh, K, s, norm, cc );
+  {
+    const double sgn = dd ? 2.0 : -2.0;
+#pragma unroll
+    for( int k=0; k<6; k++ ) acc[10+k] += sgn*cc[k];
+  }
   d_vol_set_plane( cp, pp0, fnorm, norm );
 }
 
@@ -382,20 +407,24 @@ template<bool prof> RKFD_DEV void rkfd_phase_volcol(const rkfdDevModel &m, const
     VCT(30);
     /* gather the conditions in face order, merge identical ones, sort by angle (:350-395, :490): one lane, a handful of entries */
     {
-      double *cv = scr;          /* [F][7]: has, v, n per face; then [F] angles */
+      double *cv = scr;          /* [F][8]: has, v, n, angle per face (the angle of __rk_fd_plane_cmp, :376-395, by the face's own lane); then [F] angles of the list */
       if( lane < F ){
-        cv[7*lane] = cp.has ? 1.0 : 0.0;
+        cv[8*lane] = cp.has ? 1.0 : 0.0;
 #pragma unroll
-        for( int k=0; k<3; k++ ){ cv[7*lane+1+k] = cp.v[k]; cv[7*lane+4+k] = cp.n[k]; }
+        for( int k=0; k<3; k++ ){ cv[8*lane+1+k] = cp.v[k]; cv[8*lane+4+k] = cp.n[k]; }
+        double tmp[3];
+        d_cross( ax+3, cp.n, tmp );
+        const double y = sqrt( d_dot( tmp, tmp ) ), a = cp.has ? d_atan2_ypos( y, d_dot( ax+3, cp.n ) ) : 0.0;
+        cv[8*lane+7] = d_dot( tmp, ax ) > 0 ? -a : a;
       }
       SYNC();
       if( lane == 0 ){
         double *pl = &L.VPL[8*NCP*nvp];
-        double *th = scr + 7*F;
+        double *th = scr + 8*F;
         int ncp = 0, ovf = 0;
         for( int fi=0; fi<na+nb; fi++ ){
-          if( cv[7*fi] == 0.0 ) continue;
-          const double *p = &cv[7*fi+1], *nn = &cv[7*fi+4];
+          if( cv[8*fi] == 0.0 ) continue;
+          const double *p = &cv[8*fi+1], *nn = &cv[8*fi+4];
           int merged = 0;
           for( int k=0; k<ncp && !merged; k++ ){
             double *c2 = &pl[8*k];
@@ -412,12 +441,7 @@ template<bool prof> RKFD_DEV void rkfd_phase_volcol(const rkfdDevModel &m, const
           if( ncp == NCP ){ ovf = 1; continue; }
           double *c2 = &pl[8*ncp];
           c2[0] = p[0]; c2[1] = p[1]; c2[2] = p[2]; c2[3] = nn[0]; c2[4] = nn[1]; c2[5] = nn[2];
-          {
-            double tmp[3];
-            d_cross( ax+3, nn, tmp );
-            const double y = sqrt( d_dot( tmp, tmp ) ), a = d_atan2_ypos( y, d_dot( ax+3, nn ) );
-            th[ncp] = d_dot( tmp, ax ) > 0 ? -a : a;
-          }
+          th[ncp] = cv[8*fi+7];
           ncp++;
         }
         for( int i=1; i<ncp; i++ ){
