@@ -448,7 +448,7 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
   SYNC();
   MST(15);
 #ifndef RKFD_EMU
-  if( !pk && m.mlcp_mfma && M <= 32 ) rkfd_mlcp_matrix_mfma( m, L, nc, ld, vert );
+  if( !pk && ( m.mlcp_mfma & 1 ) && M <= 32 ) rkfd_mlcp_matrix_mfma( m, L, nc, ld, vert );
   else
 #endif
   /* A, one 3x3 block per lane and pass: block ( cr, ck <= cr ) and its mirror image */

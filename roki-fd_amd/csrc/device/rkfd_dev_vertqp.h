@@ -90,6 +90,37 @@ RKFD_DEV double rkfd_w_sum(double v, double *scr)
   return r;
 }
 
+#ifndef RKFD_EMU
+/* S = W'W (r x r, r <= 32) of the active-set iteration on the matrix cores (measurement variant, switch RKFD_VERT_MFMA; see DESIGN.md
+ * "MFMA"): W is n x r in LDS (row stride ldq); v_mfma_f64_16x16x4_f64 takes A[i = lane & 15][k = lane >> 4] and
+ * B[k = lane >> 4][j = lane & 15] - for a Gram product both operands are W[k][column], so a lane loads ONE value per column block
+ * and k-step where the VALU loop loads 2 n values per entry.  Tiles (0,0), (0,1), (1,1); the fourth by symmetry. */
+typedef double rkfd_qd4 __attribute__((ext_vector_type(4)));
+RKFD_DEV void rkfd_vert_s_mfma(const double *W, int ldq, int n, int r, double *S, int ld)
+{
+  const int lane = LANE();
+  const int kk = lane >> 4, cc = lane & 15;
+  rkfd_qd4 c00 = { 0, 0, 0, 0 }, c01 = { 0, 0, 0, 0 }, c11 = { 0, 0, 0, 0 };
+  for( int k0=0; k0<n; k0+=4 ){
+    const int k = k0 + kk;
+    const double a0 = ( k < n && cc < r ) ? W[k*ldq + cc] : 0.0;
+    const double a1 = ( k < n && 16+cc < r ) ? W[k*ldq + 16 + cc] : 0.0;
+    c00 = __builtin_amdgcn_mfma_f64_16x16x4f64( a0, a0, c00, 0, 0, 0 );
+    if( r > 16 ){
+      c01 = __builtin_amdgcn_mfma_f64_16x16x4f64( a0, a1, c01, 0, 0, 0 );
+      c11 = __builtin_amdgcn_mfma_f64_16x16x4f64( a1, a1, c11, 0, 0, 0 );
+    }
+  }
+#pragma unroll
+  for( int rg=0; rg<4; rg++ ){
+    const int row = kk + 4*rg;
+    if( row < r && cc < r ) S[row*ld + cc] = c00[rg];
+    if( row < r && 16+cc < r ){ S[row*ld + 16+cc] = c01[rg]; S[( 16+cc )*ld + row] = c01[rg]; }
+    if( 16+row < r && 16+cc < r ) S[( 16+row )*ld + 16+cc] = c11[rg];
+  }
+}
+#endif
+
 #define RKFD_QP_ASM_TOL 1.0e-8
 #define RKFD_QP_MAXITER 256
 
@@ -210,6 +241,10 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
     }
     SYNC();
     double *S = L.MA;
+#ifndef RKFD_EMU
+    if( ( m.mlcp_mfma & 2 ) && r <= 32 ) rkfd_vert_s_mfma( W, ldq, n, r, S, ld );
+    else
+#endif
     for( int t0=0; t0<r*r; t0+=RKFD_WAVE ){
       const int t = t0 + lane, a = r > 0 ? t/r : 0, b = t - a*r;
       if( t < r*r && b <= a ){

@@ -33,7 +33,8 @@ typedef struct {
   int npurow;            /* rows of PU per side: nlevel (+6 with a float joint)                         */
   int nside;             /* 1 when every rigid-capable pair has a static cell (probe walks one-sided) else 2 */
   int maxrg;             /* capacity: rigid contact vertices solved per instance (3*maxrg <= 128) */
-  int mlcp_mfma;         /* 1: the contact matrix A = N'N is formed with v_mfma_f64_16x16x4_f64 (worlds with at most 32 rows;
+  int mlcp_mfma;         /* bit 0: the contact matrix A = N'N is formed with v_mfma_f64_16x16x4_f64 (worlds with at most 32 rows;
+                            bit 1 (switch RKFD_VERT_MFMA): the Vert QP's Schur complement S = W'W likewise;
                             measurement switch RKFD_MLCP_MFMA, see DESIGN.md "MFMA") */
   /* Volume plugin (solver == RKFD_SOLVER_VOLUME and rigid pairs exist; device/rkfd_dev_volume.h) */
   int vol_npair;         /* rigid pairs of the model */
