@@ -91,8 +91,8 @@ RKFD_DEV double rkfd_w_sum(double v, double *scr)
 }
 
 #ifndef RKFD_EMU
-/* S = W'W (r x r, r <= 32) of the active-set iteration on the matrix cores (measurement variant, switch RKFD_VERT_MFMA; see DESIGN.md
- * "MFMA"): W is n x r in LDS (row stride ldq); v_mfma_f64_16x16x4_f64 takes A[i = lane & 15][k = lane >> 4] and
+/* A Gram product G'G (r x r, r <= 32) on the matrix cores: the Vert QP's Q = A'A (once per evaluation, on by default) and the
+ * Schur complement S = W'W of its iterations (switch RKFD_VERT_MFMA_S, measured: no gain); see DESIGN.md "MFMA".  W is n x r in LDS (row stride ldq); v_mfma_f64_16x16x4_f64 takes A[i = lane & 15][k = lane >> 4] and
  * B[k = lane >> 4][j = lane & 15] - for a Gram product both operands are W[k][column], so a lane loads ONE value per column block
  * and k-step where the VALU loop loads 2 n values per entry.  Tiles (0,0), (0,1), (1,1); the fourth by symmetry. */
 typedef double rkfd_qd4 __attribute__((ext_vector_type(4)));
@@ -172,6 +172,20 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
     if( onc ){ g0 = mu*c0; g1 = s1; g2 = c1; }
   }
   /* q = A'A + L (lower triangle, packed by rows), c = A'c */
+#ifndef RKFD_EMU
+  if( ( m.mlcp_mfma & 4 ) && n <= 32 ){
+    /* the Gram product on the matrix cores (v_mfma_f64_16x16x4_f64) into W's storage, free until the first iteration, then packed:
+     * a full 24 x 24 x 24 product, where the VALU loop below loads 2 x 24 values from LDS per entry: q:setup 337 k -> 257 k cycles per
+     * step, config 4 under the Vert plugin 3.30 -> 3.48 M steps/s (profiles/r02_vert_mfma_ab.txt) */
+    rkfd_vert_s_mfma( L.MA, ld, n, n, W, ldq );
+    SYNC();
+    for( int t0=0; t0<n*n; t0+=RKFD_WAVE ){
+      const int t = t0 + lane, i = t/n, k = t - i*n;
+      if( t < n*n && k <= i ) Q[RKFD_QI( i, k )] = W[i*ldq+k] + ( i == k ? m.ci_l[RKFD_CI_CI( L.CIp[L.lrg[i/3]] )] : 0.0 );
+    }
+    SYNC();
+  } else
+#endif
   for( int t0=0; t0<n*n; t0+=RKFD_WAVE ){
     const int t = t0 + lane, i = t/n, k = t - i*n;
     if( t < n*n && k <= i ){

@@ -524,7 +524,10 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   if( vol_np > 0 ){ dm.vert_rigid = 0; dm.qscr_alias = 0; dm.ma_packed = 0; dm.ma_size = 6*vol_np*( 6*vol_np+1 ); }
   dm.maxact = maxact; dm.nside = nside;
   { const char *e = getenv( "RKFD_MLCP_MFMA" ); dm.mlcp_mfma = ( e && atoi( e ) > 0 && 3*max_rigid <= 32 ) ? 1 : 0; }
-  { const char *e = getenv( "RKFD_VERT_MFMA" ); if( e && atoi( e ) > 0 ) dm.mlcp_mfma |= 2; }      /* bit 1: the Vert QP's S = W'W on the matrix cores */
+  /* the Vert QP's Gram products: Q = A'A on the matrix cores by default (bit 2; measured +5.5 % on config 4 under the Vert plugin,
+   * RKFD_VERT_MFMA=0 switches it off), S = W'W of the iterations only on request (bit 1, RKFD_VERT_MFMA_S=1: measured no gain) */
+  { const char *e = getenv( "RKFD_VERT_MFMA" ); if( !e || atoi( e ) > 0 ) dm.mlcp_mfma |= 4; }
+  { const char *e = getenv( "RKFD_VERT_MFMA_S" ); if( e && atoi( e ) > 0 ) dm.mlcp_mfma |= 2; }
   const size_t Mrows = 3*(size_t)max_rigid;
   /* probe scratch: one row per tree level plus six for a float root, per side; it overlays the
    * C|PA block of the link arrays (dead while the contact problem is solved) when it fits */

@@ -34,7 +34,8 @@ typedef struct {
   int nside;             /* 1 when every rigid-capable pair has a static cell (probe walks one-sided) else 2 */
   int maxrg;             /* capacity: rigid contact vertices solved per instance (3*maxrg <= 128) */
   int mlcp_mfma;         /* bit 0: the contact matrix A = N'N is formed with v_mfma_f64_16x16x4_f64 (worlds with at most 32 rows;
-                            bit 1 (switch RKFD_VERT_MFMA): the Vert QP's Schur complement S = W'W likewise;
+                            bit 1 (switch RKFD_VERT_MFMA_S): the Vert QP's Schur complement S = W'W likewise; bit 2 (default on,
+                            RKFD_VERT_MFMA=0 switches it off): the Vert QP's Q = A'A likewise - the one product where it pays;
                             measurement switch RKFD_MLCP_MFMA, see DESIGN.md "MFMA") */
   /* Volume plugin (solver == RKFD_SOLVER_VOLUME and rigid pairs exist; device/rkfd_dev_volume.h) */
   int vol_npair;         /* rigid pairs of the model */
