@@ -259,16 +259,24 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
     if( ( m.mlcp_mfma & 2 ) && r <= 32 ) rkfd_vert_s_mfma( W, ldq, n, r, S, ld );
     else
 #endif
-    for( int t0=0; t0<r*r; t0+=RKFD_WAVE ){
-      const int t = t0 + lane, a = r > 0 ? t/r : 0, b = t - a*r;
-      if( t < r*r && b <= a ){
+    for( int t0=0; t0<( r*( r+1 ) >> 1 ); t0+=RKFD_WAVE ){
+      /* lane = entry ( a, b <= a ) of the lower triangle, counted row by row: every lane of a pass has work */
+      const int t = t0 + lane;
+      int a = (int)( ( sqrt( 8.0*t + 1.0 ) - 1.0 )*0.5 );
+      if( ( a*( a+1 ) >> 1 ) > t ) a--;
+      if( ( ( a+1 )*( a+2 ) >> 1 ) <= t ) a++;
+      const int b = t - ( a*( a+1 ) >> 1 );
+      if( t < ( r*( r+1 ) >> 1 ) ){
+        /* column a of W = L^-1 C' is zero above the first unknown of its contact (the forward substitution starts there):
+         * the skipped terms are exact zeros, the sum is bit for bit the same */
+        const int ca = L.CRC[a], cb = L.CRC[b];
         double sacc = 0;
-        for( int i=0; i<n; i++ ) sacc = fma( W[i*ldq+a], W[i*ldq+b], sacc );
+        for( int i=3*( ca > cb ? ca : cb ); i<n; i++ ) sacc = fma( W[i*ldq+a], W[i*ldq+b], sacc );
         S[a*ld+b] = sacc; S[b*ld+a] = sacc;
       }
     }
     double rl = 0;
-    if( lane < r ) for( int i=0; i<n; i++ ) rl = fma( W[i*ldq+lane], zv[i], rl );
+    if( lane < r ) for( int i=3*L.CRC[lane]; i<n; i++ ) rl = fma( W[i*ldq+lane], zv[i], rl );
     SYNC();
     VST(26);
     rkfd_w_chol<false>( S, ld, r );
