@@ -513,6 +513,24 @@ RKFD_DEV double rkfd_vol_pinv(double *S, double *EV, double *vec, int ld, int r,
     const double s00 = S[0], r0 = BCAST( rhs_i, 0 );
     return ( lane == 0 && fabs( s00 ) > 0.0 ) ? r0/s00 : 0.0;
   }
+  if( r == 2 ){
+    /* two active rows (the centre of normal force at a corner of the polygon): ONE Jacobi rotation diagonalises a 2 x 2 matrix -
+     * the same rotation, eigenvalues and rank test as the general loop below, in scalar arithmetic without barriers */
+    const double a = S[0], bq = S[1], d = S[ld+1], r0 = BCAST( rhs_i, 0 ), r1 = BCAST( rhs_i, 1 );
+    double c = 1.0, sn = 0.0, e0 = a, e1 = d;
+    if( bq != 0.0 ){
+      const double theta = ( d - a )/( 2.0*bq );
+      const double t = ( theta >= 0 ? 1.0 : -1.0 )/( fabs( theta ) + sqrt( theta*theta + 1.0 ) );
+      c = 1.0/sqrt( t*t + 1.0 ); sn = t*c;
+      /* the diagonal after the column and the row rotation of the loop below */
+      const double k00 = c*a - sn*bq, k01 = sn*a + c*bq, k10 = c*bq - sn*d, k11 = sn*bq + c*d;
+      e0 = c*k00 - sn*k10; e1 = sn*k01 + c*k11;
+    }
+    /* eigenvectors: columns ( c, -sn ) and ( sn, c ) */
+    const double wmax = fabs( e0 ) > fabs( e1 ) ? fabs( e0 ) : fabs( e1 );
+    const double y0 = fabs( e0 ) > 1e-12*wmax ? ( c*r0 - sn*r1 )/e0 : 0.0, y1 = fabs( e1 ) > 1e-12*wmax ? ( sn*r0 + c*r1 )/e1 : 0.0;
+    return lane == 0 ? c*y0 + sn*y1 : ( lane == 1 ? -sn*y0 + c*y1 : 0.0 );
+  }
   if( lane < r ) for( int j=0; j<r; j++ ) EV[lane*ld+j] = lane == j ? 1.0 : 0.0;
   SYNC();
   for( int sweep=0; sweep<60; sweep++ ){
