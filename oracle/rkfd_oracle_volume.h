@@ -607,7 +607,7 @@ static void vol_slide_dir(const rkfdOracle *o, VolPair *vp, VolCP *cp)
 static void vol_kinetic(rkfdOracle *o, VolPair *vp, double *w)
 {
   const int n = vp->ncp;
-  double *ma = (double *)malloc( sizeof(double)*3*n ), *mc = (double *)malloc( sizeof(double)*n ), *mf = (double *)calloc( n, sizeof(double) );
+  double *ma = (double *)malloc( sizeof(double)*3*n ), *mc = (double *)calloc( (size_t)n, sizeof(double) ), *mf = (double *)calloc( (size_t)n, sizeof(double) );
   double mb[3] = { w[0], w[4], w[5] }, wn[3];
   int k, i;
   for( k=0; k<n; k++ ){ ma[k] = 1.0; ma[n+k] = vp->cp[k].r[1]; ma[2*n+k] = -vp->cp[k].r[0]; }
@@ -759,7 +759,7 @@ static int volume_rigid(rkfdOracle *o, int doUpRef)
   /* _rkFDSolverCountContacts (:21-28), _rkFDSolverFrictionConstraint (:121-138) */
   for( c=0; c<np; c++ ) colnum += o->vp[c].ncp;
   cnum = np + colnum;
-  nf = (double *)calloc( (size_t)cnum*n, sizeof(double) ); d = (double *)calloc( cnum, sizeof(double) ); idx = (int *)malloc( sizeof(int)*cnum );
+  nf = (double *)calloc( (size_t)cnum*n, sizeof(double) ); d = (double *)calloc( (size_t)cnum, sizeof(double) ); idx = (int *)malloc( sizeof(int)*(size_t)cnum );
   io = 0; jo = 0;
   for( c=0; c<np; c++ ){
     const VolPair *vp = &o->vp[c];

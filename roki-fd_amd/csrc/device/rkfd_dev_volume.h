@@ -504,7 +504,7 @@ template<bool prof> RKFD_DEV void rkfd_phase_volcol(const rkfdDevModel &m, const
 /* Moore-Penrose solve of a small symmetric positive semi-definite system in LDS, wave-cooperative cyclic Jacobi
  * (the same method and rank tolerance as sym_pinv_solve of the oracle): S (r x r, stride ld, destroyed), EV (r x r, stride ld)
  * scratch; lane i passes rhs_i and receives x_i. */
-RKFD_DEV double rkfd_vol_pinv(double *S, double *EV, double *vec, int ld, int r, double rhs_i, double *scr)
+RKFD_DEV double rkfd_vol_pinv(double *S, double *EV, double *vec, int ld, int r, double rhs_i)
 {
   const int lane = LANE();
   if( r == 0 ) return 0.0;
@@ -585,13 +585,13 @@ RKFD_DEV double rkfd_vol_pinv(double *S, double *EV, double *vec, int ld, int r,
 /* rkFDQPSolveASM (reference src/rkfd_opt_qp.c:43-181) for the Volume plugin: min x'Qx/2 + c'x s.t. G x >= 0, G's row
  * lane touching the six unknowns of its pair; start point init (lane = unknown).  In: L.VQL = Q (packed lower triangle),
  * cv; out: ans (L.VQV + 2n).  lane = constraint as well (mc <= 64). */
-RKFD_DEV void rkfd_vol_qp(const rkfdDevModel &m, const rkfdLds &L, int n, int mc, const double *g, int gp, double init)
+RKFD_DEV void rkfd_vol_qp(const rkfdLds &L, int n, int mc, const double *g, int gp, double init)
 {
   const int lane = LANE();
   const int ldw = mc > 0 ? mc : 1;
   double *Q = L.VQL, *W = L.VQW, *S = L.VS, *EV = L.VEV;
   double *cv = L.VQV, *zv = L.VQV + n, *ans = L.VQV + 2*n, *xv = L.VQV + 3*n, *dv = L.VQV + 4*n;
-  double *lam = L.VQV + 5*n, *scr = L.VQV + 5*n + mc;
+  double *lam = L.VQV + 5*n;
   const bool onc = lane < mc;
   if( lane < n ) ans[lane] = init;
   SYNC();
@@ -633,7 +633,7 @@ RKFD_DEV void rkfd_vol_qp(const rkfdDevModel &m, const rkfdLds &L, int n, int mc
     if( lane < r ) for( int i=0; i<n; i++ ) rl = fma( W[i*ldw+lane], zv[i], rl );
     SYNC();
     {
-      const double l = rkfd_vol_pinv( S, EV, lam, ldw, r, rl, scr );
+      const double l = rkfd_vol_pinv( S, EV, lam, ldw, r, rl );
       if( lane < r ) lam[lane] = l;
     }
     SYNC();
@@ -1119,7 +1119,7 @@ template<bool prof> RKFD_DEV void rkfd_phase_volume(const rkfdDevModel &m, const
   if( lane < n ){ const int c = lane/6, i = lane - 6*c; init = i < 3 ? L.VD[RKFD_VD*c + RKFD_VD_AX + i] : 0.0; }
   SYNC();
   VST(24);
-  rkfd_vol_qp( m, L, n, mc, g, gp, init );
+  rkfd_vol_qp( L, n, mc, g, gp, init );
   VST(25);
   /* _rkFDSolverQP (:547), _rkFDSolverSetForce (:552-568; the offset stays behind a pair without conditions, as in the reference) */
   {
