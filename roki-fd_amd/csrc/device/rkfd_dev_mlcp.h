@@ -452,10 +452,22 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
   else
 #endif
   /* A, one 3x3 block per lane and pass: block ( cr, ck <= cr ) and its mirror image */
-  for( int e0=0; e0<nc*nc; e0+=RKFD_WAVE ){
+  for( int e0=0; e0<( pk ? ( nc*( nc+1 ) >> 1 ) : nc*nc ); e0+=RKFD_WAVE ){
     const int e = e0 + lane;
-    const int cr = e/nc, ck = e - cr*nc;
-    if( e < nc*nc && ck <= cr ){
+    int cr, ck; bool one;
+    if( pk ){
+      /* (the packed-matrix kernels serve the worlds with many contacts: lane = block of the lower triangle counted row by row, so
+       * that every lane of a pass has one - 24 contacts: 5 passes instead of 9) */
+      cr = (int)( ( sqrt( 8.0*e + 1.0 ) - 1.0 )*0.5 );
+      if( ( cr*( cr+1 ) >> 1 ) > e ) cr--;
+      if( ( ( cr+1 )*( cr+2 ) >> 1 ) <= e ) cr++;
+      ck = e - ( cr*( cr+1 ) >> 1 );
+      one = e < ( nc*( nc+1 ) >> 1 );
+    } else {
+      cr = e/nc; ck = e - cr*nc;
+      one = e < nc*nc && ck <= cr;
+    }
+    if( one ){
       double blk[9] = {0,0,0,0,0,0,0,0,0};
       for( int sr=0; sr<NSD; sr++ ) for( int sk=0; sk<NSD; sk++ ){
         const unsigned er = (unsigned)L.tgt[cr*NSD+sr], ek = (unsigned)L.tgt[ck*NSD+sk];
