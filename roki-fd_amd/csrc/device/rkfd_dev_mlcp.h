@@ -142,6 +142,144 @@ template<bool pk> RKFD_DEV void rkfd_pgs_dpp(const double *MA, int r0, int ld, i
   }
 }
 
+/* GROUPED projected Gauss-Seidel (many contacts on several independent bodies: config 5's humanoid + four boxes).  Two contacts
+ * are coupled only when they share a moving tree (the reference zeroes the other entries, src/rkfd_mlcp.c:76-102; here they are
+ * exact zeros because the probe paths share no joint), so the contact problem falls into connected components, and an update
+ * changes the residuals of its own component only.  The components are laid out one (or several, one after the other) per DPP
+ * row of 16 lanes: the SAME instruction stream then runs the Gauss-Seidel sequence of every row at once - row_newbcast:C
+ * delivers the increment of position C of EACH row within that row - and a sweep is as long as the fullest row (config 5: 8 + 8
+ * instead of 24 + 24 updates).  Within a component the reference's order is kept; updates of different components never
+ * touch the same residual, so the result is bit for bit that of the one-after-the-other loop
+ * (tests/test_gpu_sustained.py::test_grouped_gauss_seidel_is_bit_identical; m:pgs 852 k -> 528 k cycles per step, config 5
+ * 1.26 -> 1.71 M steps/s).  grow: this lane's row of the position table (contact index or 255), pos = lane & 15. */
+template<bool pk, int C0> RKFD_DEV void rkfd_pgs_grp_normal(const double *MA, const unsigned char *grow, int r0, int ld, int maxlen, int pos, double in_,
+                                                            double &rn, double &r1, double &r2, double &fn)
+{
+  /* (blocks of two: the entries of the second update are in flight while the first runs - measured 1.71 M against 1.62 M
+   * steps/s on config 5 for one update at a time) */
+  double a0[2], a1[2], a2[2];
+#pragma unroll
+  for( int u=0; u<2; u++ ){
+    int kc = grow[C0+u < maxlen ? C0+u : 0];
+    if( kc == 255 ) kc = 0;                        /* (an empty position broadcasts a zero increment: any entry will do) */
+    a0[u] = MA[rkfd_ma_idx<pk>( r0, 3*kc, ld )]; a1[u] = MA[rkfd_ma_idx<pk>( r0+1, 3*kc, ld )]; a2[u] = MA[rkfd_ma_idx<pk>( r0+2, 3*kc, ld )];
+  }
+#define RKFD_PGS_GN(u) \
+  if( C0+u < maxlen ){ \
+    double ff = fn - rn*in_; \
+    if( ff < RKFD_DEV_TOL ) ff = 0.0; \
+    const double dl = ff - fn; \
+    if( pos == C0+u ) fn = ff; \
+    ROWBC_FMAC( C0+u, rn, dl, a0[u] ); ROWBC_FMAC( C0+u, r1, dl, a1[u] ); ROWBC_FMAC( C0+u, r2, dl, a2[u] ); \
+  }
+  RKFD_PGS_GN(0) RKFD_PGS_GN(1)
+#undef RKFD_PGS_GN
+}
+template<bool pk, int C0> RKFD_DEV void rkfd_pgs_grp_tangent(const double *MA, const unsigned char *grow, int r0, int ld, int maxlen, int pos, double i1, double i2, double fs,
+                                                             double &rn, double &r1, double &r2, double &f1, double &f2)
+{
+  if( C0 < maxlen ){
+    int kc = grow[C0];
+    if( kc == 255 ) kc = 0;
+    const double a0 = MA[rkfd_ma_idx<pk>( r0, 3*kc+1, ld )], a1 = MA[rkfd_ma_idx<pk>( r0+1, 3*kc+1, ld )], a2 = MA[rkfd_ma_idx<pk>( r0+2, 3*kc+1, ld )];
+    const double b0 = MA[rkfd_ma_idx<pk>( r0, 3*kc+2, ld )], b1 = MA[rkfd_ma_idx<pk>( r0+1, 3*kc+2, ld )], b2 = MA[rkfd_ma_idx<pk>( r0+2, 3*kc+2, ld )];
+    const double ff0 = f1 - r1*i1, ff1 = f2 - r2*i2;
+    const double fnorm = ff0*ff0 + ff1*ff1;
+    const bool zero = fnorm < RKFD_DEV_TOL || fs < RKFD_DEV_TOL;
+    double n1 = zero ? 0.0 : ff0, n2 = zero ? 0.0 : ff1;
+    /* (the lanes at position C0 of the rows decide for themselves: no wave-uniform branch here) */
+    if( !zero && fnorm > fs ){
+      const double sc = fs*RKFD_RCP( fnorm );
+      n1 = ff0*sc; n2 = ff1*sc;
+    }
+    const double d1 = n1 - f1, d2 = n2 - f2;
+    if( pos == C0 ){ f1 = n1; f2 = n2; }
+    ROWBC_FMAC( C0, rn, d2, b0 ); ROWBC_FMAC( C0, r1, d2, b1 ); ROWBC_FMAC( C0, r2, d2, b2 );
+    ROWBC_FMAC( C0, rn, d1, a0 ); ROWBC_FMAC( C0, r1, d1, a1 ); ROWBC_FMAC( C0, r2, d1, a2 );
+  }
+}
+/* returns false when the contacts do not fit the layout (a component of more than 16 contacts, rows too full): the
+ * caller then runs the general loop.  tab: 64 bytes of LDS scratch.  Writes MF itself. */
+template<bool pk> RKFD_DEV bool rkfd_pgs_grouped(const rkfdDevModel &m, const rkfdLds &L, unsigned char *tab, int nc, int ld, double dt)
+{
+  const int lane = LANE();
+  const int NSD = m.nside;
+  const unsigned long long below = lane == 0 ? 0ull : ( ~0ull >> ( 64-lane ) );
+  /* the moving trees of this lane's contact (255: none) */
+  int t0 = 255, t1 = 255;
+  if( lane < nc ){
+    const unsigned e0 = (unsigned)L.tgt[lane*NSD];
+    if( RKFD_CS_VALID( e0 ) ) t0 = RKFD_CS_TOP( e0 );
+    if( NSD > 1 ){ const unsigned e1 = (unsigned)L.tgt[lane*NSD+1]; if( RKFD_CS_VALID( e1 ) ) t1 = RKFD_CS_TOP( e1 ); }
+  }
+  /* connected components: label = the smallest contact index reachable (a few rounds of all-against-all) */
+  int label = lane < nc ? lane : 255;
+  for( int round=0; round<RKFD_WAVE; round++ ){
+    int nl = label;
+    for( int j=0; j<nc; j++ ){
+      const int u0 = (int)BCAST( (double)t0, j ), u1 = (int)BCAST( (double)t1, j ), lj = (int)BCAST( (double)label, j );
+      const bool share = ( t0 != 255 && ( t0 == u0 || t0 == u1 ) ) || ( t1 != 255 && ( t1 == u0 || t1 == u1 ) );
+      if( lane < nc && share && lj < nl ) nl = lj;
+    }
+    const bool ch = nl != label;
+    label = nl;
+    if( BALLOT( ch ) == 0ull ) break;
+  }
+  /* rows: every component (in the order of their first contacts) goes to the row that is emptiest so far - a sweep is as long as
+   * the fullest row */
+  unsigned long long leaders = BALLOT( lane < nc && label == lane );
+  int f0 = 0, f1_ = 0, f2_ = 0, f3 = 0, maxlen = 0, target = -1;
+  bool fits = true;
+  while( leaders ){
+    const int ld_ = __builtin_ctzll( leaders );
+    leaders &= leaders - 1ull;
+    const unsigned long long mk = BALLOT( lane < nc && label == ld_ );
+    const int size = __builtin_popcountll( mk );
+    int row = 0, fill = f0;
+    if( f1_ < fill ){ row = 1; fill = f1_; }
+    if( f2_ < fill ){ row = 2; fill = f2_; }
+    if( f3 < fill ){ row = 3; fill = f3; }
+    if( fill + size > 16 ){ fits = false; break; }
+    if( lane < nc && label == ld_ ) target = 16*row + fill + __builtin_popcountll( mk & below );
+    fill += size;
+    if( row == 0 ) f0 = fill; else if( row == 1 ) f1_ = fill; else if( row == 2 ) f2_ = fill; else f3 = fill;
+    if( fill > maxlen ) maxlen = fill;
+  }
+  if( !fits ) return false;
+  tab[lane] = 255;
+  SYNC();
+  if( target >= 0 ) tab[target] = (unsigned char)lane;
+  SYNC();
+  /* this lane's contact in the new layout */
+  const int k = tab[lane];
+  const bool on = k != 255;
+  const int r0 = on ? 3*k : 0, pos = lane & 15;
+  const unsigned char *grow = &tab[lane & 48];
+  double rn = 0, r1 = 0, r2 = 0, fn = 0, f1 = 0, f2 = 0, in_ = 0, i1 = 0, i2 = 0, mu = 0;
+  if( on ){
+    rn = L.MB[r0]; r1 = L.MB[r0+1]; r2 = L.MB[r0+2];
+    const double dn = L.MA[rkfd_ma_idx<pk>( r0, r0, ld )], d1 = L.MA[rkfd_ma_idx<pk>( r0+1, r0+1, ld )], d2 = L.MA[rkfd_ma_idx<pk>( r0+2, r0+2, ld )];
+    in_ = 1.0/dn;
+    i1 = fabs( d1 ) < RKFD_DEV_TOL ? 0.0 : 1.0/d1;
+    i2 = fabs( d2 ) < RKFD_DEV_TOL ? 0.0 : 1.0/d2;
+    const int jr_ = L.lrg[k], cir_ = RKFD_CI_CI( L.CIp[jr_] );
+    mu = L.typ[jr_] == RKFD_SF ? m.ci_sf[cir_] : m.ci_kf[cir_];
+  }
+  SYNC();       /* (MF shares its storage with MB in these kernels: everybody has read b before anybody writes f) */
+  for( int it=0; it<m.max_iter; it++ ){
+#define RKFD_PGS_GNB(C0) if( maxlen > C0 ) rkfd_pgs_grp_normal<pk, C0>( L.MA, grow, r0, ld, maxlen, pos, in_, rn, r1, r2, fn );
+    RKFD_PGS_GNB(0) RKFD_PGS_GNB(2) RKFD_PGS_GNB(4) RKFD_PGS_GNB(6) RKFD_PGS_GNB(8) RKFD_PGS_GNB(10) RKFD_PGS_GNB(12) RKFD_PGS_GNB(14)
+#undef RKFD_PGS_GNB
+    double fs = mu*fn; fs = fs*fs;
+#define RKFD_PGS_GTB(C0) rkfd_pgs_grp_tangent<pk, C0>( L.MA, grow, r0, ld, maxlen, pos, i1, i2, fs, rn, r1, r2, f1, f2 );
+    RKFD_PGS_GTB(0) RKFD_PGS_GTB(1) RKFD_PGS_GTB(2) RKFD_PGS_GTB(3) RKFD_PGS_GTB(4) RKFD_PGS_GTB(5) RKFD_PGS_GTB(6) RKFD_PGS_GTB(7)
+    RKFD_PGS_GTB(8) RKFD_PGS_GTB(9) RKFD_PGS_GTB(10) RKFD_PGS_GTB(11) RKFD_PGS_GTB(12) RKFD_PGS_GTB(13) RKFD_PGS_GTB(14) RKFD_PGS_GTB(15)
+#undef RKFD_PGS_GTB
+  }
+  if( on ){ L.MF[r0] = fn/dt; L.MF[r0+1] = f1/dt; L.MF[r0+2] = f2/dt; }
+  return true;
+}
+
 /* the same for exactly 8 contacts - the humanoid standing on both soles, the contact problem the headline workload
  * solves in almost every evaluation: the contact count is a literal, so the per-update guards of the block form above
  * (a scalar compare, a branch and the compiler's mask bookkeeping per update) are gone.  Same arithmetic and order.
@@ -558,6 +696,7 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
     const bool on = lane < nc;
     const int r0 = on ? 3*lane : 0;
     double rn = 0, r1 = 0, r2 = 0, fn = 0, f1 = 0, f2 = 0, in_ = 0, i1 = 0, i2 = 0, mu = 0;
+    bool grouped = false;
     if( on ){
       rn = L.MB[r0]; r1 = L.MB[r0+1]; r2 = L.MB[r0+2];
       const double dn = L.MA[rkfd_ma_idx<pk>( r0, r0, ld )], d1 = L.MA[rkfd_ma_idx<pk>( r0+1, r0+1, ld )], d2 = L.MA[rkfd_ma_idx<pk>( r0+2, r0+2, ld )];
@@ -578,8 +717,13 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
     if( nc <= RKFD_PGS_NC ) rkfd_pgs_registers<pk>( L.MA, r0, ld, nc, m.max_iter, on, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
     else if( nc == 8 ) rkfd_pgs_dpp8<pk>( L.MA, r0, ld, m.max_iter, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
     else if( !pk && nc <= RKFD_PGS_DPP_MAX ) rkfd_pgs_dpp<pk>( L.MA, r0, ld, nc, m.maxrg, m.max_iter, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
+    else if( m.maxrg > RKFD_PGS_DPP_MAX && nc > RKFD_PGS_DPP_MAX && !( m.mlcp_mfma & 8 ) && rkfd_pgs_grouped<pk>( m, L, (unsigned char *)L.AC, nc, ld, dt ) ){
+      /* (several independent bodies in contact: their Gauss-Seidel sequences run side by side, one DPP row each; the link
+       * accelerations' storage is free between the bias vector and the delta sweep) */
+      grouped = true;
+    }
     else rkfd_pgs_general<pk>( L.MA, r0, ld, nc, m.max_iter, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
-    if( on ){ L.MF[r0] = fn/dt; L.MF[r0+1] = f1/dt; L.MF[r0+2] = f2/dt; }
+    if( on && !grouped ){ L.MF[r0] = fn/dt; L.MF[r0+1] = f1/dt; L.MF[r0+2] = f2/dt; }
   }
   SYNC();
   MST(21);

@@ -528,6 +528,9 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
    * RKFD_VERT_MFMA=0 switches it off), S = W'W of the iterations only on request (bit 1, RKFD_VERT_MFMA_S=1: measured no gain) */
   { const char *e = getenv( "RKFD_VERT_MFMA" ); if( !e || atoi( e ) > 0 ) dm.mlcp_mfma |= 4; }
   { const char *e = getenv( "RKFD_VERT_MFMA_S" ); if( e && atoi( e ) > 0 ) dm.mlcp_mfma |= 2; }
+  /* bit 3: the grouped Gauss-Seidel (independent bodies side by side in DPP rows) switched off - for the A/B test of its claim
+   * that it reproduces the one-after-the-other loop bit for bit */
+  { const char *e = getenv( "RKFD_PGS_GROUPED" ); if( e && atoi( e ) == 0 ) dm.mlcp_mfma |= 8; }
   const size_t Mrows = 3*(size_t)max_rigid;
   /* probe scratch: one row per tree level plus six for a float root, per side; it overlays the
    * C|PA block of the link arrays (dead while the contact problem is solved) when it fits */

@@ -36,6 +36,7 @@ typedef struct {
   int mlcp_mfma;         /* bit 0: the contact matrix A = N'N is formed with v_mfma_f64_16x16x4_f64 (worlds with at most 32 rows;
                             bit 1 (switch RKFD_VERT_MFMA_S): the Vert QP's Schur complement S = W'W likewise; bit 2 (default on,
                             RKFD_VERT_MFMA=0 switches it off): the Vert QP's Q = A'A likewise - the one product where it pays;
+                            bit 3 (RKFD_PGS_GROUPED=0): the grouped Gauss-Seidel of rkfd_dev_mlcp.h switched off (A/B test);
                             measurement switch RKFD_MLCP_MFMA, see DESIGN.md "MFMA") */
   /* Volume plugin (solver == RKFD_SOLVER_VOLUME and rigid pairs exist; device/rkfd_dev_volume.h) */
   int vol_npair;         /* rigid pairs of the model */
