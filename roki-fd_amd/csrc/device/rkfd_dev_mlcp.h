@@ -152,6 +152,8 @@ template<bool pk> RKFD_DEV void rkfd_pgs_dpp(const double *MA, int r0, int ld, i
  * touch the same residual, so the result is bit for bit that of the one-after-the-other loop
  * (tests/test_gpu_sustained.py::test_grouped_gauss_seidel_is_bit_identical; m:pgs 852 k -> 528 k cycles per step, config 5
  * 1.26 -> 1.71 M steps/s).  grow: this lane's row of the position table (contact index or 255), pos = lane & 15. */
+/* position c (a literal) of a row of the position table held in four registers */
+#define RKFD_GRP_POS(gw, c) ( (int)( ( (gw)[(c) >> 2] >> ( 8*( (c) & 3 ) ) ) & 255u ) )
 /* entry ( row, col ) of the contact matrix where the row's own part of the packed index is known: rb = row ( row + 1 ) / 2 (per lane,
  * fixed for the solve), cbase = col ( col + 1 ) / 2 (from the position's contact) - no multiplication per entry */
 template<bool pk> RKFD_DEV int rkfd_ma_idx2(int row, int rb, int col, int cbase, int ld)
@@ -159,7 +161,7 @@ template<bool pk> RKFD_DEV int rkfd_ma_idx2(int row, int rb, int col, int cbase,
   if( !pk ) return row*ld + col;
   return col <= row ? rb + col : cbase + row;
 }
-template<bool pk, int C0> RKFD_DEV void rkfd_pgs_grp_normal(const double *MA, const unsigned char *grow, int r0, const int *rb, int ld, int maxlen, int pos, double in_,
+template<bool pk, int C0> RKFD_DEV void rkfd_pgs_grp_normal(const double *MA, const unsigned *gw, int r0, const int *rb, int ld, int maxlen, int pos, double in_,
                                                             double &rn, double &r1, double &r2, double &fn)
 {
   /* (blocks of two: the entries of the second update are in flight while the first runs - measured 1.71 M against 1.62 M
@@ -167,7 +169,7 @@ template<bool pk, int C0> RKFD_DEV void rkfd_pgs_grp_normal(const double *MA, co
   double a0[2], a1[2], a2[2];
 #pragma unroll
   for( int u=0; u<2; u++ ){
-    int kc = grow[C0+u < maxlen ? C0+u : 0];
+    int kc = RKFD_GRP_POS( gw, C0+u );
     if( kc == 255 ) kc = 0;                        /* (an empty position broadcasts a zero increment: any entry will do) */
     const int c3 = 3*kc, cb = ( c3*( c3+1 ) ) >> 1;
     a0[u] = MA[rkfd_ma_idx2<pk>( r0, rb[0], c3, cb, ld )]; a1[u] = MA[rkfd_ma_idx2<pk>( r0+1, rb[1], c3, cb, ld )]; a2[u] = MA[rkfd_ma_idx2<pk>( r0+2, rb[2], c3, cb, ld )];
@@ -183,11 +185,11 @@ template<bool pk, int C0> RKFD_DEV void rkfd_pgs_grp_normal(const double *MA, co
   RKFD_PGS_GN(0) RKFD_PGS_GN(1)
 #undef RKFD_PGS_GN
 }
-template<bool pk, int C0> RKFD_DEV void rkfd_pgs_grp_tangent(const double *MA, const unsigned char *grow, int r0, const int *rb, int ld, int maxlen, int pos, double i1, double i2, double fs,
+template<bool pk, int C0> RKFD_DEV void rkfd_pgs_grp_tangent(const double *MA, const unsigned *gw, int r0, const int *rb, int ld, int maxlen, int pos, double i1, double i2, double fs,
                                                              double &rn, double &r1, double &r2, double &f1, double &f2)
 {
   if( C0 < maxlen ){
-    int kc = grow[C0];
+    int kc = RKFD_GRP_POS( gw, C0 );
     if( kc == 255 ) kc = 0;
     const int c1 = 3*kc+1, c2 = c1+1, cb1 = ( c1*c2 ) >> 1, cb2 = cb1 + c2;      /* c ( c + 1 ) / 2 of the two tangential columns */
     const double a0 = MA[rkfd_ma_idx2<pk>( r0, rb[0], c1, cb1, ld )], a1 = MA[rkfd_ma_idx2<pk>( r0+1, rb[1], c1, cb1, ld )], a2 = MA[rkfd_ma_idx2<pk>( r0+2, rb[2], c1, cb1, ld )];
@@ -263,7 +265,11 @@ template<bool pk> RKFD_DEV bool rkfd_pgs_grouped(const rkfdDevModel &m, const rk
   const int k = tab[lane];
   const bool on = k != 255;
   const int r0 = on ? 3*k : 0, pos = lane & 15;
-  const unsigned char *grow = &tab[lane & 48];
+  unsigned gw[4];        /* this lane's row of the table: 16 positions, one byte each */
+  {
+    const unsigned *g32 = (const unsigned *)&tab[lane & 48];
+    gw[0] = g32[0]; gw[1] = g32[1]; gw[2] = g32[2]; gw[3] = g32[3];
+  }
   const int rb[3] = { ( r0*( r0+1 ) ) >> 1, ( ( r0+1 )*( r0+2 ) ) >> 1, ( ( r0+2 )*( r0+3 ) ) >> 1 };
   double rn = 0, r1 = 0, r2 = 0, fn = 0, f1 = 0, f2 = 0, in_ = 0, i1 = 0, i2 = 0, mu = 0;
   if( on ){
@@ -277,11 +283,16 @@ template<bool pk> RKFD_DEV bool rkfd_pgs_grouped(const rkfdDevModel &m, const rk
   }
   SYNC();       /* (MF shares its storage with MB in these kernels: everybody has read b before anybody writes f) */
   for( int it=0; it<m.max_iter; it++ ){
-#define RKFD_PGS_GNB(C0) if( maxlen > C0 ) rkfd_pgs_grp_normal<pk, C0>( L.MA, grow, r0, rb, ld, maxlen, pos, in_, rn, r1, r2, fn );
+#ifndef RKFD_EMU
+    /* (the table is re-read through an opaque asm every sweep: otherwise the compiler hoists the index arithmetic of all 48
+     * updates out of the sweep loop and spills hundreds of registers) */
+    asm volatile( "" : "+v"(gw[0]), "+v"(gw[1]), "+v"(gw[2]), "+v"(gw[3]) );
+#endif
+#define RKFD_PGS_GNB(C0) if( maxlen > C0 ) rkfd_pgs_grp_normal<pk, C0>( L.MA, gw, r0, rb, ld, maxlen, pos, in_, rn, r1, r2, fn );
     RKFD_PGS_GNB(0) RKFD_PGS_GNB(2) RKFD_PGS_GNB(4) RKFD_PGS_GNB(6) RKFD_PGS_GNB(8) RKFD_PGS_GNB(10) RKFD_PGS_GNB(12) RKFD_PGS_GNB(14)
 #undef RKFD_PGS_GNB
     double fs = mu*fn; fs = fs*fs;
-#define RKFD_PGS_GTB(C0) rkfd_pgs_grp_tangent<pk, C0>( L.MA, grow, r0, rb, ld, maxlen, pos, i1, i2, fs, rn, r1, r2, f1, f2 );
+#define RKFD_PGS_GTB(C0) rkfd_pgs_grp_tangent<pk, C0>( L.MA, gw, r0, rb, ld, maxlen, pos, i1, i2, fs, rn, r1, r2, f1, f2 );
     RKFD_PGS_GTB(0) RKFD_PGS_GTB(1) RKFD_PGS_GTB(2) RKFD_PGS_GTB(3) RKFD_PGS_GTB(4) RKFD_PGS_GTB(5) RKFD_PGS_GTB(6) RKFD_PGS_GTB(7)
     RKFD_PGS_GTB(8) RKFD_PGS_GTB(9) RKFD_PGS_GTB(10) RKFD_PGS_GTB(11) RKFD_PGS_GTB(12) RKFD_PGS_GTB(13) RKFD_PGS_GTB(14) RKFD_PGS_GTB(15)
 #undef RKFD_PGS_GTB
