@@ -475,6 +475,26 @@ template<bool prof> RKFD_DEV void rkfd_phase_volcol(const rkfdDevModel &m, const
         double va[3], vb[3];
         d_point_vel( &L.V[6*la], x, va ); d_point_vel( &L.V[6*lb], x, vb );
         double v[3] = { va[0]-vb[0], va[1]-vb[1], va[2]-vb[2] };
+        double vs[3] = { v[0], v[1], v[2] };          /* with the cells' slide velocities (the friction fix-ups; not the 6-D velocity) */
+        if( rec[7] ){
+#pragma unroll
+          for( int sd=0; sd<2; sd++ ){
+            if( !( ( rec[7] >> sd ) & 1 ) ) continue;
+            const double *sp = &RELOAD( m.vol_slide )[16*pr + 8*sd];
+            const double *Rk = sd == 0 ? RA : RB, *pk = sd == 0 ? pA : pB;
+            const double axl[3] = { sp[1], sp[2], sp[3] }, orl[3] = { sp[4], sp[5], sp[6] };
+            double axw[3], orw[3], sv[3];
+            d_mulv( Rk, axl, axw ); d_mulv( Rk, orl, orw );
+            const double t[3] = { x[0]-pk[0]-orw[0], x[1]-pk[1]-orw[1], x[2]-pk[2]-orw[2] };
+            d_cross( axw, t, sv );
+            const double sn = d_dot( sv, ax );
+            sv[0] -= sn*ax[0]; sv[1] -= sn*ax[1]; sv[2] -= sn*ax[2];
+            const double nr = sqrt( d_dot( sv, sv ) );
+            if( fabs( nr ) < RKFD_DEV_TOL ) continue;
+            const double gq = ( sd == 0 ? 1.0 : -1.0 )*sp[0]/nr;
+            vs[0] += gq*sv[0]; vs[1] += gq*sv[1]; vs[2] += gq*sv[2];
+          }
+        }
         if( lane == 0 ){
           double ca[3], cb[3];
           d_cross( &L.V[6*la], va, ca ); d_cross( &L.V[6*lb], vb, cb );
@@ -484,9 +504,9 @@ template<bool prof> RKFD_DEV void rkfd_phase_volcol(const rkfdDevModel &m, const
             vd[RKFD_VD_CA+k] = ca[k] - cb[k];
           }
         }
-        const double vn = d_dot( ax, v );
-        v[0] -= vn*ax[0]; v[1] -= vn*ax[1]; v[2] -= vn*ax[2];
-        const double t1 = d_dot( v, ax+3 ), t2 = d_dot( v, ax+6 );
+        const double vn = d_dot( ax, vs );
+        vs[0] -= vn*ax[0]; vs[1] -= vn*ax[1]; vs[2] -= vn*ax[2];
+        const double t1 = d_dot( vs, ax+3 ), t2 = d_dot( vs, ax+6 );
         if( lane == 0 ){ vd[RKFD_VD_TC] = t1; vd[RKFD_VD_TC+1] = t2; }
         else { double *c2 = &L.VPL[8*( NCP*nvp + lane-1 )]; c2[6] = t1; c2[7] = t2; }
       }

@@ -302,7 +302,7 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
    * vertices lying on it, counter-clockwise seen from outside, in the device link's frame (the oracle builds the same
    * loops: oracle/rkfd_oracle_volume.h vol_prepare).  A coplanar duplicate of an earlier plane gets no loop. */
   std::vector<int> vol_pair, vol_loop;
-  std::vector<double> vol_lplane, vol_lvert;
+  std::vector<double> vol_lplane, vol_lvert, vol_slide;
   int vol_npair = 0, vol_np = 0, vol_ncp = 0, vol_pv = 0, vol_nf = 0;
   if( m->solver == RKFD_SOLVER_VOLUME ){
     std::vector<int> sh_l0( m->nshape, -1 ), sh_nl( m->nshape, 0 );
@@ -372,7 +372,19 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
         if( sh_nl[sh] < 4 ) FAIL( "Volume plugin: shape %d of a rigid pair is not a closed convex polyhedron (%d faces found)", sh, sh_nl[sh] );
       }
       const int shA = m->pair_shape[2*pr], shB = m->pair_shape[2*pr+1];
-      const int rec[8] = { rep[m->shape_link[shA]], rep[m->shape_link[shB]], m->pair_ci[pr], sh_l0[shA], sh_nl[shA], sh_l0[shB], sh_nl[shB], 0 };
+      /* slide-mode cells (rkFDLinkAddSlideVel, reference src/rkfd_util.c:26-40; the plugin's friction fix-ups see them, its 6-D
+       * velocity does not, :83-85): per side the speed, the axis and the origin of the shape's model link, in the device link's frame */
+      int smode = 0;
+      for( int sd=0; sd<2; sd++ ){
+        const int sh = m->pair_shape[2*pr+sd];
+        const double *T = &Trep[12*m->shape_link[sh]];
+        const bool on = m->shape_slide_mode && m->shape_slide_mode[sh];
+        if( on ) smode |= 1 << sd;
+        double o[8] = { on ? m->shape_slide_vel[sh] : 0.0, 0, 0, 0, T[9], T[10], T[11], 0 };
+        if( on ){ const double *ax = &m->shape_slide_axis[3*sh]; for( int a=0; a<3; a++ ) o[1+a] = T[3*a]*ax[0] + T[3*a+1]*ax[1] + T[3*a+2]*ax[2]; }
+        vol_slide.insert( vol_slide.end(), o, o+8 );
+      }
+      const int rec[8] = { rep[m->shape_link[shA]], rep[m->shape_link[shB]], m->pair_ci[pr], sh_l0[shA], sh_nl[shA], sh_l0[shB], sh_nl[shB], smode };
       vol_pair.insert( vol_pair.end(), rec, rec+8 );
       vol_npair++;
       if( sh_nl[shA] + sh_nl[shB] > RKFD_WAVE ) FAIL( "Volume plugin: the two shapes of a rigid pair have %d faces together (one lane per face: at most %d)", sh_nl[shA]+sh_nl[shB], RKFD_WAVE );
@@ -398,7 +410,6 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
         if( vol_np*( 1+vol_ncp ) > RKFD_WAVE ) FAIL( "Volume plugin: %d pairs x ( 1 + %d conditions ) exceed 64 constraints", vol_np, vol_ncp );
         if( vol_pv < 10 ) vol_pv = 10;
         vol_nf = maxfaces;
-        if( has_slide ) FAIL( "Volume plugin: cells in slide mode are not supported on the device" );
       }
     }
   }
@@ -576,8 +587,10 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   if( vol_loop.empty() ) vol_loop.assign( 2, 0 );
   if( vol_lplane.empty() ) vol_lplane.assign( 4, 0.0 );
   if( vol_lvert.empty() ) vol_lvert.assign( 3, 0.0 );
+  if( vol_slide.empty() ) vol_slide.assign( 16, 0.0 );
   PUT( vol_pair, vol_pair.data(), sizeof(int)*vol_pair.size() ); PUT( vol_loop, vol_loop.data(), sizeof(int)*vol_loop.size() );
   PUT( vol_lplane, vol_lplane.data(), sizeof(double)*vol_lplane.size() ); PUT( vol_lvert, vol_lvert.data(), sizeof(double)*vol_lvert.size() );
+  PUT( vol_slide, vol_slide.data(), sizeof(double)*vol_slide.size() );
   PUT( ci_type, m->ci_type, sizeof(int)*m->nci );
   PUT( ci_sf, m->ci_sf, sizeof(double)*m->nci ); PUT( ci_kf, m->ci_kf, sizeof(double)*m->nci );
   PUT( ci_k, m->ci_k, sizeof(double)*m->nci ); PUT( ci_l, m->ci_l, sizeof(double)*m->nci );
@@ -647,7 +660,7 @@ extern "C" void rkfd_devmodel_rebase(rkfdDevModel *dm, const void *from, const v
   RB(mot_k); RB(mot_admit); RB(mot_vmax); RB(mot_vmin); RB(mot_gear); RB(mot_inertia);
   RB(anc); RB(level_off); RB(level_link); RB(child_off); RB(child_idx); RB(pathlink); RB(linfo); RB(sched); RB(cinfo); RB(pslot); RB(orig); RB(dofkind);
   RB(cand_linkA); RB(cand_linkB); RB(cand_foff); RB(cand_nf); RB(cand_ci); RB(cand_vert); RB(cand_bs); RB(cs_mode); RB(cs_par); RB(planes);
-  RB(vol_pair); RB(vol_loop); RB(vol_lplane); RB(vol_lvert);
+  RB(vol_pair); RB(vol_loop); RB(vol_lplane); RB(vol_lvert); RB(vol_slide);
   RB(ci_type); RB(ci_sf); RB(ci_kf); RB(ci_k); RB(ci_l); RB(ci_e); RB(ci_v);
 #undef RB
 }

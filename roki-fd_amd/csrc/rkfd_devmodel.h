@@ -44,10 +44,12 @@ typedef struct {
   int vol_ncp;           /* capacity: contact-plane conditions per pair (vol_np ( 1 + vol_ncp ) <= 64 constraints) */
   int vol_pv;            /* capacity: vertices of a clipped face polygon                                        */
   int vol_nf;            /* most faces the two shapes of a rigid pair have together (one lane each, <= 64)      */
-  const int *vol_pair;   /* [vol_npair*8] device link A, B, contact info, first face loop of A, loops of A, first of B, loops of B, 0 */
+  const int *vol_pair;   /* [vol_npair*8] device link A, B, contact info, first face loop of A, loops of A, first of B, loops of B,
+                            slide mode (bit 0: cell[0], bit 1: cell[1]) */
   const int *vol_loop;   /* [nloop*2] first vertex, vertices of a face loop (counter-clockwise seen from outside) */
   const double *vol_lplane; /* [nloop*4] the loop's plane, device link frame                                    */
   const double *vol_lvert;  /* [nlv*3] loop vertices, device link frame; the loops of one shape are contiguous  */
+  const double *vol_slide;  /* [vol_npair*16] per side: slide speed, axis (3), origin of the shape's model link (3), 0 - device link frame */
   double dt, fric_w;
   /* per link */
   const int *parent, *jtype, *dofoff, *mtype, *depth, *is_static;

@@ -321,3 +321,30 @@ def test_emulated_volume_sixteen_conditions(R, oracle_cls):
     o.update_n(2)
     d, v, a = eb.get_state(); od, ov, oa = o.get_state()
     assert np.abs(d[0] - od).max() < 1e-12 and np.abs(v[0] - ov).max() < 1e-10 and np.abs(a[0] - oa).max() < 1e-7
+
+
+def test_emulated_volume_slide_mode(R, oracle_cls):
+    """cells in slide mode under the Volume plugin: the belt velocities enter the friction fix-ups (the sliding directions at the
+    corners of the contact polygon), not the plugin's 6-D velocity (reference src/rkfd_util.c:83-85) - a sliding box on a running
+    floor takes another path, and the device follows the oracle"""
+    M = R.scenarios.MODELS
+    ends = {}
+    for who in ("none", "both"):
+        w = R.World(solver=R.SOLVER_VOLUME); w.contact_info(os.path.join(M, "contactinfo.ztk"))
+        bx = w.reg_file(os.path.join(M, "box.ztk")); fl = w.reg_file(os.path.join(M, "floor.ztk"))
+        if who == "both":
+            w.set_slide(bx, 0, True, 0.2, (0.0, 1.0, 0.0)); w.set_slide(fl, 0, True, -0.4, (0.3, 1.0, 0.0))
+        dis = np.zeros(6); vel = np.zeros(6); dis[2] = 0.0499; dis[5] = 0.2; vel[0] = 0.3
+        o = oracle_cls(w.model); o.set_state(dis, vel); o.update_init()
+        if who == "both":
+            eb = EmuBatch(w, 1, max_rigid=2)
+            eb.set_state(dis[None, :], vel[None, :]); eb.update_init(); eb.update(3)
+            assert eb.status() == 0
+            o.update_n(3)
+            d, v, a = eb.get_state(); od, ov, oa = o.get_state()
+            assert np.abs(d[0] - od).max() < 1e-12 and np.abs(v[0] - ov).max() < 1e-10
+            o.update_n(57)
+        else:
+            o.update_n(60)
+        ends[who] = o.get_state()[0][:2].copy()
+    assert np.abs(ends["none"] - ends["both"]).max() > 1e-3

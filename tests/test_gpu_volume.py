@@ -305,3 +305,38 @@ def test_volume_on_random_trees(R, oracle_cls, tmp_path):
     assert npairs > 300
     # (a chunk with a knife-edge friction decision differs visibly, see test_volume_rolling_cylinder; the rest agrees closely)
     assert nbad <= ntot // 50, (nbad, ntot, worst)
+
+
+@pytest.mark.parametrize("who", ["box", "floor", "both"])
+def test_volume_slide_mode(R, oracle_cls, who):
+    """cells in slide mode (fake crawler belts) under the Volume plugin: a box sliding over the floor, the box's bottom and / or
+    the floor running; 120 steps of 3 instances, every step from the oracle's state"""
+    M = R.scenarios.MODELS
+    w = R.World(solver=R.SOLVER_VOLUME); w.contact_info(os.path.join(M, "contactinfo.ztk"))
+    bx = w.reg_file(os.path.join(M, "box.ztk")); fl = w.reg_file(os.path.join(M, "floor.ztk"))
+    if who in ("box", "both"):
+        w.set_slide(bx, 0, True, 0.2, (0.0, 1.0, 0.0))
+    if who in ("floor", "both"):
+        w.set_slide(fl, 0, True, -0.4, (0.3, 1.0, 0.0))
+    B = 3
+    dis = np.zeros((B, 6)); vel = np.zeros((B, 6))
+    dis[:, 2] = 0.0499; dis[:, 5] = (0.2, -0.4, 1.0); vel[:, 0] = (0.3, 0.1, -0.2); vel[:, 1] = (0.0, 0.25, 0.1)
+    bt = R.Batch(w, B, max_rigid=2)
+    os_ = []
+    for b in range(B):
+        o = oracle_cls(w.model); o.set_state(dis[b], vel[b]); o.update_init(); os_.append(o)
+    errs = []; kin = 0
+    for k in range(120):
+        sd = np.array([o.get_state()[0] for o in os_]); sv = np.array([o.get_state()[1] for o in os_])
+        bt.set_state(sd, sv); bt.update_init(); bt.update(1)
+        assert bt.status() == 0, R.last_error()
+        d, v, a = bt.get_state()
+        for b, o in enumerate(os_):
+            assert o.update() == 0
+            od, ov, oa = o.get_state()
+            errs.append(max(np.abs(d[b] - od).max(), np.abs(v[b] - ov).max(), np.abs(a[b] - oa).max() / max(1.0, np.abs(oa).max())))
+            kin += any(p["type"] == R.KF for p in o.volume_pairs())
+    errs = np.array(errs)
+    flipped = int((errs > 1e-6).sum())
+    assert kin > 50 and flipped <= 3, (kin, flipped)
+    assert np.median(errs) < 1e-10 and np.sort(errs)[len(errs) - 1 - flipped] < 1e-6, (np.median(errs), flipped)
