@@ -209,9 +209,10 @@ template<bool pk, int C0> RKFD_DEV void rkfd_pgs_grp_tangent(const double *MA, c
     ROWBC_FMAC( C0, rn, d1, a0 ); ROWBC_FMAC( C0, r1, d1, a1 ); ROWBC_FMAC( C0, r2, d1, a2 );
   }
 }
-/* returns false when the contacts do not fit the layout (a component of more than 16 contacts, rows too full): the
- * caller then runs the general loop.  tab: 64 bytes of LDS scratch.  Writes MF itself. */
-template<bool pk> RKFD_DEV bool rkfd_pgs_grouped(const rkfdDevModel &m, const rkfdLds &L, unsigned char *tab, int nc, int ld, double dt)
+/* the layout: components -> rows; fills the position table tab (64 bytes of LDS: contact index or 255 per lane position) and
+ * returns the four row fills packed in bytes, or -1 when the contacts do not fit (a component of more than 16 contacts, rows too
+ * full).  Needs the packed moving-side records L.tgt. */
+RKFD_DEV int rkfd_pgs_group_layout(const rkfdDevModel &m, const rkfdLds &L, unsigned char *tab, int nc)
 {
   const int lane = LANE();
   const int NSD = m.nside;
@@ -256,11 +257,22 @@ template<bool pk> RKFD_DEV bool rkfd_pgs_grouped(const rkfdDevModel &m, const rk
     if( row == 0 ) f0 = fill; else if( row == 1 ) f1_ = fill; else if( row == 2 ) f2_ = fill; else f3 = fill;
     if( fill > maxlen ) maxlen = fill;
   }
-  if( !fits ) return false;
+  (void)maxlen;
+  if( !fits ) return -1;
   tab[lane] = 255;
   SYNC();
   if( target >= 0 ) tab[target] = (unsigned char)lane;
   SYNC();
+  return f0 | ( f1_ << 8 ) | ( f2_ << 16 ) | ( f3 << 24 );
+}
+/* the solve on a layout made by rkfd_pgs_group_layout.  Writes MF itself. */
+template<bool pk> RKFD_DEV void rkfd_pgs_grouped(const rkfdDevModel &m, const rkfdLds &L, const unsigned char *tab, int fills, int ld, double dt)
+{
+  const int lane = LANE();
+  int maxlen = fills & 255;
+  if( ( ( fills >> 8 ) & 255 ) > maxlen ) maxlen = ( fills >> 8 ) & 255;
+  if( ( ( fills >> 16 ) & 255 ) > maxlen ) maxlen = ( fills >> 16 ) & 255;
+  if( ( ( fills >> 24 ) & 255 ) > maxlen ) maxlen = ( fills >> 24 ) & 255;
   /* this lane's contact in the new layout */
   const int k = tab[lane];
   const bool on = k != 255;
@@ -298,7 +310,6 @@ template<bool pk> RKFD_DEV bool rkfd_pgs_grouped(const rkfdDevModel &m, const rk
 #undef RKFD_PGS_GTB
   }
   if( on ){ L.MF[r0] = fn/dt; L.MF[r0+1] = f1/dt; L.MF[r0+2] = f2/dt; }
-  return true;
 }
 
 /* the same for exactly 8 contacts - the humanoid standing on both soles, the contact problem the headline workload
@@ -534,6 +545,11 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
     if( RKFD_JT_IS1( jt ) ) L.MS[3*lane+2] = sqrt( L.MS[3*lane+0] );
   }
   SYNC();
+  /* many contacts on several independent bodies: the grouped layout (rkfd_pgs_group_layout) serves the matrix build and the
+   * Gauss-Seidel below; its table lives in the link accelerations' storage, free from here to the delta sweep */
+  int gfills = -1;
+  if( !vert && m.maxrg > RKFD_PGS_DPP_MAX && nc > RKFD_PGS_DPP_MAX && !( m.mlcp_mfma & 8 ) )
+    gfills = rkfd_pgs_group_layout( m, L, (unsigned char *)L.AC, nc );
   MST(14);
   /* probes: lane = column k = 3c+i; unit force along axis i at contact c, applied to the
    * owner link (+) and the other link (-).  Every level between the contact link and the top of
@@ -738,9 +754,9 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
     if( nc <= RKFD_PGS_NC ) rkfd_pgs_registers<pk>( L.MA, r0, ld, nc, m.max_iter, on, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
     else if( nc == 8 ) rkfd_pgs_dpp8<pk>( L.MA, r0, ld, m.max_iter, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
     else if( !pk && nc <= RKFD_PGS_DPP_MAX ) rkfd_pgs_dpp<pk>( L.MA, r0, ld, nc, m.maxrg, m.max_iter, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
-    else if( m.maxrg > RKFD_PGS_DPP_MAX && nc > RKFD_PGS_DPP_MAX && !( m.mlcp_mfma & 8 ) && rkfd_pgs_grouped<pk>( m, L, (unsigned char *)L.AC, nc, ld, dt ) ){
-      /* (several independent bodies in contact: their Gauss-Seidel sequences run side by side, one DPP row each; the link
-       * accelerations' storage is free between the bias vector and the delta sweep) */
+    else if( gfills >= 0 ){
+      /* (several independent bodies in contact: their Gauss-Seidel sequences run side by side, one DPP row each) */
+      rkfd_pgs_grouped<pk>( m, L, (const unsigned char *)L.AC, gfills, ld, dt );
       grouped = true;
     }
     else rkfd_pgs_general<pk>( L.MA, r0, ld, nc, m.max_iter, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
