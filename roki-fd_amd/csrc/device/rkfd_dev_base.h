@@ -21,6 +21,7 @@
 #  define LDS_FENCE()   rkfd_emu_sync()
 #  define RKFD_SCHED_BARRIER() do{}while(0)
 #  define BCAST(x,l)    rkfd_emu_bcast(x,l)
+#  define BCASTI(x,l)   ( (int)rkfd_emu_bcast( (double)(x), l ) )
 #  define BALLOT(p)     rkfd_emu_ballot(p)
    double rkfd_emu_wsum(double x);
    double rkfd_emu_wmin(double x);
@@ -119,6 +120,7 @@ template<int C> RKFD_DEV void rkfd_rowbc_fmac(double &acc, double x, double a)
 /* the instruction scheduler does not move anything across this point */
 #  define RKFD_SCHED_BARRIER() __builtin_amdgcn_sched_barrier( 0 )
 #  define BCAST(x,l)    rkfd_bcast(x,l)
+#  define BCASTI(x,l)   __builtin_amdgcn_readlane( (int)(x), l )      /* an int of lane l (wave-uniform l) */
 #  define BALLOT(p)     __ballot(p)
 /* sum / minimum over the whole wave in registers, the same value in every lane: the 8-lane DPP butterfly, then the eight
  * group results through v_readlane (no LDS, no barrier: ~100 cycles where a tree through LDS takes ~2000) */

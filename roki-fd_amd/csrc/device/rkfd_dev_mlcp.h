@@ -224,35 +224,34 @@ RKFD_DEV int rkfd_pgs_group_layout(const rkfdDevModel &m, const rkfdLds &L, unsi
     if( RKFD_CS_VALID( e0 ) ) t0 = RKFD_CS_TOP( e0 );
     if( NSD > 1 ){ const unsigned e1 = (unsigned)L.tgt[lane*NSD+1]; if( RKFD_CS_VALID( e1 ) ) t1 = RKFD_CS_TOP( e1 ); }
   }
-  /* connected components: label = the smallest contact index reachable (a few rounds of all-against-all) */
-  int label = lane < nc ? lane : 255;
-  for( int round=0; round<RKFD_WAVE; round++ ){
-    int nl = label;
-    for( int j=0; j<nc; j++ ){
-      const int u0 = (int)BCAST( (double)t0, j ), u1 = (int)BCAST( (double)t1, j ), lj = (int)BCAST( (double)label, j );
-      const bool share = ( t0 != 255 && ( t0 == u0 || t0 == u1 ) ) || ( t1 != 255 && ( t1 == u0 || t1 == u1 ) );
-      if( lane < nc && share && lj < nl ) nl = lj;
-    }
-    const bool ch = nl != label;
-    label = nl;
-    if( BALLOT( ch ) == 0ull ) break;
+  /* who shares a moving tree with whom: one bit per contact */
+  unsigned long long share = 0;
+  for( int j=0; j<nc; j++ ){
+    const int u0 = BCASTI( t0, j ), u1 = BCASTI( t1, j );
+    if( ( t0 != 255 && ( t0 == u0 || t0 == u1 ) ) || ( t1 != 255 && ( t1 == u0 || t1 == u1 ) ) || j == lane ) share |= 1ull << j;
   }
-  /* rows: every component (in the order of their first contacts) goes to the row that is emptiest so far - a sweep is as long as
-   * the fullest row */
-  unsigned long long leaders = BALLOT( lane < nc && label == lane );
+  /* connected components by closure, in scalar arithmetic (the masks of the members come through v_readlane), in the order of
+   * their first contacts; every component goes to the row that is emptiest so far - a sweep is as long as the fullest row */
+  unsigned long long remaining = nc >= 64 ? ~0ull : ( ( 1ull << nc ) - 1ull );
   int f0 = 0, f1_ = 0, f2_ = 0, f3 = 0, maxlen = 0, target = -1;
   bool fits = true;
-  while( leaders ){
-    const int ld_ = __builtin_ctzll( leaders );
-    leaders &= leaders - 1ull;
-    const unsigned long long mk = BALLOT( lane < nc && label == ld_ );
-    const int size = __builtin_popcountll( mk );
+  while( remaining ){
+    unsigned long long comp = 1ull << __builtin_ctzll( remaining ), frontier = comp;
+    while( frontier ){
+      const int j = __builtin_ctzll( frontier );
+      frontier &= frontier - 1ull;
+      const unsigned long long mj = ( (unsigned long long)(unsigned)BCASTI( (int)( share >> 32 ), j ) << 32 ) | (unsigned)BCASTI( (int)( share & 0xffffffffull ), j );
+      const unsigned long long nb = mj & ~comp & remaining;
+      comp |= nb; frontier |= nb;
+    }
+    remaining &= ~comp;
+    const int size = __builtin_popcountll( comp );
     int row = 0, fill = f0;
     if( f1_ < fill ){ row = 1; fill = f1_; }
     if( f2_ < fill ){ row = 2; fill = f2_; }
     if( f3 < fill ){ row = 3; fill = f3; }
     if( fill + size > 16 ){ fits = false; break; }
-    if( lane < nc && label == ld_ ) target = 16*row + fill + __builtin_popcountll( mk & below );
+    if( ( comp >> lane ) & 1ull ) target = 16*row + fill + __builtin_popcountll( comp & below );
     fill += size;
     if( row == 0 ) f0 = fill; else if( row == 1 ) f1_ = fill; else if( row == 2 ) f2_ = fill; else f3 = fill;
     if( fill > maxlen ) maxlen = fill;
