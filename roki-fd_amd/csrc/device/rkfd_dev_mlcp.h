@@ -198,10 +198,13 @@ template<bool pk, int C0> RKFD_DEV void rkfd_pgs_grp_tangent(const double *MA, c
     const double fnorm = ff0*ff0 + ff1*ff1;
     const bool zero = fnorm < RKFD_DEV_TOL || fs < RKFD_DEV_TOL;
     double n1 = zero ? 0.0 : ff0, n2 = zero ? 0.0 : ff1;
-    /* (the lanes at position C0 of the rows decide for themselves: no wave-uniform branch here) */
-    if( !zero && fnorm > fs ){
+    /* the lanes at position C0 of the rows decide for themselves; the branch stays wave-uniform (is any of them sliding?) and the
+     * lanes select: a per-lane branch would rewrite EXEC right in front of the DPP instructions below, which sit in inline asm where
+     * the compiler does not see that they need their wait states after an EXEC write */
+    const bool sl = !zero && fnorm > fs;
+    if( BALLOT( sl && pos == C0 ) != 0ull ){
       const double sc = fs*RKFD_RCP( fnorm );
-      n1 = ff0*sc; n2 = ff1*sc;
+      n1 = sl ? ff0*sc : n1; n2 = sl ? ff1*sc : n2;
     }
     const double d1 = n1 - f1, d2 = n2 - f2;
     if( pos == C0 ){ f1 = n1; f2 = n2; }
@@ -224,25 +227,29 @@ RKFD_DEV int rkfd_pgs_group_layout(const rkfdDevModel &m, const rkfdLds &L, unsi
     if( RKFD_CS_VALID( e0 ) ) t0 = RKFD_CS_TOP( e0 );
     if( NSD > 1 ){ const unsigned e1 = (unsigned)L.tgt[lane*NSD+1]; if( RKFD_CS_VALID( e1 ) ) t1 = RKFD_CS_TOP( e1 ); }
   }
-  /* who shares a moving tree with whom: one bit per contact */
-  unsigned long long share = 0;
-  for( int j=0; j<nc; j++ ){
-    const int u0 = BCASTI( t0, j ), u1 = BCASTI( t1, j );
-    if( ( t0 != 255 && ( t0 == u0 || t0 == u1 ) ) || ( t1 != 255 && ( t1 == u0 || t1 == u1 ) ) || j == lane ) share |= 1ull << j;
-  }
-  /* connected components by closure, in scalar arithmetic (the masks of the members come through v_readlane), in the order of
-   * their first contacts; every component goes to the row that is emptiest so far - a sweep is as long as the fullest row */
+  /* the moving trees of this lane's contact as a bit mask over the links (a tree is named by its top link, < 64) */
+  const unsigned long long trees = ( t0 != 255 ? 1ull << t0 : 0ull ) | ( t1 != 255 ? 1ull << t1 : 0ull );
+  const int trlo = (int)( trees & 0xffffffffull ), trhi = (int)( trees >> 32 );
+  /* connected components, in the order of their first contacts: grow a set of trees T from the first contact left - the contacts
+   * touching T (one ballot), their trees (v_readlane, every contact once) - until it stops growing; every component goes to the
+   * row that is emptiest so far: a sweep is as long as the fullest row */
   unsigned long long remaining = nc >= 64 ? ~0ull : ( ( 1ull << nc ) - 1ull );
   int f0 = 0, f1_ = 0, f2_ = 0, f3 = 0, maxlen = 0, target = -1;
   bool fits = true;
   while( remaining ){
-    unsigned long long comp = 1ull << __builtin_ctzll( remaining ), frontier = comp;
-    while( frontier ){
-      const int j = __builtin_ctzll( frontier );
-      frontier &= frontier - 1ull;
-      const unsigned long long mj = ( (unsigned long long)(unsigned)BCASTI( (int)( share >> 32 ), j ) << 32 ) | (unsigned)BCASTI( (int)( share & 0xffffffffull ), j );
-      const unsigned long long nb = mj & ~comp & remaining;
-      comp |= nb; frontier |= nb;
+    const int seed = __builtin_ctzll( remaining );
+    unsigned long long T = ( (unsigned long long)(unsigned)BCASTI( trhi, seed ) << 32 ) | (unsigned)BCASTI( trlo, seed );
+    unsigned long long comp = 1ull << seed, seen = comp;
+    for(;;){
+      const unsigned long long members = BALLOT( lane < nc && ( trees & T ) != 0ull ) & remaining;
+      unsigned long long fresh = members & ~seen;
+      comp |= members; seen |= members;
+      if( !fresh ) break;
+      while( fresh ){
+        const int j = __builtin_ctzll( fresh );
+        fresh &= fresh - 1ull;
+        T |= ( (unsigned long long)(unsigned)BCASTI( trhi, j ) << 32 ) | (unsigned)BCASTI( trlo, j );
+      }
     }
     remaining &= ~comp;
     const int size = __builtin_popcountll( comp );
@@ -546,10 +553,11 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
   SYNC();
   /* many contacts on several independent bodies: the grouped layout (rkfd_pgs_group_layout) serves the matrix build and the
    * Gauss-Seidel below; its table lives in the link accelerations' storage, free from here to the delta sweep */
+  MST(14);
   int gfills = -1;
   if( !vert && m.maxrg > RKFD_PGS_DPP_MAX && nc > RKFD_PGS_DPP_MAX && !( m.mlcp_mfma & 8 ) )
     gfills = rkfd_pgs_group_layout( m, L, (unsigned char *)L.AC, nc );
-  MST(14);
+  MST(31);
   /* probes: lane = column k = 3c+i; unit force along axis i at contact c, applied to the
    * owner link (+) and the other link (-).  Every level between the contact link and the top of
    * its path carries a 1-DoF joint; the operands of the next level are fetched while this one is
