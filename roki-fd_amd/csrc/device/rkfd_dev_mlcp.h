@@ -161,7 +161,7 @@ template<bool pk> RKFD_DEV int rkfd_ma_idx2(int row, int rb, int col, int cbase,
   if( !pk ) return row*ld + col;
   return col <= row ? rb + col : cbase + row;
 }
-template<bool pk, int C0> RKFD_DEV void rkfd_pgs_grp_normal(const double *MA, const unsigned *gw, int r0, const int *rb, int ld, int maxlen, int pos, double in_,
+template<bool pk, int C0> RKFD_DEV void rkfd_pgs_grp_normal(const double *MA, const unsigned *gw, int kfb, int r0, const int *rb, int ld, int maxlen, int pos, double in_,
                                                             double &rn, double &r1, double &r2, double &fn)
 {
   /* (blocks of two: the entries of the second update are in flight while the first runs - measured 1.71 M against 1.62 M
@@ -169,8 +169,12 @@ template<bool pk, int C0> RKFD_DEV void rkfd_pgs_grp_normal(const double *MA, co
   double a0[2], a1[2], a2[2];
 #pragma unroll
   for( int u=0; u<2; u++ ){
+    /* an empty position broadcasts a zero increment, but 0 x NaN is NaN: the entry must be one that was WRITTEN, and only the
+     * blocks within a row are (kfb: this lane's own contact, or -1 on a lane without one, which takes entry ( 0, 0 ) whatever
+     * the position holds and so stays finite, its own increments exact zeros) */
     int kc = RKFD_GRP_POS( gw, C0+u );
-    if( kc == 255 ) kc = 0;                        /* (an empty position broadcasts a zero increment: any entry will do) */
+    if( kc == 255 ) kc = kfb;
+    if( kfb < 0 ) kc = 0;
     const int c3 = 3*kc, cb = ( c3*( c3+1 ) ) >> 1;
     a0[u] = MA[rkfd_ma_idx2<pk>( r0, rb[0], c3, cb, ld )]; a1[u] = MA[rkfd_ma_idx2<pk>( r0+1, rb[1], c3, cb, ld )]; a2[u] = MA[rkfd_ma_idx2<pk>( r0+2, rb[2], c3, cb, ld )];
   }
@@ -185,12 +189,13 @@ template<bool pk, int C0> RKFD_DEV void rkfd_pgs_grp_normal(const double *MA, co
   RKFD_PGS_GN(0) RKFD_PGS_GN(1)
 #undef RKFD_PGS_GN
 }
-template<bool pk, int C0> RKFD_DEV void rkfd_pgs_grp_tangent(const double *MA, const unsigned *gw, int r0, const int *rb, int ld, int maxlen, int pos, double i1, double i2, double fs,
+template<bool pk, int C0> RKFD_DEV void rkfd_pgs_grp_tangent(const double *MA, const unsigned *gw, int kfb, int r0, const int *rb, int ld, int maxlen, int pos, double i1, double i2, double fs,
                                                              double &rn, double &r1, double &r2, double &f1, double &f2)
 {
   if( C0 < maxlen ){
     int kc = RKFD_GRP_POS( gw, C0 );
-    if( kc == 255 ) kc = 0;
+    if( kc == 255 ) kc = kfb;
+    if( kfb < 0 ) kc = 0;
     const int c1 = 3*kc+1, c2 = c1+1, cb1 = ( c1*c2 ) >> 1, cb2 = cb1 + c2;      /* c ( c + 1 ) / 2 of the two tangential columns */
     const double a0 = MA[rkfd_ma_idx2<pk>( r0, rb[0], c1, cb1, ld )], a1 = MA[rkfd_ma_idx2<pk>( r0+1, rb[1], c1, cb1, ld )], a2 = MA[rkfd_ma_idx2<pk>( r0+2, rb[2], c1, cb1, ld )];
     const double b0 = MA[rkfd_ma_idx2<pk>( r0, rb[0], c2, cb2, ld )], b1 = MA[rkfd_ma_idx2<pk>( r0+1, rb[1], c2, cb2, ld )], b2 = MA[rkfd_ma_idx2<pk>( r0+2, rb[2], c2, cb2, ld )];
@@ -282,7 +287,7 @@ template<bool pk> RKFD_DEV void rkfd_pgs_grouped(const rkfdDevModel &m, const rk
   /* this lane's contact in the new layout */
   const int k = tab[lane];
   const bool on = k != 255;
-  const int r0 = on ? 3*k : 0, pos = lane & 15;
+  const int r0 = on ? 3*k : 0, pos = lane & 15, kfb = on ? k : -1;
   unsigned gw[4];        /* this lane's row of the table: 16 positions, one byte each */
   {
     const unsigned *g32 = (const unsigned *)&tab[lane & 48];
@@ -306,11 +311,11 @@ template<bool pk> RKFD_DEV void rkfd_pgs_grouped(const rkfdDevModel &m, const rk
      * updates out of the sweep loop and spills hundreds of registers) */
     asm volatile( "" : "+v"(gw[0]), "+v"(gw[1]), "+v"(gw[2]), "+v"(gw[3]) );
 #endif
-#define RKFD_PGS_GNB(C0) if( maxlen > C0 ) rkfd_pgs_grp_normal<pk, C0>( L.MA, gw, r0, rb, ld, maxlen, pos, in_, rn, r1, r2, fn );
+#define RKFD_PGS_GNB(C0) if( maxlen > C0 ) rkfd_pgs_grp_normal<pk, C0>( L.MA, gw, kfb, r0, rb, ld, maxlen, pos, in_, rn, r1, r2, fn );
     RKFD_PGS_GNB(0) RKFD_PGS_GNB(2) RKFD_PGS_GNB(4) RKFD_PGS_GNB(6) RKFD_PGS_GNB(8) RKFD_PGS_GNB(10) RKFD_PGS_GNB(12) RKFD_PGS_GNB(14)
 #undef RKFD_PGS_GNB
     double fs = mu*fn; fs = fs*fs;
-#define RKFD_PGS_GTB(C0) rkfd_pgs_grp_tangent<pk, C0>( L.MA, gw, r0, rb, ld, maxlen, pos, i1, i2, fs, rn, r1, r2, f1, f2 );
+#define RKFD_PGS_GTB(C0) rkfd_pgs_grp_tangent<pk, C0>( L.MA, gw, kfb, r0, rb, ld, maxlen, pos, i1, i2, fs, rn, r1, r2, f1, f2 );
     RKFD_PGS_GTB(0) RKFD_PGS_GTB(1) RKFD_PGS_GTB(2) RKFD_PGS_GTB(3) RKFD_PGS_GTB(4) RKFD_PGS_GTB(5) RKFD_PGS_GTB(6) RKFD_PGS_GTB(7)
     RKFD_PGS_GTB(8) RKFD_PGS_GTB(9) RKFD_PGS_GTB(10) RKFD_PGS_GTB(11) RKFD_PGS_GTB(12) RKFD_PGS_GTB(13) RKFD_PGS_GTB(14) RKFD_PGS_GTB(15)
 #undef RKFD_PGS_GTB

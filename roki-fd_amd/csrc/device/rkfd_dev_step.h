@@ -143,6 +143,10 @@ template<bool prof, int vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDevM
   rkfdLds L;
   rkfd_lds_carve( &L, ldsbase, NL, ND, NC, 3*m.maxrg, m.nlevel, m.npool, m.nfloat, m.maxact, m.nside, m.pu_alias, m.npurow, m.vert_rigid, m.has_slide, m.ma_size,
                   vqp == 2 ? m.vol_np : 0, m.vol_ncp, m.vol_pv, m.vol_nf, m.pyramid );
+  if( m.lds_poison > 0 ){      /* (RKFD_DEBUG_POISON_LDS: see rkfd_devmodel.h) */
+    for( int i=lane; i<m.lds_poison; i+=RKFD_WAVE ) ( (unsigned *)ldsbase )[i] = 0xffffffffu;
+    SYNC();
+  }
   if( lane == 0 ){
     L.cnt[CNT_OVF] = 0; L.cnt[CNT_QPF] = 0;
     if( NC > 0 ){ L.cnt[CNT_SRG] = 0; L.cnt[CNT_SEL] = 0; L.cnt[CNT_SN] = 0; }

@@ -642,6 +642,7 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
                NL, ND, NC, nlevel, npool, nfloat, maxact, nside, npurow, dm.pu_alias, (int)M, stage, (size_t)14*NL + pool, dm.vert_rigid, out->lds_bytes );
   }
   out->dm.ma_packed = dm.ma_packed; out->dm.ma_size = dm.ma_size;
+  { const char *e = getenv( "RKFD_DEBUG_POISON_LDS" ); out->dm.lds_poison = ( e && atoi( e ) > 0 ) ? (int)( out->lds_bytes/4 ) : 0; }
   return 0;
 #undef FAIL
 }

@@ -38,6 +38,8 @@ typedef struct {
                             RKFD_VERT_MFMA=0 switches it off): the Vert QP's Q = A'A likewise - the one product where it pays;
                             bit 3 (RKFD_PGS_GROUPED=0): the grouped Gauss-Seidel of rkfd_dev_mlcp.h switched off (A/B test);
                             measurement switch RKFD_MLCP_MFMA, see DESIGN.md "MFMA") */
+  int lds_poison;        /* debugging switch RKFD_DEBUG_POISON_LDS=1: 4-byte words of LDS every instance fills with all ones (NaN / -1) before it
+                            starts, so that a read of storage nobody wrote shows in the results whatever ran on the CU before; 0: off */
   /* Volume plugin (solver == RKFD_SOLVER_VOLUME and rigid pairs exist; device/rkfd_dev_volume.h) */
   int vol_npair;         /* rigid pairs of the model */
   int vol_np;            /* capacity: pairs in collision at once (6 vol_np <= 64 unknowns)                     */

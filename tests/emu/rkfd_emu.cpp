@@ -96,7 +96,9 @@ extern "C" int rkfd_emu_run(const rkfdModel *m, int max_rigid, rkfdDevState *st,
   for( int b=0; b<st->batch; b++ ){
     std::barrier<> bar( 64 );
     g_bar = &bar;
-    std::memset( lds.data(), 0, lds.size() );
+    /* LDS is NOT cleared on the GPU: poison it (all ones: NaN as a double, -1 as an int), so that a read of storage nobody wrote
+     * shows here instead of depending on what the previous kernel on the box left behind */
+    std::memset( lds.data(), 0xFF, lds.size() );
     std::vector<std::thread> th;
     for( int l=0; l<64; l++ )
       th.emplace_back( [&, l](){ t_lane = l;

@@ -54,4 +54,4 @@ def test_volume_kernel_resources():
     is worth more than the registers it spills); keep the spill count from growing unnoticed"""
     k = _kernels()["rkfd_step_kernel_vol"]
     assert k["Occupancy"] >= 2, k
-    assert k["VGPRs Spill"] <= 128 and k["ScratchSize"] <= 512, k
+    assert k["VGPRs Spill"] <= 160 and k["ScratchSize"] <= 512, k
