@@ -241,6 +241,9 @@ RKFD_DEV int rkfd_pgs_group_layout(const rkfdDevModel &m, const rkfdLds &L, unsi
   unsigned long long remaining = nc >= 64 ? ~0ull : ( ( 1ull << nc ) - 1ull );
   int f0 = 0, f1_ = 0, f2_ = 0, f3 = 0, maxlen = 0, target = -1;
   bool fits = true;
+  /* lane i keeps component i (every component holds a contact: there are at most 64) */
+  unsigned long long mycomp = 0ull;
+  int ncomp = 0;
   while( remaining ){
     const int seed = __builtin_ctzll( remaining );
     unsigned long long T = ( (unsigned long long)(unsigned)BCASTI( trhi, seed ) << 32 ) | (unsigned)BCASTI( trlo, seed );
@@ -257,16 +260,31 @@ RKFD_DEV int rkfd_pgs_group_layout(const rkfdDevModel &m, const rkfdLds &L, unsi
       }
     }
     remaining &= ~comp;
-    const int size = __builtin_popcountll( comp );
-    int row = 0, fill = f0;
-    if( f1_ < fill ){ row = 1; fill = f1_; }
-    if( f2_ < fill ){ row = 2; fill = f2_; }
-    if( f3 < fill ){ row = 3; fill = f3; }
-    if( fill + size > 16 ){ fits = false; break; }
-    if( ( comp >> lane ) & 1ull ) target = 16*row + fill + __builtin_popcountll( comp & below );
-    fill += size;
-    if( row == 0 ) f0 = fill; else if( row == 1 ) f1_ = fill; else if( row == 2 ) f2_ = fill; else f3 = fill;
-    if( fill > maxlen ) maxlen = fill;
+    if( lane == ncomp ) mycomp = comp;
+    ncomp++;
+  }
+  /* rows: the largest components first (equal ones in the order found), each to the row that is emptiest so far - a sweep is as
+   * long as the fullest row (config 5 standing: the boxes' contacts come before the humanoid's in the candidate order; first
+   * come first served made rows of 12 4 4 4, largest first makes 8 8 4 4) */
+  const int mysize = __builtin_popcountll( mycomp );
+  const int mclo = (int)( mycomp & 0xffffffffull ), mchi = (int)( mycomp >> 32 );
+  if( BALLOT( mysize > 16 ) != 0ull ) return -1;
+  for( int sz=16; sz>=1 && fits; sz-- ){
+    unsigned long long todo = BALLOT( mysize == sz );
+    while( todo ){
+      const int j = __builtin_ctzll( todo );
+      todo &= todo - 1ull;
+      const unsigned long long comp = ( (unsigned long long)(unsigned)BCASTI( mchi, j ) << 32 ) | (unsigned)BCASTI( mclo, j );
+      int row = 0, fill = f0;
+      if( f1_ < fill ){ row = 1; fill = f1_; }
+      if( f2_ < fill ){ row = 2; fill = f2_; }
+      if( f3 < fill ){ row = 3; fill = f3; }
+      if( fill + sz > 16 ){ fits = false; break; }
+      if( ( comp >> lane ) & 1ull ) target = 16*row + fill + __builtin_popcountll( comp & below );
+      fill += sz;
+      if( row == 0 ) f0 = fill; else if( row == 1 ) f1_ = fill; else if( row == 2 ) f2_ = fill; else f3 = fill;
+      if( fill > maxlen ) maxlen = fill;
+    }
   }
   (void)maxlen;
   if( !fits ) return -1;
@@ -318,6 +336,97 @@ template<bool pk> RKFD_DEV void rkfd_pgs_grouped(const rkfdDevModel &m, const rk
 #define RKFD_PGS_GTB(C0) rkfd_pgs_grp_tangent<pk, C0>( L.MA, gw, kfb, r0, rb, ld, maxlen, pos, i1, i2, fs, rn, r1, r2, f1, f2 );
     RKFD_PGS_GTB(0) RKFD_PGS_GTB(1) RKFD_PGS_GTB(2) RKFD_PGS_GTB(3) RKFD_PGS_GTB(4) RKFD_PGS_GTB(5) RKFD_PGS_GTB(6) RKFD_PGS_GTB(7)
     RKFD_PGS_GTB(8) RKFD_PGS_GTB(9) RKFD_PGS_GTB(10) RKFD_PGS_GTB(11) RKFD_PGS_GTB(12) RKFD_PGS_GTB(13) RKFD_PGS_GTB(14) RKFD_PGS_GTB(15)
+#undef RKFD_PGS_GTB
+  }
+  if( on ){ L.MF[r0] = fn/dt; L.MF[r0+1] = f1/dt; L.MF[r0+2] = f2/dt; }
+}
+
+/* SWEEP-ORDER storage of the blocks inside the rows (rows of at most 8 contacts: config 5's 8 + 8 + 8).  The grouped solve above
+ * spends more instructions on WHERE an entry of the packed triangle lives (50 integer VALU operations per update, from the
+ * position table to the triangle index) than on the update itself (17 fp64 operations) - and at one wave per SIMD (53 KB of LDS
+ * per instance) nothing hides them.  When the fullest row has at most 8 contacts the matrix build stores, instead of the
+ * triangle, for every lane of the new layout and every position c of its row the nine entries ( rows of the lane's contact ) x
+ * ( columns of the contact at position c ) at  SW[ ( 9 c + 3 j + i ) * 32 + slot ],  slot = 8 * row + position of the lane:
+ * the solve then reads with ONE address register per lane and literal offsets, no table, no index arithmetic; lanes of one
+ * read are 8 bytes apart.  8 * 9 * 32 doubles = 18 KB, less than the packed triangle of 72 rows (21 KB).  Positions a row does
+ * not fill hold zeros (the whole array is cleared before the build): their zero increments meet 0, not storage nobody wrote. */
+#define RKFD_SW_SLOTS 32
+#define RKFD_SW_MAXLEN 8
+#define RKFD_SW_DOUBLES ( RKFD_SW_MAXLEN*9*RKFD_SW_SLOTS )
+#define RKFD_SW_AT(c, j, i) ( ( 9*(c) + 3*(j) + (i) )*RKFD_SW_SLOTS )
+template<int C0> RKFD_DEV void rkfd_pgs_sw_normal(const double *SWl, int maxlen, int pos, double in_, double &rn, double &r1, double &r2, double &fn)
+{
+  double a0[2], a1[2], a2[2];
+#pragma unroll
+  for( int u=0; u<2; u++ ){ a0[u] = SWl[RKFD_SW_AT( C0+u, 0, 0 )]; a1[u] = SWl[RKFD_SW_AT( C0+u, 0, 1 )]; a2[u] = SWl[RKFD_SW_AT( C0+u, 0, 2 )]; }
+#define RKFD_PGS_GN(u) \
+  if( C0+u < maxlen ){ \
+    double ff = fn - rn*in_; \
+    if( ff < RKFD_DEV_TOL ) ff = 0.0; \
+    const double dl = ff - fn; \
+    if( pos == C0+u ) fn = ff; \
+    ROWBC_FMAC( C0+u, rn, dl, a0[u] ); ROWBC_FMAC( C0+u, r1, dl, a1[u] ); ROWBC_FMAC( C0+u, r2, dl, a2[u] ); \
+  }
+  RKFD_PGS_GN(0) RKFD_PGS_GN(1)
+#undef RKFD_PGS_GN
+}
+template<int C0> RKFD_DEV void rkfd_pgs_sw_tangent(const double *SWl, int maxlen, int pos, double i1, double i2, double fs,
+                                                   double &rn, double &r1, double &r2, double &f1, double &f2)
+{
+  if( C0 < maxlen ){
+    const double a0 = SWl[RKFD_SW_AT( C0, 1, 0 )], a1 = SWl[RKFD_SW_AT( C0, 1, 1 )], a2 = SWl[RKFD_SW_AT( C0, 1, 2 )];
+    const double b0 = SWl[RKFD_SW_AT( C0, 2, 0 )], b1 = SWl[RKFD_SW_AT( C0, 2, 1 )], b2 = SWl[RKFD_SW_AT( C0, 2, 2 )];
+    const double ff0 = f1 - r1*i1, ff1 = f2 - r2*i2;
+    const double fnorm = ff0*ff0 + ff1*ff1;
+    const bool zero = fnorm < RKFD_DEV_TOL || fs < RKFD_DEV_TOL;
+    double n1 = zero ? 0.0 : ff0, n2 = zero ? 0.0 : ff1;
+    const bool sl = !zero && fnorm > fs;       /* (wave-uniform branch, lanes select: see rkfd_pgs_grp_tangent) */
+    if( BALLOT( sl && pos == C0 ) != 0ull ){
+      const double sc = fs*RKFD_RCP( fnorm );
+      n1 = sl ? ff0*sc : n1; n2 = sl ? ff1*sc : n2;
+    }
+    const double d1 = n1 - f1, d2 = n2 - f2;
+    if( pos == C0 ){ f1 = n1; f2 = n2; }
+    ROWBC_FMAC( C0, rn, d2, b0 ); ROWBC_FMAC( C0, r1, d2, b1 ); ROWBC_FMAC( C0, r2, d2, b2 );
+    ROWBC_FMAC( C0, rn, d1, a0 ); ROWBC_FMAC( C0, r1, d1, a1 ); ROWBC_FMAC( C0, r2, d1, a2 );
+  }
+}
+/* the solve on the sweep-order storage (L.MA holds SW).  Same updates in the same order as rkfd_pgs_grouped.  Writes MF itself. */
+RKFD_DEV void rkfd_pgs_grouped_sw(const rkfdDevModel &m, const rkfdLds &L, const unsigned char *tab, int maxlen, double dt)
+{
+  const int lane = LANE();
+  const int k = tab[lane];
+  const bool on = k != 255;
+  const int r0 = on ? 3*k : 0, pos = lane & 15;
+  /* (a lane without a contact beyond position 7 has no slot: it reads slot 0, finite numbers, and its own increments stay exact
+   * zeros because its inverse diagonals are zero) */
+  int soff = pos < RKFD_SW_MAXLEN ? RKFD_SW_MAXLEN*( lane >> 4 ) + pos : 0;
+  double rn = 0, r1 = 0, r2 = 0, fn = 0, f1 = 0, f2 = 0, in_ = 0, i1 = 0, i2 = 0, mu = 0;
+  if( on ){
+    rn = L.MB[r0]; r1 = L.MB[r0+1]; r2 = L.MB[r0+2];
+    const double *dg = L.MA + soff + 9*pos*RKFD_SW_SLOTS;
+    const double dn = dg[RKFD_SW_AT( 0, 0, 0 )], d1 = dg[RKFD_SW_AT( 0, 1, 1 )], d2 = dg[RKFD_SW_AT( 0, 2, 2 )];
+    in_ = 1.0/dn;
+    i1 = fabs( d1 ) < RKFD_DEV_TOL ? 0.0 : 1.0/d1;
+    i2 = fabs( d2 ) < RKFD_DEV_TOL ? 0.0 : 1.0/d2;
+    const int jr_ = L.lrg[k], cir_ = RKFD_CI_CI( L.CIp[jr_] );
+    mu = L.typ[jr_] == RKFD_SF ? m.ci_sf[cir_] : m.ci_kf[cir_];
+  }
+  SYNC();       /* (MF shares its storage with MB in these kernels: everybody has read b before anybody writes f) */
+  for( int it=0; it<m.max_iter; it++ ){
+#ifndef RKFD_EMU
+    /* (the address is re-read through an opaque asm every sweep: the entries do not change between sweeps, and the compiler
+     * would otherwise keep all 72 of them in registers it does not have) */
+    asm volatile( "" : "+v"(soff) );
+#endif
+    const double *SWl = L.MA + soff;
+    rkfd_pgs_sw_normal<0>( SWl, maxlen, pos, in_, rn, r1, r2, fn );
+    if( maxlen > 2 ) rkfd_pgs_sw_normal<2>( SWl, maxlen, pos, in_, rn, r1, r2, fn );
+    if( maxlen > 4 ) rkfd_pgs_sw_normal<4>( SWl, maxlen, pos, in_, rn, r1, r2, fn );
+    if( maxlen > 6 ) rkfd_pgs_sw_normal<6>( SWl, maxlen, pos, in_, rn, r1, r2, fn );
+    double fs = mu*fn; fs = fs*fs;
+#define RKFD_PGS_GTB(C0) rkfd_pgs_sw_tangent<C0>( SWl, maxlen, pos, i1, i2, fs, rn, r1, r2, f1, f2 );
+    RKFD_PGS_GTB(0) RKFD_PGS_GTB(1) RKFD_PGS_GTB(2) RKFD_PGS_GTB(3) RKFD_PGS_GTB(4) RKFD_PGS_GTB(5) RKFD_PGS_GTB(6) RKFD_PGS_GTB(7)
 #undef RKFD_PGS_GTB
   }
   if( on ){ L.MF[r0] = fn/dt; L.MF[r0+1] = f1/dt; L.MF[r0+2] = f2/dt; }
@@ -562,6 +671,15 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
   int gfills = -1;
   if( !vert && m.maxrg > RKFD_PGS_DPP_MAX && nc > RKFD_PGS_DPP_MAX && !( m.mlcp_mfma & 8 ) )
     gfills = rkfd_pgs_group_layout( m, L, (unsigned char *)L.AC, nc );
+  /* fullest row; rows of at most 8: the blocks go to the sweep-order storage (rkfd_pgs_grouped_sw) */
+  int gmaxlen = 0;
+  if( gfills >= 0 ){
+    gmaxlen = gfills & 255;
+    if( ( ( gfills >> 8 ) & 255 ) > gmaxlen ) gmaxlen = ( gfills >> 8 ) & 255;
+    if( ( ( gfills >> 16 ) & 255 ) > gmaxlen ) gmaxlen = ( gfills >> 16 ) & 255;
+    if( ( ( gfills >> 24 ) & 255 ) > gmaxlen ) gmaxlen = ( gfills >> 24 ) & 255;
+  }
+  const bool sw = gfills >= 0 && gmaxlen <= RKFD_SW_MAXLEN && m.ma_size >= RKFD_SW_DOUBLES && !( m.mlcp_mfma & 32 );
   MST(31);
   /* probes: lane = column k = 3c+i; unit force along axis i at contact c, applied to the
    * owner link (+) and the other link (-).  Every level between the contact link and the top of
@@ -643,10 +761,16 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
   if( !pk && ( m.mlcp_mfma & 1 ) && M <= 32 ) rkfd_mlcp_matrix_mfma( m, L, nc, ld, vert );
   else
 #endif
+  {
+  if( sw ){
+    for( int i=lane; i<9*RKFD_SW_SLOTS*gmaxlen; i+=RKFD_WAVE ) L.MA[i] = 0.0;
+    SYNC();
+  }
   /* A, one 3x3 block per lane and pass: block ( cr, ck <= cr ) and its mirror image */
   for( int e0=0; e0<nblk; e0+=RKFD_WAVE ){
     const int e = e0 + lane;
     int cr, ck; bool one;
+    int swr = 0, swk = 0, posr = 0, posk = 0;      /* sweep-order storage: slots and positions of the two contacts */
     if( gfills >= 0 ){
       const unsigned char *tab = (const unsigned char *)L.AC;
       const int row = e < gb1 ? 0 : ( e < gb2 ? 1 : ( e < gb3 ? 2 : 3 ) );
@@ -658,6 +782,8 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
       one = e < gb4;
       const int ka = one ? tab[16*row+a] : 0, kb = one ? tab[16*row+b] : 0;
       cr = ka > kb ? ka : kb; ck = ka > kb ? kb : ka;
+      posr = ka > kb ? a : b; posk = ka > kb ? b : a;
+      swr = RKFD_SW_MAXLEN*row + posr; swk = RKFD_SW_MAXLEN*row + posk;
     } else if( pk ){
       /* (the packed-matrix kernels serve the worlds with many contacts: lane = block of the lower triangle counted row by row, so
        * that every lane of a pass has one - 24 contacts: 5 passes instead of 9) */
@@ -710,6 +836,18 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
         const double rl = m.ci_l[RKFD_CI_CI( L.CIp[L.lrg[cr]] )];
         blk[0] += rl; blk[4] += rl; blk[8] += rl;
       }
+      if( sw ){
+        /* entry ( i, q ) of the block belongs to the lane of cr at the position of ck, and - transposed - to the lane of ck at the
+         * position of cr */
+        double *wr = L.MA + 9*posk*RKFD_SW_SLOTS + swr, *wk = L.MA + 9*posr*RKFD_SW_SLOTS + swk;
+#pragma unroll
+        for( int i=0; i<3; i++ )
+#pragma unroll
+          for( int q=0; q<3; q++ ){
+            wr[RKFD_SW_AT( 0, q, i )] = blk[3*i+q];
+            if( cr != ck ) wk[RKFD_SW_AT( 0, i, q )] = blk[3*i+q];
+          }
+      } else
 #pragma unroll
       for( int i=0; i<3; i++ )
 #pragma unroll
@@ -722,6 +860,7 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
           }
         }
     }
+  }
   }
   SYNC();
   MST(6);
@@ -784,7 +923,8 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
     else if( !pk && nc <= RKFD_PGS_DPP_MAX ) rkfd_pgs_dpp<pk>( L.MA, r0, ld, nc, m.maxrg, m.max_iter, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
     else if( gfills >= 0 ){
       /* (several independent bodies in contact: their Gauss-Seidel sequences run side by side, one DPP row each) */
-      rkfd_pgs_grouped<pk>( m, L, (const unsigned char *)L.AC, gfills, ld, dt );
+      if( sw ) rkfd_pgs_grouped_sw( m, L, (const unsigned char *)L.AC, gmaxlen, dt );
+      else rkfd_pgs_grouped<pk>( m, L, (const unsigned char *)L.AC, gfills, ld, dt );
       grouped = true;
     }
     else rkfd_pgs_general<pk>( L.MA, r0, ld, nc, m.max_iter, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );

@@ -542,6 +542,8 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   /* bit 3: the grouped Gauss-Seidel (independent bodies side by side in DPP rows) switched off - for the A/B test of its claim
    * that it reproduces the one-after-the-other loop bit for bit */
   { const char *e = getenv( "RKFD_PGS_GROUPED" ); if( e && atoi( e ) == 0 ) dm.mlcp_mfma |= 8; }
+  /* bit 5: the sweep-order storage of the grouped solve's matrix blocks switched off (the packed triangle instead; A/B test) */
+  { const char *e = getenv( "RKFD_PGS_SW" ); if( e && atoi( e ) == 0 ) dm.mlcp_mfma |= 32; }
   const size_t Mrows = 3*(size_t)max_rigid;
   /* probe scratch: one row per tree level plus six for a float root, per side; it overlays the
    * C|PA block of the link arrays (dead while the contact problem is solved) when it fits */

@@ -37,6 +37,7 @@ typedef struct {
                             bit 1 (switch RKFD_VERT_MFMA_S): the Vert QP's Schur complement S = W'W likewise; bit 2 (default on,
                             RKFD_VERT_MFMA=0 switches it off): the Vert QP's Q = A'A likewise - the one product where it pays;
                             bit 3 (RKFD_PGS_GROUPED=0): the grouped Gauss-Seidel of rkfd_dev_mlcp.h switched off (A/B test);
+                            bit 5 (RKFD_PGS_SW=0): its sweep-order matrix storage switched off (packed triangle instead; A/B test);
                             measurement switch RKFD_MLCP_MFMA, see DESIGN.md "MFMA") */
   int lds_poison;        /* debugging switch RKFD_DEBUG_POISON_LDS=1: 4-byte words of LDS every instance fills with all ones (NaN / -1) before it
                             starts, so that a read of storage nobody wrote shows in the results whatever ran on the CU before; 0: off */
