@@ -440,7 +440,9 @@ RKFD_DEV void d_load_axes(const rkfdLds &L, int slot, double *ax)
 }
 
 /* per-lane state that only lane = link ever touches: kept in registers for the whole launch */
-typedef struct { double min, pivp; int pivt; } rkfdLaneLink;
+typedef struct { double min, pivp; int pivt;
+  int dtask;   /* lane = coordinate: its link | component << 8 when the joint is a 1-DoF or a float joint, else -1 (the delta-sweep inputs) */
+} rkfdLaneLink;
 
 /* the stick anchors REF live per active-contact slot */
 #define RIDX(j) ( L.asl[j] )

@@ -597,7 +597,7 @@ RKFD_DEV void rkfd_mlcp_matrix_mfma(const rkfdDevModel &m, const rkfdLds &L, int
  * i.e. no per-column response walks and no second backward sweep; A comes out exactly
  * symmetric.  Output: contact forces CF, committed contact state, and the inputs of the delta
  * sweep (MS slot 1, U slot of float joints). */
-template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L, const double *bv, bool doUpRef, unsigned long long *pc)
+template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdDevModel &m, const rkfdLds &L, const double *bv, bool doUpRef, int dtask, unsigned long long *pc)
 {
   /* the Vert plugin's rigid branch (reference src/rkfd_vert.c:325-336) shares the contact system (A, b) and
    * the way the forces are applied; it differs in the solver (QP instead of PGS), in where the
@@ -614,7 +614,6 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
   const int PUS = NR*M;                               /* stride between the two sides of PU */
   const unsigned char *TOP = L.PL + NL*NLV;           /* where a force on a link stops propagating (255: static) */
   const unsigned char *FSL = TOP + NL;                /* float slot of a link */
-  const unsigned char *FLK = FSL + NL;                /* link of a float slot */
   const double dt = m.dt;
 
   /* b: free relative acceleration, then *dt + relative velocity + compensation
@@ -918,6 +917,10 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
      * general), 8 contacts 312 / 369 (DPP / general), 16 contacts 270 / 317.  Variants with fewer VALU instructions
      * (wave-uniform branches on the deciding lane instead of selects, one-lane moves under a narrowed EXEC) were
      * slower (8 contacts: 333): the VALU -> SALU -> branch round trips sit on the dependent path. */
+#ifdef RKFD_TRIM_PGS
+    if( gfills >= 0 && sw ){ rkfd_pgs_grouped_sw( m, L, (const unsigned char *)L.AC, gmaxlen, dt ); grouped = true; }
+    else rkfd_pgs_general<pk>( L.MA, r0, ld, nc, m.max_iter, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
+#else
     if( nc <= RKFD_PGS_NC ) rkfd_pgs_registers<pk>( L.MA, r0, ld, nc, m.max_iter, on, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
     else if( nc == 8 ) rkfd_pgs_dpp8<pk>( L.MA, r0, ld, m.max_iter, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
     else if( !pk && nc <= RKFD_PGS_DPP_MAX ) rkfd_pgs_dpp<pk>( L.MA, r0, ld, nc, m.maxrg, m.max_iter, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
@@ -928,6 +931,7 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
       grouped = true;
     }
     else rkfd_pgs_general<pk>( L.MA, r0, ld, nc, m.max_iter, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
+#endif
     if( on && !grouped ){ L.MF[r0] = fn/dt; L.MF[r0+1] = f1/dt; L.MF[r0+2] = f2/dt; }
   }
   SYNC();
@@ -956,35 +960,58 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
   }
   SYNC();
   MST(22);
-  /* inputs of the delta sweep, lane = link: what the solved forces F = MF do to the joint's
-   * innovation.  1-DoF joint: sum_k F_k nu_k / D  (= scaled sum times sqrt(1/D));  float joint:
-   * sum_k F_k y_k.  Links no contact path passes get 0. */
+  /* inputs of the delta sweep, lane = joint coordinate (dtask: its link and component, fixed for the launch): what the solved
+   * forces F = MF do to the joint's innovation.  1-DoF joint: sum_k F_k nu_k / D  (= scaled sum times sqrt(1/D));  float joint:
+   * sum_k F_k y_k, six components.  Links no contact path passes get 0. */
   {
-    const int ntask = NL + 6*m.nfloat;    /* one per link (used by those with a 1-DoF joint), then six per float joint */
-    for( int t0=0; t0<ntask; t0+=RKFD_WAVE ){
-      const int t = t0 + lane;
-      const bool isl = t < NL, isf = !isl && t < ntask;
-      const int fq = isf ? ( t-NL )%6 : 0;
-      const int link = isl ? t : ( isf ? FLK[( t-NL )/6] : 0 );
-      const int lii = L.LI[link], jt = RKFD_LI_JT( lii );
-      const bool is1 = isl && RKFD_JT_IS1( jt );
-      const int dpt = isl ? RKFD_LI_DEPTH( lii ) : 0;
-      const int row = isf ? NLV+fq : dpt;
-      double sum = 0;
-#pragma unroll 2
-      for( int cs=0; cs<nc*NSD; cs++ ){
-        const unsigned e = (unsigned)L.tgt[cs];
-        const int c = NSD == 1 ? cs : cs >> 1;
-        const double *pu = &L.PU[( NSD == 1 ? 0 : ( cs & 1 ) )*PUS + row*M + 3*c];
-        const double v = L.MF[3*c]*pu[0] + L.MF[3*c+1]*pu[1] + L.MF[3*c+2]*pu[2];
-        /* 1-DoF joint: it lies on the moving path of the contact side; float joint: the path ends there */
-        const bool onp = RKFD_CS_VALID( e ) && ( isf ? RKFD_CS_TOP( e ) == link
-                       : ( RKFD_CS_DEPTH( e ) >= dpt && RKFD_CS_D0( e ) <= dpt && L.PL[RKFD_CS_LINK( e )*NLV+dpt] == link ) );
-        sum += onp ? v : 0.0;
+    const bool has = dtask >= 0;
+    const int link = has ? dtask & 255 : 0, fq = has ? dtask >> 8 : 0;
+    const int lii = L.LI[link], jt = RKFD_LI_JT( lii );
+    const bool is1 = has && RKFD_JT_IS1( jt ), isf = has && !is1;
+    const int dpt = is1 ? RKFD_LI_DEPTH( lii ) : 0;
+    const int row = isf ? NLV+fq : dpt;
+    double sum = 0;
+    /* one side of one contact: its share of this lane's sum (e: the side's record, wave-uniform) */
+#define RKFD_DIN_ONP(e) ( isf ? RKFD_CS_TOP( e ) == link \
+                             : ( RKFD_CS_DEPTH( e ) >= dpt && RKFD_CS_D0( e ) <= dpt && L.PL[RKFD_CS_LINK( e )*NLV+dpt] == link ) )
+    if( nc*NSD <= RKFD_WAVE ){
+      /* the records and the forces wait in registers (lane = side, lane = contact) and reach everybody through v_readlane: the
+       * loop over the sides that move (the floor's do not: half of the sides where contacts may have two moving ones) then holds
+       * no LDS access that depends on another, two sides are in flight together, and the sum is still taken in the order of the
+       * sides */
+      const int mytgt = lane < nc*NSD ? L.tgt[lane] : 0;
+      double g0 = 0, g1 = 0, g2 = 0;
+      if( lane < nc ){ g0 = L.MF[3*lane]; g1 = L.MF[3*lane+1]; g2 = L.MF[3*lane+2]; }
+      unsigned long long todo = BALLOT( RKFD_CS_VALID( (unsigned)mytgt ) != 0 );
+      const double *pur = &L.PU[row*M];
+      while( todo ){
+        const int csa = __builtin_ctzll( todo );
+        todo &= todo - 1ull;
+        const bool two = todo != 0ull;
+        const int csb = two ? __builtin_ctzll( todo ) : csa;
+        todo &= todo - 1ull;
+        const unsigned ea = (unsigned)BCASTI( mytgt, csa ), eb = (unsigned)BCASTI( mytgt, csb );
+        const int ca = NSD == 1 ? csa : csa >> 1, cb = NSD == 1 ? csb : csb >> 1;
+        const double *pa = pur + ( NSD == 1 ? 0 : ( csa & 1 ) )*PUS + 3*ca, *pb = pur + ( NSD == 1 ? 0 : ( csb & 1 ) )*PUS + 3*cb;
+        const double va = BCAST( g0, ca )*pa[0] + BCAST( g1, ca )*pa[1] + BCAST( g2, ca )*pa[2];
+        const double vb = BCAST( g0, cb )*pb[0] + BCAST( g1, cb )*pb[1] + BCAST( g2, cb )*pb[2];
+        const bool oa = RKFD_DIN_ONP( ea ), ob = RKFD_DIN_ONP( eb );
+        sum += oa ? va : 0.0;
+        sum += ( two && ob ) ? vb : 0.0;
       }
-      if( is1 ) L.MS[3*link+1] = sum*L.MS[3*link+2];
-      if( isf ) L.U[6*link+fq] = sum;
+    } else
+    for( int cs=0; cs<nc*NSD; cs++ ){
+      const unsigned e = (unsigned)BCASTI( L.tgt[cs], 0 );
+      if( !RKFD_CS_VALID( e ) ) continue;
+      const int c = NSD == 1 ? cs : cs >> 1;
+      const double *pu = &L.PU[( NSD == 1 ? 0 : ( cs & 1 ) )*PUS + row*M + 3*c];
+      const double v = L.MF[3*c]*pu[0] + L.MF[3*c+1]*pu[1] + L.MF[3*c+2]*pu[2];
+      /* 1-DoF joint: it lies on the moving path of the contact side; float joint: the path ends there */
+      sum += RKFD_DIN_ONP( e ) ? v : 0.0;
     }
+#undef RKFD_DIN_ONP
+    if( is1 ) L.MS[3*link+1] = sum*L.MS[3*link+2];
+    if( isf ) L.U[6*link+fq] = sum;
   }
   SYNC();
   MST(23);

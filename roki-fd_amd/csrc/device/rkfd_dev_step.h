@@ -66,7 +66,7 @@ template<bool prof, int vqp, bool pk> RKFD_DEV int rkfd_evaluate(const rkfdDevMo
       SYNC();
       const double afree = lane < m.ndof ? L.acc[lane] : 0.0;
       /* contact forces, then their effect on the accelerations (rkChainUpdateCachedABI in the reference) */
-      rkfd_phase_mlcp<prof, vqp == 1, pk>( m, L, bv, doUpRef, pc );
+      rkfd_phase_mlcp<prof, vqp == 1, pk>( m, L, bv, doUpRef, ll.dtask, pc );
       STAMP(4);
       rkfd_phase_sweep3<true>( m, L );
       SYNC();
@@ -156,7 +156,16 @@ template<bool prof, int vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDevM
   double q = 0, qd = 0;
   int dofkind = 0;      /* 1: first angular coordinate of a float joint, 2: the other two */
   if( lane < ND ){ q = st.dis[(size_t)b*ND+lane]; qd = st.vel[(size_t)b*ND+lane]; dofkind = m.dofkind[lane]; }
-  rkfdLaneLink ll; ll.min = 0; ll.pivp = 0; ll.pivt = 0;
+  rkfdLaneLink ll; ll.min = 0; ll.pivp = 0; ll.pivt = 0; ll.dtask = -1;
+  if( m.maxrg > 0 ){
+    /* which link and component the lane's coordinate belongs to (once per launch: a scalar walk over the links) */
+    const int li = lane < NL ? m.linfo[lane] : 0;
+    for( int l=0; l<NL; l++ ){
+      const int x = BCASTI( li, l ), jt = RKFD_LI_JT( x ), off = RKFD_LI_OFF( x );
+      const int n = RKFD_JT_IS1( jt ) ? 1 : ( jt == RKFD_JOINT_FLOAT ? 6 : 0 );
+      if( lane >= off && lane < off+n && lane < ND ) ll.dtask = l | ( ( lane-off ) << 8 );
+    }
+  }
   if( lane < NL ){
     L.LI[lane]   = m.linfo[lane];
     { const int ch = m.child_idx[lane]; L.CHP[lane] = (unsigned short)( ch | ( ( m.pslot[ch]+1 ) << 8 ) ); }

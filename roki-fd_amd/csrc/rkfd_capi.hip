@@ -440,7 +440,12 @@ static std::string spec_source(const rkfdDevModel &d)
     d.npurow, d.pu_alias, d.vert_rigid, d.qscr_alias, d.has_slide, d.ma_size, d.ma_packed, d.max_iter, d.solver, d.pyramid, d.anchor, d.mlcp_mfma,
     d.vol_npair, d.vol_np, d.vol_ncp, d.vol_pv, d.vol_nf,
     d.vol_np > 0 ? 2 : 3, d.vol_np > 0 ? "2" : ( d.vert_rigid ? "1" : "0" ), d.ma_packed ? "true" : "false" );
-  return std::string( buf );
+  std::string src;
+  if( const char *pre = getenv( "RKFD_SPEC_DEFINE" ) ){      /* diagnostic: NAME[,NAME...] defined as 1 in front of the source */
+    std::string names( pre ); size_t p0 = 0;
+    while( p0 < names.size() ){ size_t p1 = names.find( ',', p0 ); if( p1 == std::string::npos ) p1 = names.size(); src += "#define " + names.substr( p0, p1-p0 ) + " 1\n"; p0 = p1+1; }
+  }
+  return src + std::string( buf );
 }
 /* hipRTC, bound at run time in a PRIVATE link namespace.  hipRTC finds its compiler (libamd_comgr) by soname, and
  * a process serves every request for a soname with the first library it loaded under it: a host program that has
