@@ -511,6 +511,17 @@ static int spec_compile(const rkfdDevModel &d, std::vector<char> &code)
   const rkfdRtc *rtc = rtc_api();
   if( !rtc ) return -1;
   const std::string src = spec_source( d );
+  if( rtc->priv ){
+    /* the private namespace carries its own copy of the C library, and that copy's `environ` still points at the array the
+     * process had when the namespace was made.  The host's setenv (Python's os.environ, say) moves the real array and frees
+     * the old one: the compiler's getenv would walk freed memory (seen: a segmentation fault in the 88th test of a pytest
+     * process that had set new variables between two specialisations).  Point the copy at the live array before every use. */
+    char ***penv = (char ***)dlsym( rtc->h, "environ" );
+    if( penv && penv != &environ ){
+      if( *penv != environ && getenv( "RKFD_SPEC_DEBUG" ) ) fprintf( stderr, "rkfd: the host's environment moved (%p -> %p): hipRTC's namespace follows\n", (void *)*penv, (void *)environ );
+      *penv = environ;
+    }
+  }
   if( const char *dump = getenv( "RKFD_SPEC_DUMP" ) ){ FILE *f = fopen( dump, "w" ); if( f ){ fputs( src.c_str(), f ); fclose( f ); } }   /* diagnostic */
   const char *opts[] = { "--offload-arch=gfx950", "-O3", "-Wno-unused-value", "-mllvm", "-disable-machine-licm" };
   hiprtcProgram prog;

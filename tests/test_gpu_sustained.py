@@ -152,23 +152,28 @@ def test_status_is_reported_once(R):
     assert b.status() == 2                                           # and it is raised again when it happens again
 
 
-def test_grouped_gauss_seidel_is_bit_identical(R):
+@pytest.mark.parametrize("specialize", [False, True], ids=["generic", "specialised"])
+def test_grouped_gauss_seidel_is_bit_identical(R, specialize, monkeypatch):
     """config 5 (humanoid + four boxes: five independent bodies, 24 contacts): the grouped Gauss-Seidel - the bodies' update
     sequences side by side in DPP rows, 8 + 8 instead of 24 + 24 updates per sweep - gives bit for bit the states and forces of
-    the one-after-the-other loop (RKFD_PGS_GROUPED=0); an update never touches the residuals of another body"""
-    import os
+    the one-after-the-other loop (RKFD_PGS_GROUPED=0); an update never touches the residuals of another body.  Both storages of
+    the row blocks: sweep order (rows of at most 8 contacts, the default here) and the packed triangle (RKFD_PGS_SW=0: what
+    longer rows use)"""
     sc = R.scenarios.config5(batch=32)
     out = []
-    for sw in ("1", "0"):
-        os.environ["RKFD_PGS_GROUPED"] = sw
-        try:
-            b = R.Batch(sc["world"], 32, max_rigid=sc["max_rigid"])
-        finally:
-            del os.environ["RKFD_PGS_GROUPED"]
+    for env in ({}, {"RKFD_PGS_SW": "0"}, {"RKFD_PGS_GROUPED": "0"}):
+        for k in ("RKFD_PGS_SW", "RKFD_PGS_GROUPED"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        b = R.Batch(sc["world"], 32, max_rigid=sc["max_rigid"])
+        if specialize:
+            b.specialize()
         b.set_state(sc["dis"], sc["vel"]); b.update_init(); b.update(40)
         assert b.status() == 0
         out.append((b.get_state(), b.get_contact()))
-    (s1, c1), (s0, c0) = out
-    for x, y in zip(s1, s0):
-        assert np.array_equal(x, y)
-    assert np.array_equal(c1[0], c0[0]) and np.array_equal(c1[3], c0[3]) and c1[0].sum(1).min() >= 16
+    (s0, c0) = out[2]
+    for s1, c1 in out[:2]:
+        for x, y in zip(s1, s0):
+            assert np.array_equal(x, y)
+        assert np.array_equal(c1[0], c0[0]) and np.array_equal(c1[3], c0[3]) and c1[0].sum(1).min() >= 16

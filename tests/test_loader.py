@@ -4,6 +4,8 @@ import os
 import numpy as np
 import pytest
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def test_humanoid30_topology(R):
     sc = R.scenarios.config4(batch=1)
@@ -211,3 +213,25 @@ def test_specialized_step_kernel_compiles_without_a_gpu(R):
     sc = R.scenarios.config4(batch=2)
     n = R.lib().rkfdSpecializeCompile(sc["world"].model, sc["max_rigid"])
     assert n > 10000, R.lib().rkfdHipLastError().decode()
+
+
+def test_specialisation_survives_the_host_changing_its_environment():
+    """hipRTC lives in a private link namespace with its own copy of the C library; the host's setenv moves the environment
+    array and frees the old one, which that copy still pointed at (a segmentation fault deep into a pytest process, round 2).
+    rkfd_capi.hip re-points it before every compile: compile, set 200 new variables, compile again - in a child process,
+    so that a regression fails this test instead of killing the test run"""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys, importlib\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "R = importlib.import_module('roki-fd_amd')\n"
+        "sc = R.scenarios.config1(batch=2)\n"
+        "n1 = R.lib().rkfdSpecializeCompile(sc['world'].model, sc['max_rigid'])\n"
+        "for i in range(200):\n"
+        "    os.environ['RKFD_TEST_FILLER_%d' % i] = 'x' * 100\n"
+        "n2 = R.lib().rkfdSpecializeCompile(sc['world'].model, sc['max_rigid'])\n"
+        "print('sizes', n1, n2)\n"
+        "assert n1 > 10000 and n1 == n2\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
