@@ -366,6 +366,9 @@ typedef struct {
    * conditions of a pair, its model pair.  n = 6 np, mc = np ( 1 + ncp ). */
   double *VD, *VPL, *VPOLY, *VRED, *VQL, *VQW, *VS, *VEV, *VQV, *VLP;
   int *VI;
+  /* grouped Gauss-Seidel (worlds with more than 16 rigid contact vertices): the layout of the last evaluation - per lane the two
+   * moving trees of its contact (2 bytes), the position table (64 bytes), the row fills, the contact count (RKFD_GC_INTS ints) */
+  int *GC;
 } rkfdLds;
 RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int M, int nlevel, int npool, int nfloat, int maxact, int nside, int pu_alias, int npurow, int vert_rigid, int has_slide, int ma_size,
                              int vol_np, int vol_ncp, int vol_pv, int vol_nf, int pyramid)
@@ -420,6 +423,7 @@ RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int
   L->CIp = ip; ip += NC;
   L->tgt = ip; ip += nside*maxact; L->cnt = ip; ip += vol_np ? 12 : ( NC > 0 ? 8 : 4 );
   L->VI = ip; if( vol_np ) ip += 2*vol_np;
+  L->GC = ip; if( RKFD_GC_NEEDED( M ) ) ip += RKFD_GC_INTS;
   L->LI = ip; ip += NL;
   unsigned short *sp = (unsigned short *)ip;
   L->CHP = sp; sp += NL; L->CFO = sp; sp += NC;

@@ -149,6 +149,7 @@ template<bool prof, int vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDevM
   }
   if( lane == 0 ){
     L.cnt[CNT_OVF] = 0; L.cnt[CNT_QPF] = 0;
+    if( RKFD_GC_NEEDED( 3*m.maxrg ) ) L.GC[RKFD_GC_INTS-1] = -1;      /* no grouped layout remembered yet */
     if( NC > 0 ){ L.cnt[CNT_SRG] = 0; L.cnt[CNT_SEL] = 0; L.cnt[CNT_SN] = 0; }
   }
 

@@ -629,7 +629,8 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
                      + (size_t)maxact*( 21 + ( NC > RKFD_WAVE ? 3 : 0 ) + ( dm.has_slide ? 6 : 0 ) ) + ( ( dm.vert_rigid || vol_np > 0 ) ? 2 : 1 )*M + ( dm.pu_alias ? 0 : (size_t)nside*npurow*M )
                      + ( dm.vert_rigid ? M*M + M*( M+1 )/2 + 5*M + ( dm.qscr_alias ? 0 : RKFD_WAVE ) + 3*M : 0 )   /* Vert QP: QL, QW, QV, CR */
                      + ( vol_np > 0 ? (size_t)RKFD_VOL_LDS_DOUBLES( vol_np, vol_ncp, vol_pv, vol_nf, dm.pyramid ) : 0 );
-    const size_t ints = (size_t)NC + (size_t)nside*maxact + ( vol_np > 0 ? 12 + 2*vol_np : ( NC > 0 ? 8 : 4 ) ) + (size_t)NL;     /* CIp, tgt, cnt (VI), LI */
+    const size_t ints = (size_t)NC + (size_t)nside*maxact + ( vol_np > 0 ? 12 + 2*vol_np : ( NC > 0 ? 8 : 4 ) ) + (size_t)NL     /* CIp, tgt, cnt (VI), LI */
+                      + ( RKFD_GC_NEEDED( (int)M ) ? RKFD_GC_INTS : 0 );                                                            /* GC */
     const size_t bytes = (size_t)2*NL + (size_t)5*NC + (size_t)4*maxact + ( dm.vert_rigid ? M : 0 )                                     /* CHP (16 bit), act typ asl (bytes) */
                        + ( max_rigid > 0 ? (size_t)NL*( nlevel+3 ) : 0 );                /* PL */
     out->lds_bytes = dbl*sizeof(double) + ints*sizeof(int) + bytes;

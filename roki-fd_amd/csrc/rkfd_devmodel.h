@@ -102,6 +102,9 @@ typedef struct {
 #define RKFD_DJT_SPHX 4
 #define RKFD_DJT_SPHY 5
 #define RKFD_DJT_SPHZ 6
+/* LDS ints of the grouped Gauss-Seidel's remembered layout (rkfdLds.GC), kept by worlds with more than 16 rigid contact vertices (M = 3 maxrg rows) */
+#define RKFD_GC_INTS 50
+#define RKFD_GC_NEEDED(M) ( (M) > 3*16 )
 #define RKFD_JT_IS1(jt) ( (jt) == RKFD_JOINT_REVOL || (jt) == RKFD_JOINT_PRISM || (jt) >= RKFD_DJT_SPHX )
 #define RKFD_LI_PACK(par,jt,depth,stat,mt,off) \
   ( ((par)+1) | ((jt)<<8) | ((depth)<<11) | ((stat)<<18) | ((mt)<<19) | ((off)<<21) )
