@@ -1010,9 +1010,14 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
         const double *pa = pur + ( NSD == 1 ? 0 : ( csa & 1 ) )*PUS + 3*ca, *pb = pur + ( NSD == 1 ? 0 : ( csb & 1 ) )*PUS + 3*cb;
         const double va = BCAST( g0, ca )*pa[0] + BCAST( g1, ca )*pa[1] + BCAST( g2, ca )*pa[2];
         const double vb = BCAST( g0, cb )*pb[0] + BCAST( g1, cb )*pb[1] + BCAST( g2, cb )*pb[2];
-        const bool oa = RKFD_DIN_ONP( ea ), ob = RKFD_DIN_ONP( eb );
+        /* (no short-circuit evaluation: as branches around the byte load the test serialised the two sides) */
+        const int pla = L.PL[RKFD_CS_LINK( ea )*NLV+dpt], plb = L.PL[RKFD_CS_LINK( eb )*NLV+dpt];
+        const bool o1a = ( RKFD_CS_DEPTH( ea ) >= dpt ) & ( RKFD_CS_D0( ea ) <= dpt ) & ( pla == link );
+        const bool o1b = ( RKFD_CS_DEPTH( eb ) >= dpt ) & ( RKFD_CS_D0( eb ) <= dpt ) & ( plb == link );
+        const bool ofa = RKFD_CS_TOP( ea ) == link, ofb = RKFD_CS_TOP( eb ) == link;
+        const bool oa = isf ? ofa : o1a, ob = isf ? ofb : o1b;
         sum += oa ? va : 0.0;
-        sum += ( two && ob ) ? vb : 0.0;
+        sum += ( two & ob ) ? vb : 0.0;
       }
     } else
     for( int cs=0; cs<nc*NSD; cs++ ){
