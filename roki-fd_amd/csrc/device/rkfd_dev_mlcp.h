@@ -150,8 +150,8 @@ template<bool pk> RKFD_DEV void rkfd_pgs_dpp(const double *MA, int r0, int ld, i
  * delivers the increment of position C of EACH row within that row - and a sweep is as long as the fullest row (config 5: 8 + 8
  * instead of 24 + 24 updates).  Within a component the reference's order is kept; updates of different components never
  * touch the same residual, so the result is bit for bit that of the one-after-the-other loop
- * (tests/test_gpu_sustained.py::test_grouped_gauss_seidel_is_bit_identical; m:pgs 862 k -> 437 k cycles per step, config 5
- * 1.25 -> 1.94 M steps/s).  grow: this lane's row of the position table (contact index or 255), pos = lane & 15. */
+ * (tests/test_gpu_sustained.py::test_grouped_gauss_seidel_is_bit_identical; m:pgs 862 k -> 182 k cycles per step with the sweep-order
+ * storage below, config 5 1.25 -> 2.77 M steps/s).  grow: this lane's row of the position table (contact index or 255), pos = lane & 15. */
 /* position c (a literal) of a row of the position table held in four registers */
 #define RKFD_GRP_POS(gw, c) ( (int)( ( (gw)[(c) >> 2] >> ( 8*( (c) & 3 ) ) ) & 255u ) )
 /* entry ( row, col ) of the contact matrix where the row's own part of the packed index is known: rb = row ( row + 1 ) / 2 (per lane,
@@ -233,7 +233,7 @@ RKFD_DEV int rkfd_pgs_group_layout(const rkfdDevModel &m, const rkfdLds &L, unsi
     if( NSD > 1 ){ const unsigned e1 = (unsigned)L.tgt[lane*NSD+1]; if( RKFD_CS_VALID( e1 ) ) t1 = RKFD_CS_TOP( e1 ); }
   }
   /* the same contacts on the same trees as in the last evaluation (most evaluations: a step has five, the contact set changes
-   * rarely): its layout again (36 k -> 9 k cycles per step on config 5) */
+   * rarely): its layout again (36 k -> 7 k cycles per step on config 5) */
   unsigned short *gct = (unsigned short *)L.GC;
   const unsigned short mine = (unsigned short)( t0 | ( t1 << 8 ) );
   if( L.GC[RKFD_GC_INTS-1] == nc && BALLOT( gct[lane] != mine ) == 0ull ){
