@@ -8,7 +8,27 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-WORKLOADS = ["config1", "config1b", "config2", "config3", "config4", "config4v", "config5", "config1_volume", "config4_volume", "config4_shell"]
+WORKLOADS = ["config1", "config1b", "config2", "config3", "config4", "config4v", "config5", "config1_volume", "config4_volume", "config4_shell",
+             "config4_26", "arm_press", "arm_press_revroot", "arm_press_vert", "arm_press_volume", "ball_roll", "arm_spher"]
+
+
+def _scenario(R, cfg, B):
+    S = R.scenarios
+    if cfg == "arm_press":
+        return S.arm_press(batch=B)                                   # a rigid pair with two moving sides, motors, a prismatic joint
+    if cfg == "arm_press_revroot":
+        return S.arm_press(batch=B, root="rev", with_box=False)
+    if cfg == "arm_press_vert":
+        sc = S.arm_press(batch=B, solver=R.SOLVER_VERT)
+        sc["max_rigid"] = 8                                           # (64 pyramid faces: one constraint per lane)
+        return sc
+    if cfg == "arm_press_volume":
+        return S.arm_press(batch=B, solver=R.SOLVER_VOLUME)
+    if cfg == "ball_roll":
+        return S.ball_roll(batch=B)                                   # 274 candidate vertices: the collision sweep in chunks
+    if cfg == "arm_spher":
+        return S.arm_spher(batch=B, contact=True)                     # spherical joints (three device links each)
+    return S.CONFIGS[cfg](batch=B)
 
 
 def _steps(R, sc, B, nsteps, specialize):
@@ -16,6 +36,8 @@ def _steps(R, sc, B, nsteps, specialize):
     if specialize:
         b.specialize()
     b.set_state(sc["dis"][:B], sc["vel"][:B])
+    if "motor_in" in sc:
+        b.set_motor_input(sc["motor_in"][:B])
     b.update_init(); b.update(nsteps)
     assert b.status() == 0
     return b.get_state(), b.get_contact()
@@ -24,8 +46,8 @@ def _steps(R, sc, B, nsteps, specialize):
 @pytest.mark.parametrize("specialize", [False, True], ids=["generic", "specialised"])
 @pytest.mark.parametrize("cfg", WORKLOADS)
 def test_results_do_not_depend_on_what_lds_held_before(R, cfg, specialize, monkeypatch):
-    B, nsteps = 256, 12
-    sc = R.scenarios.CONFIGS[cfg](batch=B)
+    B, nsteps = (256, 12) if cfg.startswith("config") else (32, 40)
+    sc = _scenario(R, cfg, B)
     monkeypatch.delenv("RKFD_DEBUG_POISON_LDS", raising=False)
     (d0, v0, a0), (act0, typ0, ref0, f0) = _steps(R, sc, B, nsteps, specialize)
     monkeypatch.setenv("RKFD_DEBUG_POISON_LDS", "1")
