@@ -8,7 +8,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-LIB_PATH = os.path.join(HERE, "librkfd_emu.so")
+LIB_PATH = os.environ.get("RKFD_EMU_LIB", os.path.join(HERE, "librkfd_emu.so"))      # (RKFD_EMU_LIB: a sanitizer build, tools/emu_asan.sh)
 _lib = None
 
 
