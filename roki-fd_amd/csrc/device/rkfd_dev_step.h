@@ -265,7 +265,9 @@ template<bool prof, int vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDevM
     st.dis[(size_t)b*ND+lane] = q; st.vel[(size_t)b*ND+lane] = qd;
     st.acc[(size_t)b*ND+lane] = L.acc[lane];
   }
-  if( lane < NL ){
+  /* (a spherical joint is three device links of one model link: the real one writes - the pseudo-links in front of it hold the same
+   * untouched values, but three lanes storing to one address is a race all the same; found by ThreadSanitizer on the emulator) */
+  if( lane < NL && RKFD_LI_JT( L.LI[lane] ) != RKFD_DJT_SPHX && RKFD_LI_JT( L.LI[lane] ) != RKFD_DJT_SPHY ){
     const int lm = m.orig[lane];
     st.piv_type[(size_t)b*m.nlink_model+lm] = ll.pivt;
     st.piv_prev[(size_t)b*m.nlink_model+lm] = ll.pivp;
