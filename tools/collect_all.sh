@@ -31,6 +31,7 @@ python3 bench.py --workload config4_26 --no-cpu-baseline > gpurun_out/bench_conf
 python3 bench.py --workload config1_volume > gpurun_out/bench_config1_volume.json 2> gpurun_out/bench_config1_volume.log
 python3 bench.py --workload config4_volume > gpurun_out/bench_config4_volume.json 2> gpurun_out/bench_config4_volume.log
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_config4_volume/trace -- python3 bench.py --workload config4_volume --no-cpu-baseline > gpurun_out/prof_${TAG}_config4_volume.bench.json 2> gpurun_out/prof_${TAG}_config4_volume.trace.log || true
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_config5/trace -- python3 bench.py --workload config5 --steps 100 --warmup 20 --no-cpu-baseline > gpurun_out/prof_${TAG}_config5.bench.json 2> gpurun_out/prof_${TAG}_config5.trace.log || true
 WARM=10 python3 tools/prof_phases.py config1_volume config4_volume > gpurun_out/phase_cycles_volume.txt 2>&1
 echo "benches done"
 tools/ubench/pgs 11 > gpurun_out/ubench_pgs.txt 2>&1

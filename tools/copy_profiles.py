@@ -80,6 +80,11 @@ for w in ("config1_volume", "config4_volume"):
 try:
     ks = sorted(glob.glob(f"gpurun_out/prof_{tag}_config4_volume/trace/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)[-1]
     shutil.copy(ks, f"profiles/{tag}_config4_volume_kernel_stats.csv")
+    k5 = sorted(glob.glob(f"gpurun_out/prof_{tag}_config5/trace/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)
+    if k5:
+        shutil.copy(k5[-1], f"profiles/{tag}_config5_kernel_stats.csv")
+        if os.path.exists(f"gpurun_out/prof_{tag}_config5.bench.json"):
+            shutil.copy(f"gpurun_out/prof_{tag}_config5.bench.json", f"profiles/{tag}_config5_kernel_stats.bench.json")
     shutil.copy("gpurun_out/phase_cycles_volume.txt", f"profiles/{tag}_phase_cycles_volume.txt")
 except (OSError, IndexError) as e:
     print("missing", e)
