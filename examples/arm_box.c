@@ -58,6 +58,9 @@ int main(int argc, char *argv[])
   dis[0] = zVecAlloc( rkChainJointSize( rkFDCellChain(cell[0]) ) );
   zVecElemNC(dis[0],1) = 0.6;
   rkFDChainSetDis( cell[0], dis[0] );
+  /* the arm's OWN pairs go (self-collision off); it goes on touching the box and the floor - exactly where the reference's
+   * driver has the call (example/chain/arm_box_test.c:49, after arm, box and floor are registered) */
+  rkCDPairChainUnreg( rkFDCDBase(&fd.cd), rkFDCellChain(cell[0]) );
   dis[1] = zVecAlloc( rkChainJointSize( rkFDCellChain(cell[1]) ) );
   zVecElemNC(dis[1],0) = 0.25; zVecElemNC(dis[1],1) = 0.05; zVecElemNC(dis[1],2) = 0.05 - 1.0e-5;
   rkFDChainSetDis( cell[1], dis[1] );

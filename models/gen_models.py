@@ -212,6 +212,30 @@ def arm(name, root_joint):
     return s
 
 
+def arm_fold():
+    """SYNTHETIC test model for SELF-COLLISION (pairs between links of one chain, which registration forms by default:
+    reference src/rkfd_sim.c:198, the "self collision" branch of src/rkfd_util.c:163-170): a pedestal with a base block and
+    three links in a vertical plane, a box on every link (shorter than the link, so that neighbours do not touch at the
+    joints), torque motors on the joints.  Folded (q2 ~ 120 deg, q3 ~ 140 deg) the last link's box comes down on the first
+    link's - a rigid 'body body' contact with BOTH sides on the same tree."""
+    inertia = "inertia : {\n 1e-3, 0, 0\n 0, 1e-3, 0\n 0, 0, 1e-3\n}\n"
+    s = "[roki::chain]\nname : arm_fold\n\n"
+    s += "[zeo::shape]\ntype : box\nname : base\ncenter : 0, 0, -0.1\ndepth : 0.1\nwidth : 0.1\nheight : 0.1\n\n"
+    s += "[zeo::shape]\ntype : box\nname : beam\ncenter : 0.15, 0, 0\ndepth : 0.18\nwidth : 0.04\nheight : 0.04\n\n"
+    s += "[zeo::shape]\ntype : box\nname : finger\ncenter : 0.13, 0, 0\ndepth : 0.2\nwidth : 0.03\nheight : 0.03\n\n"
+    s += "[roki::motor]\nname : trqm\ntype: trq\nmax : 20.0\nmin : -20.0\n\n"
+    s += "[roki::link]\nname : pedestal\njointtype : fixed\nmass : 5.0\nstuff : body\n" + inertia
+    s += "frame : {\n 1, 0, 0, 0\n 0, 1, 0, 0\n 0, 0, 1, 0.5\n}\nshape : base\n\n"
+    # local z = -parent's y: a positive joint angle lifts the link's x axis towards +z
+    s += "[roki::link]\nname : link1\njointtype : revolute\nmass : 0.5\nstuff : body\nCOM : { 0.15, 0, 0 }\n" + inertia
+    s += "motor : trqm\nviscosity: 0.05\nframe : {\n 1, 0, 0, 0\n 0, 0, -1, 0\n 0, 1, 0, 0\n}\nparent : pedestal\nshape : beam\n\n"
+    s += "[roki::link]\nname : link2\njointtype : revolute\nmass : 0.5\nstuff : body\nCOM : { 0.15, 0, 0 }\n" + inertia
+    s += "motor : trqm\nviscosity: 0.05\nframe : {\n 1, 0, 0, 0.3\n 0, 1, 0, 0\n 0, 0, 1, 0\n}\nparent : link1\nshape : beam\n\n"
+    s += "[roki::link]\nname : link3\njointtype : revolute\nmass : 0.3\nstuff : body\nCOM : { 0.1, 0, 0 }\n" + inertia
+    s += "motor : trqm\nviscosity: 0.05\nframe : {\n 1, 0, 0, 0.3\n 0, 1, 0, 0\n 0, 0, 1, 0\n}\nparent : link2\nshape : finger\n\n"
+    return s
+
+
 def humanoid(ref_root):
     src = os.path.join(ref_root, "example", "model", "mighty.ztk")
     text = open(src).read()
@@ -300,6 +324,7 @@ def main():
     w("chain30.ztk", chain30())
     w("arm_fixedroot.ztk", arm("arm_fixedroot", "fixed"))
     w("arm_revroot.ztk", arm("arm_revroot", "revolute"))
+    w("arm_fold.ztk", arm_fold())
     ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
     if os.path.isdir(ref):
         humanoid(ref)

@@ -25,22 +25,18 @@ void rkfdWorldDestroy(rkfdWorld *w)
 {
   int i;
   for( i=0; i<w->nchain; i++ ) rkfdChainDescFree( w->chain[i] );
-  free( w->chain ); free( w->nopair ); free( w->ci ); free( w->blob ); free( w->pair_off );
+  free( w->chain ); free( w->noself ); free( w->ci ); free( w->blob );
   memset( w, 0, sizeof(rkfdWorld) );
 }
 
 int rkfdWorldAddChain(rkfdWorld *w, rkfdChainDesc *c)
 {
-  int n = w->nchain, i, j;
-  unsigned char *np;
+  int n = w->nchain;
 
   w->chain = (rkfdChainDesc **)realloc( w->chain, sizeof(rkfdChainDesc*)*(n+1) );
-  np = (unsigned char *)calloc( (size_t)(n+1)*(n+1), 1 );
-  if( !w->chain || !np ) return -1;
-  for( i=0; i<n; i++ )
-    for( j=0; j<n; j++ ) np[i*(n+1)+j] = w->nopair[i*n+j];
-  free( w->nopair );
-  w->nopair = np;
+  w->noself = (unsigned char *)realloc( w->noself, (size_t)(n+1) );
+  if( !w->chain || !w->noself ) return -1;
+  w->noself[n] = 0;
   w->chain[n] = c;
   w->nchain = n+1;
   w->built = 0;
@@ -49,34 +45,18 @@ int rkfdWorldAddChain(rkfdWorld *w, rkfdChainDesc *c)
 
 void rkfdWorldRemoveChain(rkfdWorld *w, int chain)
 {
-  int n = w->nchain, i, j, ii, jj;
-  unsigned char *np;
+  int n = w->nchain, i;
   if( chain < 0 || chain >= n ) return;
   rkfdChainDescFree( w->chain[chain] );
-  for( i=chain; i<n-1; i++ ) w->chain[i] = w->chain[i+1];
-  /* the no-pair matrix loses row and column `chain` (in place: entries only move towards the front) */
-  np = w->nopair;
-  for( i=0, ii=0; i<n; i++ ){
-    if( i == chain ) continue;
-    for( j=0, jj=0; j<n; j++ ){
-      if( j == chain ) continue;
-      np[ii*(n-1)+jj] = np[i*n+j];
-      jj++;
-    }
-    ii++;
-  }
+  for( i=chain; i<n-1; i++ ){ w->chain[i] = w->chain[i+1]; w->noself[i] = w->noself[i+1]; }
   w->nchain = n-1;
   w->built = 0;
 }
 
 void rkfdWorldPairChainUnreg(rkfdWorld *w, int chain)
 {
-  int j, n = w->nchain;
-  if( chain < 0 || chain >= n ) return;
-  for( j=0; j<n; j++ ){
-    w->nopair[chain*n+j] = 1;
-    w->nopair[j*n+chain] = 1;
-  }
+  if( chain < 0 || chain >= w->nchain ) return;
+  w->noself[chain] = 1;
   w->built = 0;
 }
 
@@ -113,6 +93,27 @@ static int assoc_ci(const rkfdWorld *w, const char *s0, const char *s1)
         ( strcmp( w->ci[i].stuff[0], s1 ) == 0 && strcmp( w->ci[i].stuff[1], s0 ) == 0 ) ) return i;
   }
   return w->nci; /* default entry */
+}
+
+/* The link a link is rigidly attached to: itself unless it hangs on a FIXED joint, then what its parent is attached to
+ * (-1: the world).  Two cells of one chain whose links share it can never move against each other. */
+static int rigid_rep(const rkfdChainDesc *cd, int link)
+{
+  while( link >= 0 && cd->link[link].jtype == RKFD_JOINT_FIXED ) link = cd->link[link].parent;
+  return link;
+}
+
+/* Does registration pair these two cells (chain, chain-local link)?  rkCDChainReg -> rkCDPairReg [RoKi, UNVERIFIED-DEP]:
+ * every new cell against every cell registered before it, of another chain or of its own (the reference's drivers then drop
+ * an articulated chain's own pairs with rkCDPairChainUnreg, example/chain/arm_box_test.c:49; arm_wall_test.c keeps the
+ * wall's: its bricks are links of one chain and do collide).  Not paired: two cells on the same link, and - this build -
+ * two cells of one chain that are rigidly attached to each other (only FIXED joints between them): such a pair cannot
+ * change any acceleration, it would only occupy contact slots (RoKi skips the static-static case the same way; DEVIATIONS.md). */
+static int cells_pair(const rkfdWorld *w, int cx, int lx, int cy, int ly)
+{
+  if( cx != cy ) return 1;
+  if( w->noself[cx] || lx == ly ) return 0;
+  return rigid_rep( w->chain[cx], lx ) != rigid_rep( w->chain[cx], ly );
 }
 
 /* bump allocator over one blob */
@@ -160,6 +161,7 @@ int rkfdWorldBuild(rkfdWorld *w)
   /* count pairs and candidates */
   {
     int *sc = (int *)malloc( sizeof(int)*( nshape ? nshape : 1 ) );
+    int *sl = (int *)malloc( sizeof(int)*( nshape ? nshape : 1 ) );
     int *sv = (int *)malloc( sizeof(int)*( nshape ? nshape : 1 ) );
     int *scv = (int *)malloc( sizeof(int)*( nshape ? nshape : 1 ) );
     int n = 0, x, y;
@@ -169,18 +171,17 @@ int rkfdWorldBuild(rkfdWorld *w)
         for( s=0; s<cd->link[i].nshape; s++ ){
           rkfdShape *sh = &cd->shape[cd->link[i].shape[s]];
           if( sh->nvert == 0 || sh->nplane == 0 ) continue;
-          sc[n] = c; sv[n] = sh->nvert; scv[n] = sh->convex; n++;
+          sc[n] = c; sl[n] = i; sv[n] = sh->nvert; scv[n] = sh->convex; n++;
         }
     }
     for( y=0; y<n; y++ )
       for( x=0; x<y; x++ ){
-        if( sc[x] == sc[y] ) continue;
-        if( w->nopair[sc[x]*w->nchain+sc[y]] ) continue;
+        if( !cells_pair( w, sc[x], sl[x], sc[y], sl[y] ) ) continue;
         /* a shape's vertices are candidates against the OTHER shape of the pair only when that one is convex (the
          * inside test is the intersection of its face half-spaces) */
         npair++; ncand += ( scv[y] ? sv[x] : 0 ) + ( scv[x] ? sv[y] : 0 );
       }
-    free( sc ); free( sv ); free( scv );
+    free( sc ); free( sl ); free( sv ); free( scv );
   }
 
   for( pass=0; pass<2; pass++ ){
@@ -251,13 +252,13 @@ int rkfdWorldBuild(rkfdWorld *w)
       ci_type[i] = q->type; ci_sf[i] = q->sf; ci_kf[i] = q->kf;
       ci_k[i] = q->k; ci_l[i] = q->l; ci_e[i] = q->e; ci_v[i] = q->v;
     }
-    /* pairs: each later-registered cell against every earlier cell of another chain */
+    /* pairs: each later-registered cell against every earlier cell (cells_pair) */
     {
       int x, y;
       for( y=0; y<nshape; y++ )
         for( x=0; x<y; x++ ){
-          if( shape_chain[x] == shape_chain[y] ) continue;
-          if( w->nopair[shape_chain[x]*w->nchain+shape_chain[y]] ) continue;
+          if( !cells_pair( w, shape_chain[x], shape_link[x] - rkfdWorldChainLinkOffset( w, shape_chain[x] ),
+                              shape_chain[y], shape_link[y] - rkfdWorldChainLinkOffset( w, shape_chain[y] ) ) ) continue;
           pair_shape[2*pi] = x; pair_shape[2*pi+1] = y;
           pair_ci[pi] = assoc_ci( w, shape_stuff[x], shape_stuff[y] );
           for( s=0; s<2; s++ ){

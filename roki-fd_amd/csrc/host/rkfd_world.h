@@ -11,8 +11,7 @@
 typedef struct rkfdWorld_ {
   int nchain;
   rkfdChainDesc **chain;
-  int *pair_off;        /* [nchain] chain's cells are not paired with chains whose bit is set ... see .c */
-  unsigned char *nopair;/* [nchain*nchain] 1 = pairs between the two chains were unregistered */
+  unsigned char *noself;/* [nchain] 1 = the pairs between cells of this chain itself were unregistered (rkCDPairChainUnreg) */
   int nci;
   rkfdContactInfo *ci;
   rkfdContactInfo cidef;/* solver default contact info */
@@ -28,8 +27,11 @@ void rkfdWorldDestroy(rkfdWorld *w);
 int  rkfdWorldAddChain(rkfdWorld *w, rkfdChainDesc *c);
 /* remove chain id (rkCDChainUnreg + cell removal, reference src/rkfd_sim.c:237-255); later chains move down by one */
 void rkfdWorldRemoveChain(rkfdWorld *w, int chain);
-/* drop every collision pair that involves chain id and a chain registered so far
- * (rkCDPairChainUnreg as used in reference example/chain/boxdrop_test.c:37) */
+/* rkCDPairChainUnreg [RoKi; UNVERIFIED-DEP, meaning taken from the reference's own usage]: drop the collision pairs whose
+ * TWO cells both belong to chain id - its self-collision pairs, which registration forms by default between shapes on different
+ * links of one chain (reference src/rkfd_sim.c:198; the "self collision" branch of src/rkfd_util.c:163-170 serves them).  Pairs
+ * with other chains stay: reference example/chain/arm_box_test.c:39-49 registers arm, box and floor and only then calls this
+ * for the arm, which must go on touching both. */
 void rkfdWorldPairChainUnreg(rkfdWorld *w, int chain);
 int  rkfdWorldSetContactInfo(rkfdWorld *w, const char *filename);
 /* (re)build w->model; returns 0 on success */

@@ -195,6 +195,7 @@ def _humanoid(batch, ci_file, solver, seed, model="humanoid30.ztk", first=0):
     w.contact_info(_m(ci_file))
     h = w.reg_file(_m(model))
     w.reg_file(_m("floor.ztk"))
+    w.pair_chain_unreg(h)              # no self-collision pairs, as the reference's drivers ask for an articulated chain (arm_box_test.c:49)
     init = w.init_dis(h)
     n = init.shape[0]
     u = splitmix64_uniform(seed, batch * (n - 6), start=first * (n - 6)).reshape(batch, n - 6)
@@ -226,19 +227,21 @@ def config4_vert(batch=4096, model="humanoid30.ztk", first=0):
 
 
 def config5(batch=4096, max_rigid=24, first=0):
-    """config 4 + clutter: four small boxes resting on the floor around the feet; box-floor and
-    box-foot pairs are RIGID ('ground body' / 'body body' of contactinfo.ztk), box-box pairs are
-    unregistered (as the reference's box-drop drivers do).  54 joint coordinates, 34 links,
-    224 candidate contact vertices per instance.  Contact capacity 24 vertices = 72 MLCP rows (two
+    """config 4 + clutter: four small boxes resting on the floor around the feet; box-floor, box-foot and box-box
+    pairs are RIGID ('ground body' / 'body body' of contactinfo.ztk).  Registration and rkCDPairChainUnreg in the order
+    of the reference's box-drop drivers (boxdrop_test.c:27-39: the call drops a chain's OWN pairs - none for a one-link box;
+    the humanoid's sole-sole pair goes).  54 joint coordinates, 34 links, 320 candidate contact vertices per instance
+    (6 box-box + 8 box-sole + 4 box-floor + 2 sole-floor pairs x 16).  Contact capacity 24 vertices = 72 MLCP rows (two
     rows per lane)."""
     w = B.World(solver=B.SOLVER_MLCP)
     w.contact_info(_m("contactinfo.ztk"))
     boxes = []
     for _ in range(4):
         c = w.reg_file(_m("box_small.ztk"))
-        w.pair_chain_unreg(c)          # drops the pairs with the boxes registered so far
+        w.pair_chain_unreg(c)          # as reference example/chain/boxdrop_test.c:37
         boxes.append(c)
     h = w.reg_file(_m("humanoid30.ztk"))
+    w.pair_chain_unreg(h)
     w.reg_file(_m("floor.ztk"))
     init = w.init_dis(h)
     n = init.shape[0]
@@ -296,6 +299,48 @@ def arm_press(batch=8, root="fixed", with_box=True, seed=0x5EED00A1, solver=B.SO
         inp[b, w.link_offset(a) + (1 if root == "fixed" else 0)] = (u[b, 7] - 0.5) * 20.0     # yaw motor voltage
         inp[b, w.link_offset(a) + (2 if root == "fixed" else 1)] = 2.0                         # shoulder torque, pressing down
     return dict(name=f"arm_press_{root}{'_box' if with_box else ''}", world=w, dis=dis, vel=vel, motor_in=inp, max_rigid=12, steps=200)
+
+
+def arm_fold(batch=8, seed=0x5EED00E1, solver=B.SOLVER_MLCP, unreg=False):
+    """TEST scenario (SELF-COLLISION): models/arm_fold.ztk folded so that its last link's box presses on its first link's
+    box - a rigid contact whose two sides are links of ONE chain (the pairs registration forms by default between the
+    cells of a chain, reference src/rkfd_sim.c:198; probed through the "self collision" branch of src/rkfd_util.c:163-170).
+    The joint-3 motor presses the finger down, so the contact force is an internal force of the arm.  unreg=True calls
+    rkCDPairChainUnreg for the arm as the reference's arm drivers do (example/chain/arm_box_test.c:49): the finger then
+    passes through the beam."""
+    w = B.World(solver=solver)
+    w.contact_info(_m("contactinfo.ztk"))
+    a = w.reg_file(_m("arm_fold.ztk"))
+    w.reg_file(_m("floor.ztk"))
+    if unreg:
+        w.pair_chain_unreg(a)
+    m = w.model.contents
+    u = splitmix64_uniform(seed, batch * 8).reshape(batch, 8)
+    dis = np.zeros((batch, m.ndof)); vel = np.zeros((batch, m.ndof)); inp = np.zeros((batch, m.nlink))
+    ao, lo_ = w.dof_offset(a), w.link_offset(a)
+    slink = m.arr("shape_link", m.nshape); voff = m.arr("shape_voff", m.nshape + 1)
+    fsh = [sh for sh in range(m.nshape) if slink[sh] == lo_ + 3][0]        # the finger's shape; vertices of the chain come in shape order
+    v0 = int(voff[fsh] - voff[[sh for sh in range(m.nshape) if slink[sh] == lo_][0]])
+    nv = int(voff[fsh + 1] - voff[fsh])
+    for b in range(batch):
+        q = np.zeros(m.ndof)
+        q[ao + 0] = (u[b, 0] - 0.5) * 0.2
+        q[ao + 1] = np.deg2rad(130.0 + 6.0 * (u[b, 1] - 0.5))
+        lo, hi = np.deg2rad(150.0), np.deg2rad(178.0)        # joint 3: the finger's lowest vertex SEAT_DEPTH inside the beam's top face
+        for _ in range(60):
+            q[ao + 2] = 0.5 * (lo + hi)
+            Rl, pl = link_frames(m, q[None])
+            f = chain_vertices(m, q, a)[v0:v0 + nv]
+            y = ((f - pl[0, lo_ + 1]) @ Rl[0, lo_ + 1])[:, 1].min() - 0.02
+            if y > -SEAT_DEPTH:
+                hi = q[ao + 2]
+            else:
+                lo = q[ao + 2]
+        dis[b] = q
+        vel[b, ao:ao + 3] = (u[b, 2:5] - 0.5) * 0.1
+        inp[b, lo_ + 3] = -1.0 - u[b, 5]                      # joint 3 presses the finger onto the beam
+        inp[b, lo_ + 1] = 2.0 * u[b, 6]                       # joint 1 carries part of the arm's weight
+    return dict(name="arm_fold" + ("_unreg" if unreg else ""), world=w, dis=dis, vel=vel, motor_in=inp, max_rigid=8, steps=200)
 
 
 def config3_26(batch=4096, first=0):

@@ -143,6 +143,7 @@ def test_emulated_world_with_more_than_256_candidates(R, oracle_cls, which):
             pytest.skip("reference checkout not present")
         w = R.World(solver=R.SOLVER_MLCP); w.contact_info(os.path.join(R.scenarios.MODELS, "contact_rigid.ztk"))
         h = w.reg_file(ref); w.reg_file(os.path.join(R.scenarios.MODELS, "floor.ztk"))
+        w.pair_chain_unreg(h)     # the robot's own pairs off, as the reference's drivers do for an articulated chain (arm_box_test.c:49)
         dis = w.init_dis(h)[None].copy()
         dis[0, 2] -= R.scenarios.lowest_vertex_z(w.model.contents, dis[0], h) + R.scenarios.SEAT_DEPTH
         sc = dict(world=w, dis=dis, vel=np.zeros_like(dis), max_rigid=8); nsteps = 2
@@ -182,7 +183,7 @@ def test_emulated_spherical_joints(R, oracle_cls, which):
         if not os.path.exists(ref):
             pytest.skip("reference checkout not present")
         w = R.World(solver=R.SOLVER_MLCP); w.contact_info(os.path.join(R.scenarios.MODELS, "contactinfo.ztk"))
-        w.reg_file(ref)           # (alone: with the floor its tessellated spheres and cylinders make 2361 candidates, above the limit of 1024)
+        w.pair_chain_unreg(w.reg_file(ref))           # (alone: with the floor its tessellated spheres and cylinders make 2361 candidates, above the limit of 1024)
         m = w.model.contents
         rng = np.random.default_rng(3)
         sc = dict(world=w, dis=rng.uniform(-0.4, 0.4, (2, m.ndof)), vel=rng.uniform(-1, 1, (2, m.ndof)), max_rigid=8); nsteps = 3
@@ -293,7 +294,10 @@ def test_emulated_reference_arm_box_world_under_volume(R, oracle_cls):
     M = "/root/reference/example/model"
     w = R.World(solver=R.SOLVER_VOLUME)
     w.contact_info(os.path.join(M, "contactinfo.ztk"))
-    w.reg_file(os.path.join(M, "arm_2DoF.ztk")); b = w.reg_file(os.path.join(M, "box.ztk")); w.reg_file(os.path.join(M, "floor.ztk"))
+    a = w.reg_file(os.path.join(M, "arm_2DoF.ztk")); b = w.reg_file(os.path.join(M, "box.ztk")); w.reg_file(os.path.join(M, "floor.ztk"))
+    m = w.model.contents
+    assert m.npair == 11 + 8        # the arm's five cells on three links: eight pairs of its own ...
+    w.pair_chain_unreg(a)           # ... which the driver unregisters (arm_box_test.c:49); arm x box, arm x floor, box x floor stay
     m = w.model.contents
     assert m.npair == 11
     dis = np.zeros(m.ndof); off = w.dof_offset(b); dis[off:off + 3] = (0.3, 0.0, 0.05 - 1e-5)
@@ -348,3 +352,70 @@ def test_emulated_volume_slide_mode(R, oracle_cls):
             o.update_n(60)
         ends[who] = o.get_state()[0][:2].copy()
     assert np.abs(ends["none"] - ends["both"]).max() > 1e-3
+
+
+def _oracle_step_from(oracle_cls, model, motor_in, st, ct, pv, dq=None):
+    """one rkFDUpdate of a fresh oracle from the given state (optionally with joint displacement j nudged: dq = (j, eps))"""
+    o = oracle_cls(model); o.set_motor_input(motor_in)
+    d = st[0].copy()
+    if dq is not None:
+        d[dq[0]] += dq[1]
+    o.set_state(d, st[1]); o.set_contact(*ct[:3]); o.set_pivot(*pv); o.update_init()
+    o.set_contact(*ct[:3]); o.set_pivot(*pv)
+    o.update()
+    return o
+
+
+@pytest.mark.parametrize("solver", ["mlcp", "vert"])
+def test_emulated_self_collision_matches_oracle(R, oracle_cls, solver):
+    """SELF-COLLISION (scenarios.arm_fold): a rigid contact between two links of ONE chain - the pairs registration forms by
+    default (reference src/rkfd_sim.c:198, "self collision" branch of src/rkfd_util.c:163-170).  Both sides of the contact
+    are on the same tree: the probe paths of the two sides share the joints above their common ancestor, the contact
+    matrix gets the cross terms between the sides, the force is an internal force of the arm.
+    The finger bounces on the beam (the last joint's inertia is tiny) and the system is stiff by construction: the oracle's
+    own d(acc)/d(q) is 5e5 ... 8e7 s^-2 in contact (measured below by nudging a joint by 1e-12 rad), so two correct
+    implementations whose vertex positions differ in the last bit (1e-16 m) differ by up to 1e-8 in acc.  Every step
+    therefore starts from the oracle's state, and the tolerance is 1e-9 relative PLUS what a 2e-14 rad nudge of the state
+    does to the oracle's own result."""
+    B, nsteps = 2, 10
+    sc = R.scenarios.arm_fold(batch=B, solver=R.SOLVER_MLCP if solver == "mlcp" else R.SOLVER_VERT)
+    model = sc["world"].model
+    eb = EmuBatch(sc["world"], B, max_rigid=sc["max_rigid"])
+    eb.set_motor_input(sc["motor_in"])
+    os_ = []
+    for i in range(B):
+        o = oracle_cls(model)
+        o.set_state(sc["dis"][i], sc["vel"][i]); o.set_motor_input(sc["motor_in"][i]); o.update_init()
+        os_.append(o)
+    in_contact = 0
+    for k in range(nsteps):
+        st = [o.get_state() for o in os_]; ct = [o.get_contact() for o in os_]; pv = [o.get_pivot() for o in os_]
+        eb.set_state(np.array([x[0] for x in st]), np.array([x[1] for x in st]))
+        eb.set_contact(np.array([c[0] for c in ct]), np.array([c[1] for c in ct]), np.array([c[2] for c in ct]))
+        eb.set_pivot(np.array([p_[0] for p_ in pv]), np.array([p_[1] for p_ in pv]))
+        eb.update(1)
+        assert eb.status() == 0
+        dis, vel, acc = eb.get_state()
+        act, typ, ref, f = eb.get_contact()
+        for i, o in enumerate(os_):
+            o.update()
+            od, ov, oa = o.get_state()
+            oact, otyp, oref, of = o.get_contact()
+            in_contact += int(oact.sum() >= 1 and np.abs(of).max() > 1.0)
+            # the oracle's own sensitivity of this step to its start state
+            sa = sf = 0.0
+            for j in range(3):
+                on = _oracle_step_from(oracle_cls, model, sc["motor_in"][i], st[i], ct[i], pv[i], dq=(j, 1e-12))
+                sa = max(sa, np.abs(on.get_state()[2] - oa).max() / 1e-12); sf = max(sf, np.abs(on.get_contact()[3] - of).max() / 1e-12)
+            assert np.abs(dis[i] - od).max() < 1e-9 and np.abs(vel[i] - ov).max() < 1e-9 * max(1.0, np.abs(ov).max()) + 2e-14 * sa * 1e-3
+            assert np.abs(acc[i] - oa).max() < 1e-9 * max(1.0, np.abs(oa).max()) + 2e-14 * sa, (k, i, sa)
+            assert (act[i] == oact).all() and (typ[i] == otyp * (oact != 0)).all()
+            assert np.abs(f[i] - of).max() < 1e-9 * max(1.0, np.abs(of).max()) + 2e-14 * sf, (k, i, sf)
+    assert in_contact >= nsteps          # the finger does press on the beam in most steps
+    # with the arm's own pairs unregistered (what the reference's arm drivers do) the finger meets nothing
+    sc2 = R.scenarios.arm_fold(batch=1, unreg=True)
+    o = oracle_cls(sc2["world"].model)
+    o.set_state(sc2["dis"][0], sc2["vel"][0]); o.set_motor_input(sc2["motor_in"][0]); o.update_init()
+    assert o.get_contact()[0].sum() == 0
+    o.update_n(2)
+    assert o.get_contact()[0].sum() == 0

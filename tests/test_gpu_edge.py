@@ -160,6 +160,68 @@ def test_arm_press_paths(R, oracle_cls, root, with_box):
         assert seen > 0
 
 
+@pytest.mark.parametrize("solver", ["mlcp", "vert"])
+def test_self_collision(R, oracle_cls, solver):
+    """SELF-COLLISION on the GPU (scenarios.arm_fold: the folded arm's last link presses on its first): a rigid contact
+    whose two sides are links of ONE chain - the pairs registration forms by default (reference src/rkfd_sim.c:198; probed
+    through the "self collision" branch of src/rkfd_util.c:163-170).  The finger bounces and the system is stiff by
+    construction (the oracle's own d(acc)/d(q) is 5e5 ... 8e7 s^-2 in contact), so every step starts from the oracle's
+    state and the tolerance is 1e-9 relative plus what a 2e-14 rad nudge of the start state does to the oracle's own
+    result (same test under the lane emulator: tests/test_emu_parity.py)."""
+    B, nsteps = 8, 12
+    sc = R.scenarios.arm_fold(batch=B, solver=R.SOLVER_MLCP if solver == "mlcp" else R.SOLVER_VERT)
+    model = sc["world"].model
+    b = R.Batch(sc["world"], B, max_rigid=sc["max_rigid"])
+    b.set_motor_input(sc["motor_in"])
+    b.set_state(sc["dis"], sc["vel"]); b.update_init()
+    os_ = []
+    for i in range(B):
+        o = oracle_cls(model)
+        o.set_state(sc["dis"][i], sc["vel"][i]); o.set_motor_input(sc["motor_in"][i]); o.update_init()
+        os_.append(o)
+    in_contact = 0
+
+    def step_from(i, st, ct, pv, dq):
+        o = oracle_cls(model); o.set_motor_input(sc["motor_in"][i])
+        d = st[0].copy(); d[dq[0]] += dq[1]
+        o.set_state(d, st[1]); o.set_contact(*ct[:3]); o.set_pivot(*pv); o.update_init()
+        o.set_contact(*ct[:3]); o.set_pivot(*pv)
+        o.update()
+        return o
+    for k in range(nsteps):
+        st = [o.get_state() for o in os_]; ct = [o.get_contact() for o in os_]; pv = [o.get_pivot() for o in os_]
+        b.set_state(np.array([x[0] for x in st]), np.array([x[1] for x in st]))
+        b.set_contact(np.array([c[0] for c in ct]), np.array([c[1] for c in ct]), np.array([c[2] for c in ct]))
+        b.set_pivot(np.array([p_[0] for p_ in pv]), np.array([p_[1] for p_ in pv]))
+        b.update(1)
+        assert b.status() == 0
+        dis, vel, acc = b.get_state()
+        act, typ, ref, f = b.get_contact()
+        for i, o in enumerate(os_):
+            o.update()
+            od, ov, oa = o.get_state()
+            oact, otyp, oref, of = o.get_contact()
+            in_contact += int(oact.sum() >= 1 and np.abs(of).max() > 1.0)
+            sa = sf = 0.0
+            for j in range(3):
+                on = step_from(i, st[i], ct[i], pv[i], (j, 1e-12))
+                sa = max(sa, np.abs(on.get_state()[2] - oa).max() / 1e-12); sf = max(sf, np.abs(on.get_contact()[3] - of).max() / 1e-12)
+            assert np.abs(dis[i] - od).max() < 1e-9 and np.abs(vel[i] - ov).max() < 1e-9 * max(1.0, np.abs(ov).max()) + 2e-17 * sa
+            assert np.abs(acc[i] - oa).max() < 1e-9 * max(1.0, np.abs(oa).max()) + 2e-14 * sa, (k, i, sa)
+            assert (act[i] == oact).all() and (typ[i] == otyp * (oact != 0)).all()
+            assert np.abs(f[i] - of * (oact[:, None] != 0)).max() < 1e-9 * max(1.0, np.abs(of).max()) + 2e-14 * sf, (k, i, sf)
+    assert in_contact >= B * nsteps // 2
+    # the arm's own pairs unregistered, as the reference's arm drivers do (arm_box_test.c:49): the finger meets nothing
+    sc2 = R.scenarios.arm_fold(batch=2, unreg=True)
+    b2 = R.Batch(sc2["world"], 2, max_rigid=sc2["max_rigid"])
+    b2.set_state(sc2["dis"], sc2["vel"]); b2.set_motor_input(sc2["motor_in"]); b2.update_init(); b2.update(3)
+    assert b2.status() == 0 and b2.get_contact()[0].sum() == 0
+    for i in range(2):
+        o = oracle_cls(sc2["world"].model)
+        o.set_state(sc2["dis"][i], sc2["vel"][i]); o.set_motor_input(sc2["motor_in"][i]); o.update_init(); o.update_n(3)
+        assert _rel(b2.get_state()[2][i], o.get_state()[2]) < RTOL
+
+
 def test_far_from_the_world_origin(R, oracle_cls):
     """spatial quantities are taken about the anchor link, not the world origin: a humanoid in free
     flight 1 km away from the origin still matches the oracle (parallel-axis terms about the world

@@ -39,15 +39,58 @@ def test_contact_info_association_and_pair_unreg(R):
     w.contact_info(os.path.join(R.scenarios.MODELS, "contactinfo.ztk"))
     b1 = w.reg_file(os.path.join(R.scenarios.MODELS, "box.ztk"))
     b2 = w.reg_file(os.path.join(R.scenarios.MODELS, "box.ztk"))
-    w.pair_chain_unreg(b2)                                          # as reference example/chain/boxdrop_test.c:37
+    w.pair_chain_unreg(b1); w.pair_chain_unreg(b2)                  # as reference example/chain/boxdrop_test.c:37: a chain's OWN pairs
     w.reg_file(os.path.join(R.scenarios.MODELS, "floor_hardsoft.ztk"))
     m = w.model.contents
-    assert m.npair == 4                                             # 2 boxes x (ground, soft); no box-box pair
+    # box x box (they can land on each other: the call above drops nothing of a one-link box), 2 boxes x (ground, soft);
+    # the floor's own ground - soft pair is not formed: the two links are rigidly attached to each other
+    assert m.npair == 5
+    assert m.arr("pair_shape", 2 * m.npair).reshape(-1, 2).tolist() == [[0, 1], [0, 2], [1, 2], [0, 3], [1, 3]]
     types = m.arr("ci_type", m.nci)[m.arr("pair_ci", m.npair)]
-    assert sorted(types.tolist()) == [R.CONTACT_RIGID, R.CONTACT_RIGID, R.CONTACT_ELASTIC, R.CONTACT_ELASTIC]
+    assert types.tolist() == [R.CONTACT_RIGID, R.CONTACT_RIGID, R.CONTACT_RIGID, R.CONTACT_ELASTIC, R.CONTACT_ELASTIC]
     # box planes: 6 unit normals
     pl = m.arr("planes", 4 * m.arr("shape_foff", m.nshape + 1)[-1]).reshape(-1, 4)
     assert np.allclose(np.linalg.norm(pl[:, :3], axis=1), 1.0)
+
+
+def test_pair_chain_unreg_drops_only_the_chains_own_pairs(R):
+    """rkCDPairChainUnreg in the call order of reference example/chain/arm_box_test.c:39-49: arm, box and floor are
+    registered FIRST, then the arm's pairs are unregistered - and the arm must go on touching the box and the floor.  So
+    the call removes the pairs whose two cells both belong to the chain (self-collision), which registration
+    (rkCDChainReg, reference src/rkfd_sim.c:198) forms by default between cells on different links of one chain."""
+    M = R.scenarios.MODELS
+    w = R.World(solver=R.SOLVER_MLCP)
+    w.contact_info(os.path.join(M, "contactinfo.ztk"))
+    arm = w.reg_file(os.path.join(M, "arm_fold.ztk"))              # a base block and a box on each of three links
+    box = w.reg_file(os.path.join(M, "box.ztk"))
+    floor = w.reg_file(os.path.join(M, "floor.ztk"))
+
+    def pairs():
+        m = w.model.contents
+        ch = m.arr("chain", m.nlink)[m.arr("shape_link", m.nshape)]
+        ps = m.arr("pair_shape", 2 * m.npair).reshape(-1, 2)
+        return [tuple(sorted((int(ch[a]), int(ch[b])))) for a, b in ps], ps
+    kinds, ps = pairs()
+    assert kinds.count((arm, arm)) == 6                             # 4 cells on 4 different links: every one against every other
+    assert kinds.count((arm, box)) == 4 and kinds.count((arm, floor)) == 4 and kinds.count((box, floor)) == 1
+    assert (ps[:, 0] < ps[:, 1]).all()                              # later cell x earlier cells, in registration order
+    w.pair_chain_unreg(arm)
+    kinds, _ = pairs()
+    assert kinds.count((arm, arm)) == 0                             # the arm's own pairs are gone ...
+    assert kinds.count((arm, box)) == 4 and kinds.count((arm, floor)) == 4 and kinds.count((box, floor)) == 1      # ... nothing else
+    w.pair_chain_unreg(box)                                         # a one-link chain has no pairs of its own
+    assert pairs()[0] == kinds
+
+
+def test_humanoid_scenarios_carry_no_self_pairs_and_config5_has_box_box_pairs(R):
+    sc = R.scenarios.config5(batch=1)
+    m = sc["world"].model.contents
+    ch = m.arr("chain", m.nlink)[m.arr("shape_link", m.nshape)]
+    ps = m.arr("pair_shape", 2 * m.npair).reshape(-1, 2)
+    kinds = [tuple(sorted((int(ch[a]), int(ch[b])))) for a, b in ps]
+    assert all(a != b for a, b in kinds)                            # the humanoid's sole - sole pair was unregistered
+    assert sum(1 for a, b in kinds if a < 4 and b < 4) == 6         # four boxes: six box - box pairs
+    assert (m.npair, m.ncand) == (20, 320)
 
 
 def test_unknown_file_fails_loudly(R):
@@ -155,7 +198,7 @@ def test_reader_loads_the_reference_shipped_models(R):
     # spherical joints run on the device (three pseudo-links per joint); breakable-float joints are read, but a world
     # that holds one is refused by the device path (and the oracle) with a message
     for f in ("arm.ztk", "dualarm.ztk"):
-        w = R.World(); w.reg_file(os.path.join(REF_MODELS, f))
+        w = R.World(); w.pair_chain_unreg(w.reg_file(os.path.join(REF_MODELS, f)))      # (own pairs off, as the reference's arm drivers do)
         assert R.lib().rkfdLdsBytesFor(w.model, 0) > 0, R.lib().rkfdHipLastError()
     w = R.World(); w.reg_file(os.path.join(REF_MODELS, "wall.ztk"))
     assert R.lib().rkfdLdsBytesFor(w.model, 0) < 0
