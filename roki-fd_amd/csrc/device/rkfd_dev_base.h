@@ -460,6 +460,13 @@ typedef struct { double min, pivp; int pivt;
 #define RKFD_CS_SIDE(e)   ( (int)( ( (e) >> 30 ) & 1 ) )
 #define RKFD_CS_VALID(e)  ( (int)( (e) >> 31 ) )
 
+/* The probe scratch PU: entry ( side s, column col of the contact problem, tree level d ) - the scaled innovation the unit probe of
+ * that column leaves at the joint of its path on level d; the six components of a float joint sit at levels nlevel .. nlevel + 5.
+ * A column's levels are contiguous (the delta-sweep inputs read lane = level: neighbouring addresses), no 1-DoF joint sits above
+ * level pu_d0, and every stride is a dimension of the WORLD (a literal in the kernels compiled for one world), not of the
+ * evaluation's contact count. */
+#define RKFD_PU_AT(m, s, col, d) ( ( (s)*3*(m).maxrg + (col) )*(m).npurow + (d) - (m).pu_d0 )
+
 /* counters in L->cnt */
 #define CNT_NRG 0
 #define CNT_NEL 1

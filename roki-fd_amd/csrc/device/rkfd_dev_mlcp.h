@@ -539,7 +539,7 @@ typedef double rkfd_d4 __attribute__((ext_vector_type(4)));
 RKFD_DEV void rkfd_mlcp_matrix_mfma(const rkfdDevModel &m, const rkfdLds &L, int nc, int ld, bool vert)
 {
   const int lane = LANE();
-  const int M = 3*nc, NLV = m.nlevel, NL = m.nlink, NSD = m.nside, PUS = m.npurow*M;
+  const int M = 3*nc, NLV = m.nlevel, NL = m.nlink, NSD = m.nside;
   const unsigned char *TOP = L.PL + NL*NLV, *FSL = TOP + NL;
   const int kk = lane >> 4, cc = lane & 15;
   const int col0 = cc, col1 = 16 + cc;
@@ -548,7 +548,7 @@ RKFD_DEV void rkfd_mlcp_matrix_mfma(const rkfdDevModel &m, const rkfdLds &L, int
   if( col1 < M ){ e10 = (unsigned)L.tgt[( col1/3 )*NSD]; if( NSD > 1 ) e11 = (unsigned)L.tgt[( col1/3 )*NSD+1]; }
   rkfd_d4 c00 = { 0, 0, 0, 0 }, c01 = { 0, 0, 0, 0 }, c11 = { 0, 0, 0, 0 };
   /* element of N' for (joint j at depth d, column col) from one side's packed path record */
-#define RKFD_NP_ELEM(e, s, col) ( ( RKFD_CS_VALID( e ) && d >= RKFD_CS_D0( e ) && d <= RKFD_CS_DEPTH( e ) && L.PL[RKFD_CS_LINK( e )*NLV+d] == j ) ? L.PU[(s)*PUS + d*M + (col)] : 0.0 )
+#define RKFD_NP_ELEM(e, s, col) ( ( RKFD_CS_VALID( e ) && d >= RKFD_CS_D0( e ) && d <= RKFD_CS_DEPTH( e ) && L.PL[RKFD_CS_LINK( e )*NLV+d] == j ) ? L.PU[RKFD_PU_AT( m, s, col, d )] : 0.0 )
   for( int j0=0; j0<NL; j0+=4 ){
     const int j = j0 + kk;
     const int lij = j < NL ? L.LI[j] : 0, jt = RKFD_LI_JT( lij ), d = RKFD_LI_DEPTH( lij );
@@ -562,7 +562,7 @@ RKFD_DEV void rkfd_mlcp_matrix_mfma(const rkfdDevModel &m, const rkfdLds &L, int
     if( M > 16 ) c11 = __builtin_amdgcn_mfma_f64_16x16x4f64( a1, a1, c11, 0, 0, 0 );
   }
 #undef RKFD_NP_ELEM
-#define RKFD_NP_FLT(e, s, col) ( ( RKFD_CS_VALID( e ) && RKFD_CS_FLOAT( e ) && FSL[RKFD_CS_TOP( e )] == f ) ? L.PU[(s)*PUS + ( NLV+q )*M + (col)] : 0.0 )
+#define RKFD_NP_FLT(e, s, col) ( ( RKFD_CS_VALID( e ) && RKFD_CS_FLOAT( e ) && FSL[RKFD_CS_TOP( e )] == f ) ? L.PU[RKFD_PU_AT( m, s, col, NLV+q )] : 0.0 )
   for( int f=0; f<m.nfloat; f++ )
     for( int q0=0; q0<8; q0+=4 ){
       const int q = q0 + kk;
@@ -626,7 +626,7 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
   const int ld = ( m.vert_rigid || nc < m.maxrg ) ? M+1 : M;   /* odd row stride unless every slot is taken (see rkfd_lds_carve) */
   const int NLV = m.nlevel, NL = m.nlink, NR = m.npurow;
   const int NSD = m.nside;
-  const int PUS = NR*M;                               /* stride between the two sides of PU */
+  const int PUS = 3*m.maxrg;                          /* columns between the two sides of PU (RKFD_PU_AT) */
   const unsigned char *TOP = L.PL + NL*NLV;           /* where a force on a link stops propagating (255: static) */
   const unsigned char *FSL = TOP + NL;                /* float slot of a link */
   const double dt = m.dt;
@@ -724,7 +724,7 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
         const double sg = RKFD_CS_SIDE( e ) == 0 ? -1.0 : 1.0;
 #pragma unroll
         for( int k=0; k<6; k++ ) dp[k] = sg*W[k];
-        double *pu = &L.PU[s2*PUS + col];
+        double *pu = &L.PU[RKFD_PU_AT( m, s2, col, 0 )];
         const unsigned char *path = &L.PL[a*NLV];
         double Sx[6], Ux[6], sdx, dix;
 #pragma unroll
@@ -742,7 +742,7 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
           du0 = fma( Sx[2], dp[2], du0 ); du1 = fma( Sx[3], dp[3], du1 );
           du0 = fma( Sx[4], dp[4], du0 ); du1 = fma( Sx[5], dp[5], du1 );
           const double du = -( du0 + du1 );
-          pu[d*M] = du*sdx;
+          pu[d] = du*sdx;
           const double t = du*dix;
 #pragma unroll
           for( int k=0; k<6; k++ ) dp[k] = fma( Ux[k], t, dp[k] );
@@ -759,7 +759,7 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
           d_chol6_load( &L.CHOL[21*FSL[RKFD_CS_TOP( e )]], Lr );
           d_chol6_fwd( Lr, rhs, y );
 #pragma unroll
-          for( int k=0; k<6; k++ ) pu[( NLV+k )*M] = y[k];
+          for( int k=0; k<6; k++ ) pu[NLV+k] = y[k];
         }
       }
     }
@@ -815,7 +815,7 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
       for( int sr=0; sr<NSD; sr++ ) for( int sk=0; sk<NSD; sk++ ){
         const unsigned er = (unsigned)L.tgt[cr*NSD+sr], ek = (unsigned)L.tgt[ck*NSD+sk];
         if( !RKFD_CS_VALID( er ) || !RKFD_CS_VALID( ek ) || RKFD_CS_TOP( er ) != RKFD_CS_TOP( ek ) ) continue;   /* no joint in common */
-        const double *pr = &L.PU[sr*PUS + 3*cr], *pkk = &L.PU[sk*PUS + 3*ck];
+        const double *pr = &L.PU[RKFD_PU_AT( m, sr, 3*cr, 0 )], *pkk = &L.PU[RKFD_PU_AT( m, sk, 3*ck, 0 )];
         const int a = RKFD_CS_LINK( er ), b = RKFD_CS_LINK( ek );
         const int d0 = RKFD_CS_D0( er );
         int dc = RKFD_CS_DEPTH( er ) < RKFD_CS_DEPTH( ek ) ? RKFD_CS_DEPTH( er ) : RKFD_CS_DEPTH( ek );
@@ -827,8 +827,8 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
         }
 #pragma unroll 2
         for( int d=d0; d<=dc; d++ ){
-          const double r0 = pr[d*M], r1 = pr[d*M+1], r2 = pr[d*M+2];
-          const double k0 = pkk[d*M], k1 = pkk[d*M+1], k2 = pkk[d*M+2];
+          const double r0 = pr[d], r1 = pr[NR+d], r2 = pr[2*NR+d];
+          const double k0 = pkk[d], k1 = pkk[NR+d], k2 = pkk[2*NR+d];
           blk[0] = fma( r0, k0, blk[0] ); blk[1] = fma( r0, k1, blk[1] ); blk[2] = fma( r0, k2, blk[2] );
           blk[3] = fma( r1, k0, blk[3] ); blk[4] = fma( r1, k1, blk[4] ); blk[5] = fma( r1, k2, blk[5] );
           blk[6] = fma( r2, k0, blk[6] ); blk[7] = fma( r2, k1, blk[7] ); blk[8] = fma( r2, k2, blk[8] );
@@ -837,8 +837,8 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
 #pragma unroll
           for( int q=0; q<6; q++ ){
             const int d = NLV + q;
-            const double r0 = pr[d*M], r1 = pr[d*M+1], r2 = pr[d*M+2];
-            const double k0 = pkk[d*M], k1 = pkk[d*M+1], k2 = pkk[d*M+2];
+            const double r0 = pr[d], r1 = pr[NR+d], r2 = pr[2*NR+d];
+            const double k0 = pkk[d], k1 = pkk[NR+d], k2 = pkk[2*NR+d];
             blk[0] = fma( r0, k0, blk[0] ); blk[1] = fma( r0, k1, blk[1] ); blk[2] = fma( r0, k2, blk[2] );
             blk[3] = fma( r1, k0, blk[3] ); blk[4] = fma( r1, k1, blk[4] ); blk[5] = fma( r1, k2, blk[5] );
             blk[6] = fma( r2, k0, blk[6] ); blk[7] = fma( r2, k1, blk[7] ); blk[8] = fma( r2, k2, blk[8] );
@@ -983,7 +983,7 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
     const int link = has ? dtask & 255 : 0, fq = has ? dtask >> 8 : 0;
     const int lii = L.LI[link], jt = RKFD_LI_JT( lii );
     const bool is1 = has && RKFD_JT_IS1( jt ), isf = has && !is1;
-    const int dpt = is1 ? RKFD_LI_DEPTH( lii ) : 0;
+    const int dpt = is1 ? RKFD_LI_DEPTH( lii ) : m.pu_d0;
     const int row = isf ? NLV+fq : dpt;
     double sum = 0;
     /* one side of one contact: its share of this lane's sum (e: the side's record, wave-uniform) */
@@ -998,7 +998,7 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
       double g0 = 0, g1 = 0, g2 = 0;
       if( lane < nc ){ g0 = L.MF[3*lane]; g1 = L.MF[3*lane+1]; g2 = L.MF[3*lane+2]; }
       unsigned long long todo = BALLOT( RKFD_CS_VALID( (unsigned)mytgt ) != 0 );
-      const double *pur = &L.PU[row*M];
+      const double *pur = &L.PU[RKFD_PU_AT( m, 0, 0, row )];
       while( todo ){
         const int csa = __builtin_ctzll( todo );
         todo &= todo - 1ull;
@@ -1007,9 +1007,9 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
         todo &= todo - 1ull;
         const unsigned ea = (unsigned)BCASTI( mytgt, csa ), eb = (unsigned)BCASTI( mytgt, csb );
         const int ca = NSD == 1 ? csa : csa >> 1, cb = NSD == 1 ? csb : csb >> 1;
-        const double *pa = pur + ( NSD == 1 ? 0 : ( csa & 1 ) )*PUS + 3*ca, *pb = pur + ( NSD == 1 ? 0 : ( csb & 1 ) )*PUS + 3*cb;
-        const double va = BCAST( g0, ca )*pa[0] + BCAST( g1, ca )*pa[1] + BCAST( g2, ca )*pa[2];
-        const double vb = BCAST( g0, cb )*pb[0] + BCAST( g1, cb )*pb[1] + BCAST( g2, cb )*pb[2];
+        const double *pa = pur + ( ( NSD == 1 ? 0 : ( csa & 1 ) )*PUS + 3*ca )*NR, *pb = pur + ( ( NSD == 1 ? 0 : ( csb & 1 ) )*PUS + 3*cb )*NR;
+        const double va = BCAST( g0, ca )*pa[0] + BCAST( g1, ca )*pa[NR] + BCAST( g2, ca )*pa[2*NR];
+        const double vb = BCAST( g0, cb )*pb[0] + BCAST( g1, cb )*pb[NR] + BCAST( g2, cb )*pb[2*NR];
         /* (no short-circuit evaluation: as branches around the byte load the test serialised the two sides) */
         const int pla = L.PL[RKFD_CS_LINK( ea )*NLV+dpt], plb = L.PL[RKFD_CS_LINK( eb )*NLV+dpt];
         const bool o1a = ( RKFD_CS_DEPTH( ea ) >= dpt ) & ( RKFD_CS_D0( ea ) <= dpt ) & ( pla == link );
@@ -1024,8 +1024,8 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
       const unsigned e = (unsigned)BCASTI( L.tgt[cs], 0 );
       if( !RKFD_CS_VALID( e ) ) continue;
       const int c = NSD == 1 ? cs : cs >> 1;
-      const double *pu = &L.PU[( NSD == 1 ? 0 : ( cs & 1 ) )*PUS + row*M + 3*c];
-      const double v = L.MF[3*c]*pu[0] + L.MF[3*c+1]*pu[1] + L.MF[3*c+2]*pu[2];
+      const double *pu = &L.PU[RKFD_PU_AT( m, NSD == 1 ? 0 : ( cs & 1 ), 3*c, row )];
+      const double v = L.MF[3*c]*pu[0] + L.MF[3*c+1]*pu[NR] + L.MF[3*c+2]*pu[2*NR];
       /* 1-DoF joint: it lies on the moving path of the contact side; float joint: the path ends there */
       sum += RKFD_DIN_ONP( e ) ? v : 0.0;
     }

@@ -130,7 +130,7 @@ template<bool prof, int vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDevM
   m.nlink = RKFD_SPEC_NLINK; m.ndof = RKFD_SPEC_NDOF; m.ncand = RKFD_SPEC_NCAND; m.nlink_model = RKFD_SPEC_NLINK_MODEL;
   m.nlevel = RKFD_SPEC_NLEVEL; m.nround = RKFD_SPEC_NROUND; m.maxrg = RKFD_SPEC_MAXRG;
   m.npool = RKFD_SPEC_NPOOL; m.nfloat = RKFD_SPEC_NFLOAT; m.maxact = RKFD_SPEC_MAXACT; m.nside = RKFD_SPEC_NSIDE;
-  m.npurow = RKFD_SPEC_NPUROW; m.pu_alias = RKFD_SPEC_PU_ALIAS; m.vert_rigid = RKFD_SPEC_VERT_RIGID; m.qscr_alias = RKFD_SPEC_QSCR_ALIAS;
+  m.npurow = RKFD_SPEC_NPUROW; m.pu_d0 = RKFD_SPEC_PU_D0; m.pu_alias = RKFD_SPEC_PU_ALIAS; m.vert_rigid = RKFD_SPEC_VERT_RIGID; m.qscr_alias = RKFD_SPEC_QSCR_ALIAS;
   m.has_slide = RKFD_SPEC_HAS_SLIDE; m.ma_size = RKFD_SPEC_MA_SIZE; m.ma_packed = RKFD_SPEC_MA_PACKED;
   m.max_iter = RKFD_SPEC_MAX_ITER; m.solver = RKFD_SPEC_SOLVER; m.pyramid = RKFD_SPEC_PYRAMID; m.anchor = RKFD_SPEC_ANCHOR;
   m.mlcp_mfma = RKFD_SPEC_MLCP_MFMA;

@@ -965,9 +965,9 @@ template<bool prof> RKFD_DEV void rkfd_phase_volume(const rkfdDevModel &m, const
   unsigned long long q0 = prof ? RKFD_CLOCK() : 0ull, q1;
 #define VST(k) do{ if( prof ){ q1 = RKFD_CLOCK(); pc[k] += q1 - q0; q0 = q1; } }while(0)
   const int lane = LANE();
-  const int np = L.cnt[CNT_NVP], n = 6*np, M = n, ld = n+1;
+  const int np = L.cnt[CNT_NVP], n = 6*np, ld = n+1;
   const int NCP = m.vol_ncp;
-  const int NLV = m.nlevel, NL = m.nlink, NR = m.npurow, NSD = m.nside, PUS = NR*M;
+  const int NLV = m.nlevel, NL = m.nlink, NR = m.npurow, NSD = m.nside;
   const unsigned char *TOP = L.PL + NL*NLV, *FSL = TOP + NL, *FLK = FSL + NL;
   const double dt = m.dt;
 
@@ -1026,7 +1026,7 @@ template<bool prof> RKFD_DEV void rkfd_phase_volume(const rkfdDevModel &m, const
       const double sg = RKFD_CS_SIDE( e ) == 0 ? -1.0 : 1.0;
 #pragma unroll
       for( int k=0; k<6; k++ ) dp[k] = sg*W[k];
-      double *pu = &L.PU[s2*PUS + col];
+      double *pu = &L.PU[RKFD_PU_AT( m, s2, col, 0 )];
       const unsigned char *path = &L.PL[a*NLV];
       for( int d=da; d>=d0; d-- ){
         const int il = path[d];
@@ -1034,7 +1034,7 @@ template<bool prof> RKFD_DEV void rkfd_phase_volume(const rkfdDevModel &m, const
 #pragma unroll
         for( int k=0; k<6; k++ ) du += L.S[6*il+k]*dp[k];
         du = -du;
-        pu[d*M] = du*L.MS[3*il+2];
+        pu[d] = du*L.MS[3*il+2];
         const double t = du*L.MS[3*il+0];
 #pragma unroll
         for( int k=0; k<6; k++ ) dp[k] = fma( L.U[6*il+k], t, dp[k] );
@@ -1046,7 +1046,7 @@ template<bool prof> RKFD_DEV void rkfd_phase_volume(const rkfdDevModel &m, const
         d_chol6_load( &L.CHOL[21*FSL[RKFD_CS_TOP( e )]], Lr );
         d_chol6_fwd( Lr, rhs, y );
 #pragma unroll
-        for( int k=0; k<6; k++ ) pu[( NLV+k )*M] = y[k];
+        for( int k=0; k<6; k++ ) pu[NLV+k] = y[k];
       }
     }
   }
@@ -1061,7 +1061,7 @@ template<bool prof> RKFD_DEV void rkfd_phase_volume(const rkfdDevModel &m, const
       for( int sr=0; sr<NSD; sr++ ) for( int sk=0; sk<NSD; sk++ ){
         const unsigned er = (unsigned)L.tgt[cr*NSD+sr], ek = (unsigned)L.tgt[ck*NSD+sk];
         if( !RKFD_CS_VALID( er ) || !RKFD_CS_VALID( ek ) || RKFD_CS_TOP( er ) != RKFD_CS_TOP( ek ) ) continue;
-        const double *pr = &L.PU[sr*PUS + r], *pk = &L.PU[sk*PUS + k];
+        const double *pr = &L.PU[RKFD_PU_AT( m, sr, r, 0 )], *pk = &L.PU[RKFD_PU_AT( m, sk, k, 0 )];
         const int a = RKFD_CS_LINK( er ), b = RKFD_CS_LINK( ek ), d0 = RKFD_CS_D0( er );
         int dc = RKFD_CS_DEPTH( er ) < RKFD_CS_DEPTH( ek ) ? RKFD_CS_DEPTH( er ) : RKFD_CS_DEPTH( ek );
         if( a != b ){
@@ -1069,9 +1069,9 @@ template<bool prof> RKFD_DEV void rkfd_phase_volume(const rkfdDevModel &m, const
           while( d <= dc && L.PL[a*NLV+d] == L.PL[b*NLV+d] ) d++;
           dc = d-1;
         }
-        for( int d=d0; d<=dc; d++ ) acc = fma( pr[d*M], pk[d*M], acc );
+        for( int d=d0; d<=dc; d++ ) acc = fma( pr[d], pk[d], acc );
         if( RKFD_CS_FLOAT( er ) )
-          for( int q=0; q<6; q++ ) acc = fma( pr[( NLV+q )*M], pk[( NLV+q )*M], acc );
+          for( int q=0; q<6; q++ ) acc = fma( pr[NLV+q], pk[NLV+q], acc );
       }
       L.MA[r*ld+k] = acc;
     }
@@ -1269,16 +1269,16 @@ template<bool prof> RKFD_DEV void rkfd_phase_volume(const rkfdDevModel &m, const
       const int link = isl ? t : ( isf ? FLK[( t-NL )/6] : 0 );
       const int lii = L.LI[link], jt = RKFD_LI_JT( lii );
       const bool is1 = isl && RKFD_JT_IS1( jt );
-      const int dpt = isl ? RKFD_LI_DEPTH( lii ) : 0;
+      const int dpt = is1 ? RKFD_LI_DEPTH( lii ) : m.pu_d0;
       const int row = isf ? NLV+fq : dpt;
       double sum = 0;
       for( int cs=0; cs<np*NSD; cs++ ){
         const unsigned e = (unsigned)L.tgt[cs];
         const int c = NSD == 1 ? cs : cs >> 1;
-        const double *pu = &L.PU[( NSD == 1 ? 0 : ( cs & 1 ) )*PUS + row*M + 6*c];
+        const double *pu = &L.PU[RKFD_PU_AT( m, NSD == 1 ? 0 : ( cs & 1 ), 6*c, row )];
         double v = 0;
 #pragma unroll
-        for( int k=0; k<6; k++ ) v += L.MF[6*c+k]*pu[k];
+        for( int k=0; k<6; k++ ) v += L.MF[6*c+k]*pu[k*NR];
         const bool onp = RKFD_CS_VALID( e ) && ( isf ? RKFD_CS_TOP( e ) == link
                        : ( RKFD_CS_DEPTH( e ) >= dpt && RKFD_CS_D0( e ) <= dpt && L.PL[RKFD_CS_LINK( e )*NLV+dpt] == link ) );
         sum += onp ? v : 0.0;

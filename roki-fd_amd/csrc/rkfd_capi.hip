@@ -423,7 +423,7 @@ static std::string spec_source(const rkfdDevModel &d)
     "#define RKFD_SPEC_NLINK %d\n#define RKFD_SPEC_NDOF %d\n#define RKFD_SPEC_NCAND %d\n#define RKFD_SPEC_NLINK_MODEL %d\n"
     "#define RKFD_SPEC_NLEVEL %d\n#define RKFD_SPEC_NROUND %d\n#define RKFD_SPEC_NSCHED %d\n#define RKFD_SPEC_MAXRG %d\n"
     "#define RKFD_SPEC_NPOOL %d\n#define RKFD_SPEC_NFLOAT %d\n#define RKFD_SPEC_MAXACT %d\n#define RKFD_SPEC_NSIDE %d\n"
-    "#define RKFD_SPEC_NPUROW %d\n#define RKFD_SPEC_PU_ALIAS %d\n#define RKFD_SPEC_VERT_RIGID %d\n#define RKFD_SPEC_QSCR_ALIAS %d\n"
+    "#define RKFD_SPEC_NPUROW %d\n#define RKFD_SPEC_PU_D0 %d\n#define RKFD_SPEC_PU_ALIAS %d\n#define RKFD_SPEC_VERT_RIGID %d\n#define RKFD_SPEC_QSCR_ALIAS %d\n"
     "#define RKFD_SPEC_HAS_SLIDE %d\n#define RKFD_SPEC_MA_SIZE %d\n#define RKFD_SPEC_MA_PACKED %d\n"
     "#define RKFD_SPEC_MAX_ITER %d\n#define RKFD_SPEC_SOLVER %d\n#define RKFD_SPEC_PYRAMID %d\n#define RKFD_SPEC_ANCHOR %d\n#define RKFD_SPEC_MLCP_MFMA %d\n"
     "#define RKFD_SPEC_VOL_NPAIR %d\n#define RKFD_SPEC_VOL_NP %d\n#define RKFD_SPEC_VOL_NCP %d\n#define RKFD_SPEC_VOL_PV %d\n#define RKFD_SPEC_VOL_NF %d\n"
@@ -437,7 +437,7 @@ static std::string spec_source(const rkfdDevModel &d)
     "  rkfd_instance<false, %s, %s>( m, st, b, lds, mode, nsteps, errflag );\n"
     "}\n",
     d.nlink, d.ndof, d.ncand, d.nlink_model, d.nlevel, d.nround, d.nsched, d.maxrg, d.npool, d.nfloat, d.maxact, d.nside,
-    d.npurow, d.pu_alias, d.vert_rigid, d.qscr_alias, d.has_slide, d.ma_size, d.ma_packed, d.max_iter, d.solver, d.pyramid, d.anchor, d.mlcp_mfma,
+    d.npurow, d.pu_d0, d.pu_alias, d.vert_rigid, d.qscr_alias, d.has_slide, d.ma_size, d.ma_packed, d.max_iter, d.solver, d.pyramid, d.anchor, d.mlcp_mfma,
     d.vol_npair, d.vol_np, d.vol_ncp, d.vol_pv, d.vol_nf,
     d.vol_np > 0 ? 2 : 3, d.vol_np > 0 ? "2" : ( d.vert_rigid ? "1" : "0" ), d.ma_packed ? "true" : "false" );
   std::string src;
@@ -568,7 +568,8 @@ extern "C" int rkfdBatchSpecialize(rkfdBatch *b)
     hipFuncGetAttribute( &regs, HIP_FUNC_ATTRIBUTE_NUM_REGS, b->spec_fn );
     hipFuncGetAttribute( &scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, b->spec_fn );
     if( getenv( "RKFD_SPEC_DEBUG" ) ) fprintf( stderr, "rkfdBatchSpecialize: %d VGPRs, %d bytes of scratch per lane, %zu bytes of LDS\n", regs, scratch, b->lds_bytes );
-    if( scratch > ( b->dm.vol_np > 0 ? 512 : 64 ) ){      /* (the Volume variant is built for two waves per SIMD and spills a few registers on purpose) */
+    if( scratch > ( b->dm.vol_np > 0 ? 512 : 160 ) ){      /* (the Volume variant is built for two waves per SIMD and spills a few registers on purpose; worlds with two moving
+                                                             * contact sides sit at the 168-register limit and spill a handful - tools/spec_resources.py; the wrong compiler: 912 B) */
       (void)hipModuleUnload( b->spec_mod ); b->spec_mod = NULL; b->spec_fn = NULL;
       SETERR( "rkfdBatchSpecialize: the compiler hipRTC resolved to in this process produced a spilling kernel (%d VGPRs, %d bytes of scratch per lane); "
               "point RKFD_ROCM_LIBDIR at the ROCm libraries this library was built with; the generic kernel stays in use", regs, scratch );

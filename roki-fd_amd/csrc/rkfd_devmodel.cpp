@@ -547,8 +547,11 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   const size_t Mrows = 3*(size_t)max_rigid;
   /* probe scratch: one row per tree level plus six for a float root, per side; it overlays the
    * C|PA block of the link arrays (dead while the contact problem is solved) when it fits */
-  const int npurow = nlevel + ( nfloat > 0 ? 6 : 0 );
-  dm.npurow = npurow;
+  int pu_d0 = nlevel;
+  for( int i=0; i<NL; i++ ) if( RKFD_JT_IS1( R_jtype[i] ) && depth[i] < pu_d0 ) pu_d0 = depth[i];
+  if( pu_d0 == nlevel ) pu_d0 = nlevel > 0 ? nlevel-1 : 0;      /* (no 1-DoF joint at all: one unused row) */
+  const int npurow = nlevel - pu_d0 + ( nfloat > 0 ? 6 : 0 );
+  dm.npurow = npurow; dm.pu_d0 = pu_d0;
   dm.pu_alias = ( (size_t)nside*npurow*Mrows <= (size_t)12*NL ) ? 1 : 0;
   std::vector<int> dofkind( ND ? ND : 1, 0 );
   for( int i=0; i<NL; i++ ){

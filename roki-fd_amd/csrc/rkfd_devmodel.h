@@ -30,7 +30,8 @@ typedef struct {
   int ma_packed;         /* 1: the contact matrix is kept as a packed lower triangle (PGS kernels only), chosen where it lets one more instance share a CU */
   int ma_size;           /* doubles the contact matrix may take: full rows with an odd stride for the Vert QP, else the packed lower triangle */
   int pyramid;           /* faces of the Vert plugin's friction pyramid                                  */
-  int npurow;            /* rows of PU per side: nlevel (+6 with a float joint)                         */
+  int npurow;            /* rows of PU per side: nlevel - pu_d0 (+6 with a float joint)                 */
+  int pu_d0;             /* first tree level that holds a 1-DoF joint: the probe scratch has no rows above it     */
   int nside;             /* 1 when every rigid-capable pair has a static cell (probe walks one-sided) else 2 */
   int maxrg;             /* capacity: rigid contact vertices solved per instance (3*maxrg <= 128) */
   int mlcp_mfma;         /* bit 0: the contact matrix A = N'N is formed with v_mfma_f64_16x16x4_f64 (worlds with at most 32 rows;
