@@ -18,6 +18,14 @@ template<bool pk> RKFD_DEV int rkfd_ma_idx(int Rr, int K, int ld)
   if( !pk ) return Rr*ld + K;
   return K <= Rr ? ( Rr*( Rr+1 ) >> 1 ) + K : ( K*( K+1 ) >> 1 ) + Rr;
 }
+/* entry ( Rr, K ) as the Gauss-Seidel loops read it: from the TRANSPOSED position.  A is exactly symmetric (the matrix build
+ * writes every off-diagonal block and its mirror image from the same registers, and a diagonal block's ( i, q ) and ( q, i ) are
+ * the same products summed in the same order), so the value is bit for bit the same - but lane = contact reads rows
+ * 3 lane, 3 lane + 1, 3 lane + 2: as ROWS of the full layout the lanes are one row stride x 3 apart (24 contacts x 3 = 72
+ * doubles = 144 dwords when every slot is taken, the headline case: 16 banks apart, lanes 0 / 4 and 1 / 5 ... collide, counters:
+ * SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 27 % on config 4); as positions r0 .. r0 + 2 of the column's row the
+ * lanes are 3 doubles apart - no two in one bank - and a lane's three entries are neighbours in memory. */
+template<bool pk> RKFD_DEV int rkfd_ma_idx_t(int Rr, int K, int ld){ return rkfd_ma_idx<pk>( K, Rr, ld ); }
 template<bool pk> RKFD_DEV void rkfd_pgs_registers(const double *MA, int r0, int ld, int nc, int max_iter, bool on, int lane, double mu,
                                  double in_, double i1, double i2, double &rn, double &r1, double &r2, double &fn, double &f1, double &f2)
 {
@@ -79,7 +87,7 @@ template<bool pk, int C0> RKFD_DEV void rkfd_pgs_dpp_normal(const double *MA, in
 #pragma unroll
   for( int u=0; u<RKFD_PGS_BLK; u++ ){
     const int c = C0+u < nc ? C0+u : nc-1;       /* (a column beyond the last contact is not used: stay inside the matrix) */
-    a0[u] = MA[rkfd_ma_idx<pk>( r0, 3*c, ld )]; a1[u] = MA[rkfd_ma_idx<pk>( r0+1, 3*c, ld )]; a2[u] = MA[rkfd_ma_idx<pk>( r0+2, 3*c, ld )];
+    a0[u] = MA[rkfd_ma_idx_t<pk>( r0, 3*c, ld )]; a1[u] = MA[rkfd_ma_idx_t<pk>( r0+1, 3*c, ld )]; a2[u] = MA[rkfd_ma_idx_t<pk>( r0+2, 3*c, ld )];
   }
 #define RKFD_PGS_N(u) \
   if( C0+u < nc ){ \
@@ -101,8 +109,8 @@ template<bool pk, int C0> RKFD_DEV void rkfd_pgs_dpp_tangent(const double *MA, i
 #pragma unroll
   for( int u=0; u<2; u++ ){
     const int c = C0+u < nc ? C0+u : nc-1;
-    a0[u] = MA[rkfd_ma_idx<pk>( r0, 3*c+1, ld )]; a1[u] = MA[rkfd_ma_idx<pk>( r0+1, 3*c+1, ld )]; a2[u] = MA[rkfd_ma_idx<pk>( r0+2, 3*c+1, ld )];
-    b0[u] = MA[rkfd_ma_idx<pk>( r0, 3*c+2, ld )]; b1[u] = MA[rkfd_ma_idx<pk>( r0+1, 3*c+2, ld )]; b2[u] = MA[rkfd_ma_idx<pk>( r0+2, 3*c+2, ld )];
+    a0[u] = MA[rkfd_ma_idx_t<pk>( r0, 3*c+1, ld )]; a1[u] = MA[rkfd_ma_idx_t<pk>( r0+1, 3*c+1, ld )]; a2[u] = MA[rkfd_ma_idx_t<pk>( r0+2, 3*c+1, ld )];
+    b0[u] = MA[rkfd_ma_idx_t<pk>( r0, 3*c+2, ld )]; b1[u] = MA[rkfd_ma_idx_t<pk>( r0+1, 3*c+2, ld )]; b2[u] = MA[rkfd_ma_idx_t<pk>( r0+2, 3*c+2, ld )];
   }
 #define RKFD_PGS_T(u) \
   if( C0+u < nc ){ \
@@ -158,7 +166,7 @@ template<bool pk> RKFD_DEV void rkfd_pgs_dpp(const double *MA, int r0, int ld, i
  * fixed for the solve), cbase = col ( col + 1 ) / 2 (from the position's contact) - no multiplication per entry */
 template<bool pk> RKFD_DEV int rkfd_ma_idx2(int row, int rb, int col, int cbase, int ld)
 {
-  if( !pk ) return row*ld + col;
+  if( !pk ) return col*ld + row;      /* (the transposed position: see rkfd_ma_idx_t) */
   return col <= row ? rb + col : cbase + row;
 }
 template<bool pk, int C0> RKFD_DEV void rkfd_pgs_grp_normal(const double *MA, const unsigned *gw, int kfb, int r0, const int *rb, int ld, int maxlen, int pos, double in_,
@@ -456,10 +464,16 @@ template<bool pk> RKFD_DEV void rkfd_pgs_dpp8(const double *MA, int r0, int ld, 
                                               double in_, double i1, double i2, double &rn, double &r1, double &r2, double &fn, double &f1, double &f2)
 {
   for( int it=0; it<max_iter; it++ ){
+#ifndef RKFD_EMU
+    /* (the row index is re-read through an opaque asm every sweep: the entries do not change between sweeps, a lane's three
+     * are neighbours in memory and their offsets literals - the compiler would otherwise load all 216 of them once, in front
+     * of the sweeps, into registers it does not have: 425 spills) */
+    asm volatile( "" : "+v"(r0) );
+#endif
 #define RKFD_PGS_N8(C0) { \
       double a0[4], a1[4], a2[4]; \
       _Pragma("unroll") for( int u=0; u<4; u++ ){ \
-        a0[u] = MA[rkfd_ma_idx<pk>( r0, 3*( C0+u ), ld )]; a1[u] = MA[rkfd_ma_idx<pk>( r0+1, 3*( C0+u ), ld )]; a2[u] = MA[rkfd_ma_idx<pk>( r0+2, 3*( C0+u ), ld )]; } \
+        a0[u] = MA[rkfd_ma_idx_t<pk>( r0, 3*( C0+u ), ld )]; a1[u] = MA[rkfd_ma_idx_t<pk>( r0+1, 3*( C0+u ), ld )]; a2[u] = MA[rkfd_ma_idx_t<pk>( r0+2, 3*( C0+u ), ld )]; } \
       RKFD_PGS_N1( C0, 0 ) RKFD_PGS_N1( C0, 1 ) RKFD_PGS_N1( C0, 2 ) RKFD_PGS_N1( C0, 3 ) }
 #define RKFD_PGS_N1(C0, u) { \
       double ff = fn - rn*in_; \
@@ -472,8 +486,8 @@ template<bool pk> RKFD_DEV void rkfd_pgs_dpp8(const double *MA, int r0, int ld, 
 #undef RKFD_PGS_N8
     double fs = mu*fn; fs = fs*fs;
 #define RKFD_PGS_T1(c) { \
-      const double a0 = MA[rkfd_ma_idx<pk>( r0, 3*c+1, ld )], a1 = MA[rkfd_ma_idx<pk>( r0+1, 3*c+1, ld )], a2 = MA[rkfd_ma_idx<pk>( r0+2, 3*c+1, ld )]; \
-      const double b0 = MA[rkfd_ma_idx<pk>( r0, 3*c+2, ld )], b1 = MA[rkfd_ma_idx<pk>( r0+1, 3*c+2, ld )], b2 = MA[rkfd_ma_idx<pk>( r0+2, 3*c+2, ld )]; \
+      const double a0 = MA[rkfd_ma_idx_t<pk>( r0, 3*c+1, ld )], a1 = MA[rkfd_ma_idx_t<pk>( r0+1, 3*c+1, ld )], a2 = MA[rkfd_ma_idx_t<pk>( r0+2, 3*c+1, ld )]; \
+      const double b0 = MA[rkfd_ma_idx_t<pk>( r0, 3*c+2, ld )], b1 = MA[rkfd_ma_idx_t<pk>( r0+1, 3*c+2, ld )], b2 = MA[rkfd_ma_idx_t<pk>( r0+2, 3*c+2, ld )]; \
       const double ff0 = f1 - r1*i1, ff1 = f2 - r2*i2; \
       const double fnorm = ff0*ff0 + ff1*ff1; \
       const bool zero = fnorm < RKFD_DEV_TOL || fs < RKFD_DEV_TOL; \
@@ -617,7 +631,8 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
   /* the Vert plugin's rigid branch (reference src/rkfd_vert.c:325-336) shares the contact system (A, b) and
    * the way the forces are applied; it differs in the solver (QP instead of PGS), in where the
    * relaxation enters (the QP objective, not A) and in when contact state is committed */
-  const bool vert = vqp && m.solver == RKFD_SOLVER_VERT;     /* vqp: this kernel variant carries the QP code at all */
+  const bool vert = vqp;     /* (the host launches the QP-carrying variant exactly for the worlds with rigid pairs under the Vert plugin, dm.vert_rigid:
+                              * the Gauss-Seidel code is not part of that kernel at all) */
   unsigned long long q0 = prof ? RKFD_CLOCK() : 0ull, q1;
 #define MST(k) do{ if( prof ){ q1 = RKFD_CLOCK(); pc[k] += q1 - q0; q0 = q1; } }while(0)
   const int lane = LANE();

@@ -58,3 +58,16 @@ def test_volume_kernel_resources():
     k = _kernels()["rkfd_step_kernel_vol"]
     assert k["Occupancy"] >= 2, k
     assert k["VGPRs Spill"] <= 160 and k["ScratchSize"] <= 512, k
+
+
+@pytest.mark.parametrize("world", ["config4", "config5", "arm_press"])
+def test_specialised_kernel_budget(R, world):
+    """the kernels rkfdBatchSpecialize compiles for ONE world (hipRTC; the headline runs on config 4's), checked without a GPU:
+    tools/spec_resources.py compiles the world's kernel and reads the code object's metadata note.  Three waves per SIMD
+    (<= 168 VGPRs) and no vector spills - round 3 saw config 4's kernel go from 154 registers to 425 spills when the
+    Gauss-Seidel's matrix reads were re-indexed (the register variant for <= 4 contacts holds its rows in registers)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("spec_resources", os.path.join(ROOT, "tools", "spec_resources.py"))
+    sr = importlib.util.module_from_spec(spec); spec.loader.exec_module(sr)
+    r = sr.resources(sr.world(world))
+    assert r["vgpr"] <= 168 and r["vgpr_spill"] == 0 and r["scratch"] <= 64, r
