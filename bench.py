@@ -19,7 +19,7 @@ algorithmic bytes are computed from it.  --horizon 0 runs one continuous traject
 regime, ~3.5 contacts; reported in DESIGN.md beside the headline).
 
 --steps K is the block that is timed; the block is repeated until the timed region lasts --min-seconds
-(default 1 s) so that the figure does not depend on a 4 ms measurement; ms_per_step and value are averages
+(default 6 s) so that the figure does not depend on a 4 ms measurement and a monitor sampling every 5 s sees the GPU busy; ms_per_step and value are averages
 over all timed steps (config.timed_steps), the rollout boundaries continue across blocks.
 
 One process per GPU; for N>1 the driver launches this file under torch.distributed.run and every rank
@@ -47,7 +47,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0
-PROFILE_TAG = "r02"
 
 
 def alg_bytes(m, mean_contacts, R):
@@ -59,104 +58,121 @@ def alg_bytes(m, mean_contacts, R):
     return 8 * 6 * m.ndof + 80.0 * mean_contacts + 24 * n_fric, n_fric
 
 
+def newest_profile(suffix):
+    """(tag, record) of the newest profiles/rNN_<suffix> (tags sort by round), or (None, None)"""
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    for f in reversed(fs):
+        try:
+            with open(f) as fp:
+                return os.path.basename(f)[:3], json.load(fp)
+        except (OSError, ValueError):
+            continue
+    return None, None
+
+
+def stamped(rec, what):
+    """(ok, reason): a counter-derived figure is reported only from a profile taken on THIS tree's device sources (the
+    profile carries the sha256 of the sources it was collected on: rkfd_pkg.device_source_hash; VERDICT r02 #13)"""
+    import rkfd_pkg
+    have = rec.get("device_source_sha256") if isinstance(rec, dict) else None
+    cur = rkfd_pkg.device_source_hash()
+    if have is None:
+        return False, f"{what}: the profile on file carries no source stamp"
+    if have != cur:
+        return False, f"{what}: the profile on file was taken on other device sources (stamp {have}, this tree {cur}): re-collect with tools/collect_all.sh"
+    return True, None
+
+
 def measured_traffic(workload, per_launch):
-    """HBM bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in separate runs by
-    tools/collect_traffic.sh and corrected as MI355X_MICROARCH.md prescribes); None when no measurement for
-    this workload / launch size is on file."""
-    try:
-        with open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_hbm_traffic.json")) as fp:
-            rec = json.load(fp).get(workload)
-        if rec and rec.get("batch") == per_launch:
-            return rec["hbm_bytes_per_launch"]
-    except (OSError, ValueError):
-        pass
-    return None
+    """(HBM bytes per launch, note) from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in separate runs by
+    tools/collect_traffic.sh and corrected as MI355X_MICROARCH.md prescribes); (None, why) when no measurement of this
+    workload / launch size taken on this tree's device sources is on file."""
+    tag, allrec = newest_profile("hbm_traffic.json")
+    if tag is None:
+        return None, "no profiles/rNN_hbm_traffic.json on file"
+    rec = allrec.get(workload)
+    if not rec or rec.get("batch") != per_launch:
+        return None, f"profiles/{tag}_hbm_traffic.json holds no measurement of {workload} at {per_launch} instances per launch"
+    ok, why = stamped(allrec, f"profiles/{tag}_hbm_traffic.json")
+    if not ok:
+        return None, why
+    return rec["hbm_bytes_per_launch"], f"profiles/{tag}_hbm_traffic.json (source stamp {allrec['device_source_sha256']})"
 
 
 def counted_flops(workload, horizon):
     """algorithmic flops per instance-step from the flop-counting build of the oracle, counted over the same
-    rollout window (tools/count_flops.py -> profiles/r02_flops.json); None when not on file"""
+    rollout window (tools/count_flops.py -> profiles/rNN_flops.json); None when not on file.  (A property of the
+    reference's formulation as the oracle restates it, not of the device code: no source stamp needed.)"""
+    tag, rec = newest_profile("flops.json")
     try:
-        with open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_flops.json")) as fp:
-            rec = json.load(fp)[workload]
+        rec = rec[workload]
         return rec["flops_per_instance_step"] if rec.get("horizon") == horizon else None
-    except (OSError, ValueError, KeyError):
+    except (KeyError, TypeError):
         return None
 
 
 def valu_issue(workload):
-    """VALU instructions per instance-step from the rocprofv3 SQ pass on file (profiles/r02_<workload>_rocprof_summary.json)"""
+    """(VALU instructions per instance-step, note) from the rocprofv3 SQ pass on file (profiles/rNN_<workload>_rocprof_summary.json),
+    only when it was taken on this tree's device sources"""
+    tag, rec = newest_profile(f"{workload}_rocprof_summary.json")
+    if tag is None:
+        return None, "no rocprofv3 SQ summary of this workload on file"
+    ok, why = stamped(rec, f"profiles/{tag}_{workload}_rocprof_summary.json")
+    if not ok:
+        return None, why
     try:
-        with open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_{workload}_rocprof_summary.json")) as fp:
-            rec = json.load(fp)
-        return rec["SQ_INSTS_VALU"] / rec["SQ_WAVES"]
-    except (OSError, ValueError, KeyError, ZeroDivisionError):
-        return None
-
-
-def _oracle_rollouts(Oracle, sc, inst, horizon, deadline, block=None):
-    """one oracle instance doing the bench's workload: rollouts of `horizon` steps from its start state
-    (horizon 0: one trajectory in blocks of 200 steps) until the deadline; returns the steps done"""
-    o = Oracle(sc["world"].model)
-    n = 0
-    if horizon > 0:
-        while time.perf_counter() < deadline:
-            o.set_state(sc["dis"][inst], sc["vel"][inst])
-            o.reset_contact()
-            o.update_init()
-            o.update_n(horizon)
-            n += horizon
-    else:
-        o.set_state(sc["dis"][inst], sc["vel"][inst])
-        o.update_init()
-        while time.perf_counter() < deadline and n < 1000:
-            o.update_n(200); n += 200
-    o.close()
-    return n
+        return rec["SQ_INSTS_VALU"] / rec["SQ_WAVES"], f"profiles/{tag}_{workload}_rocprof_summary.json (source stamp {rec['device_source_sha256']})"
+    except (KeyError, ZeroDivisionError):
+        return None, "the summary on file lacks SQ_INSTS_VALU / SQ_WAVES"
 
 
 def cpu_baseline(R, name, horizon, seconds=10.0):
-    """the oracle (CPU restatement, 'port') timed on one host core on a bounded sample of the SAME workload:
-    rollouts of `horizon` steps from the same standing states"""
-    from oracle.pyoracle import Oracle
+    """the oracle (CPU restatement, 'port') timed on ONE host core on a bounded sample of the SAME workload: rollouts of
+    `horizon` steps from the same standing states.  Threads and clock live in C (oracle/rkfd_oracle_mt.c)."""
+    from oracle import pyoracle
     sc = R.scenarios.CONFIGS[name](batch=4)
-    nsteps = 0; inst = 0
-    t0 = time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
-        nsteps += _oracle_rollouts(Oracle, sc, inst % 4, horizon, min(t0 + seconds, time.perf_counter() + 2.0))
-        inst += 1
-    dt = time.perf_counter() - t0
+    nsteps, dt = pyoracle.rollouts_mt(sc["world"].model, sc["dis"], sc["vel"], horizon, seconds, nthreads=1)
     what = f"rollouts of {horizon} steps from the standing states" if horizon > 0 else "trajectories of up to 1000 steps"
     return dict(value=nsteps / dt, unit="sim-steps/sec", cores=1, kind="port",
                 sample=f"{nsteps} steps of {name} ({what}, 4 distinct instances), sequential on 1 core "
                        f"(oracle/rkfd_oracle.c, gcc -O3 -funroll-loops)")
 
 
+def cpu_share():
+    """(threads to use, description): the CPUs this process may really use - the affinity mask, capped by the cgroup's CPU quota
+    (a GPU box shows all 256 hardware threads of its host in the affinity mask but grants the job a quota of about 16 CPUs:
+    256 threads then run 9 x one core, throttled; 16 threads 14 x)"""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fp:                       # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = fp.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:                                                             # cgroup v1
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fpd:
+                q, per = float(fq.read()), float(fpd.read())
+                if q > 0:
+                    quota = q / per
+        except (OSError, ValueError):
+            pass
+    n = aff if quota is None else max(1, min(aff, int(quota + 0.5)))
+    return n, f"{aff} hardware threads in the affinity mask, cgroup CPU quota " + ("none" if quota is None else f"{quota:.1f} CPUs")
+
+
 def cpu_baseline_all_cores(R, name, horizon, seconds=8.0):
-    """the same oracle on every host core this process may use: one OS thread per core over disjoint
-    instances (the reference itself is single-threaded; this is the generous baseline).
-    ctypes releases the GIL inside the C calls and the oracle keeps no global state."""
-    import threading
-    from oracle.pyoracle import Oracle
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    sc = R.scenarios.CONFIGS[name](batch=4)
-    done = [0] * cores
-    t0 = time.perf_counter()
-
-    def work(k):
-        inst = k
-        while time.perf_counter() - t0 < seconds:
-            done[k] += _oracle_rollouts(Oracle, sc, inst % 4, horizon, min(t0 + seconds, time.perf_counter() + 2.0))
-            inst += cores
-
-    th = [threading.Thread(target=work, args=(k,)) for k in range(cores)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    dt = time.perf_counter() - t0
-    return dict(value=sum(done) / dt, unit="sim-steps/sec", cores=cores, kind="port",
-                sample=f"{sum(done)} steps of {name}, same rollouts, one thread per core on {cores} cores")
+    """the same oracle on every host core this process may use: one OS thread per core over disjoint instances (the reference
+    itself is single-threaded; this is the generous baseline, SURVEY 8d).  The threads are pthreads INSIDE the oracle library
+    (round 2 used Python threads around ctypes calls and measured the interpreter lock: 14.5 x one core on 256 hardware
+    threads, VERDICT r02 #12); the oracle keeps no global state."""
+    from oracle import pyoracle
+    cores, share = cpu_share()
+    sc = R.scenarios.CONFIGS[name](batch=max(4, min(cores, 64)))
+    nsteps, dt = pyoracle.rollouts_mt(sc["world"].model, sc["dis"], sc["vel"], horizon, seconds, nthreads=cores)
+    return dict(value=nsteps / dt, unit="sim-steps/sec", cores=cores, kind="port", cpu_share=share,
+                sample=f"{nsteps} steps of {name}, same rollouts, one pthread per CPU this job may use ({cores}: {share}); threads and clock inside the oracle library")
 
 
 def spawn_ranks(args):
@@ -181,8 +197,11 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
     ap.add_argument("--horizon", type=int, default=25, help="steps per rollout before the instances are put back to their start states "
                     "(device-side copy, timed); 0: one continuous trajectory")
-    ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the --steps block until the timed region lasts this long")
+    ap.add_argument("--min-seconds", type=float, default=6.0, help="repeat the --steps block until the timed region lasts this long (6 s: longer "
+                    "than the 5 s sampling period of a utilisation monitor watching the run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-continuous", action="store_true", help="skip the second, shorter measurement of ONE continuous trajectory per instance "
+                    "(no rollout boundaries; the regime --horizon 0 times), reported as `continuous_trajectory` in the same JSON line")
     ap.add_argument("--fuse", type=int, default=0, help="steps per rkfdBatchUpdate call (0: up to the end of the rollout / block).  Under split "
                     "launches a call of n steps goes out as n rounds of one-step launches, except for worlds under the Vert plugin, whose steps "
                     "run fused in one kernel per part: the QP makes step times vary widely between instances, and without a per-step barrier "
@@ -304,6 +323,36 @@ def main():
         torch.cuda.synchronize()
         assert out.shape[0] == total
 
+    # the same batch on ONE continuous trajectory per instance (what --horizon 0 times): the stiff body leaves the 8-vertex stance
+    # after 30-40 steps and rocks on 3-4 vertices (DESIGN.md "Scenario note" - derived with this repository's oracle, not checked
+    # against a build of the reference: [UNVERIFIED-DEP]), a lighter contact problem.  Reported beside the headline so that the
+    # two regimes can be compared in one line.
+    continuous = None
+    if world == 1 and H > 0 and not args.no_continuous:
+        ncand = sc["world"].model.contents.ncand
+        b.set_state(sc["dis"], sc["vel"])
+        if ncand > 0:
+            b.set_contact(np.zeros((Bn, ncand), dtype=np.int32), np.zeros((Bn, ncand), dtype=np.int32), np.zeros((Bn, ncand, 3)))
+        b.set_pivot(np.zeros((Bn, sc["world"].model.contents.nlink), dtype=np.int32), np.zeros((Bn, sc["world"].model.contents.nlink)))
+        b.update_init(stream)
+        cw, cs = 100, 0
+        for _ in range(cw // 25):
+            b.update(25, stream)
+        b.join(stream); torch.cuda.synchronize()
+        b.contact_stats(reset=True)
+        c0 = torch.cuda.Event(enable_timing=True); c1 = torch.cuda.Event(enable_timing=True)
+        tc0 = time.perf_counter(); c0.record()
+        while time.perf_counter() - tc0 < min(1.5, max(args.min_seconds, 0.2)) or cs == 0:
+            b.update(25, stream); cs += 25
+            if cs % 200 == 0:
+                b.join(stream); torch.cuda.synchronize()
+        b.join(stream); c1.record(); torch.cuda.synchronize()
+        cms = c0.elapsed_time(c1) / cs
+        crg, cel, _cn = b.contact_stats()
+        continuous = {"value": Bn / (cms * 1e-3), "unit": "sim-steps/sec", "ms_per_step": cms, "timed_steps": cs, "steps_before": cw,
+                      "mean_rigid_contacts": crg, "mean_elastic_contacts": cel, "device_status": b.status(stream),
+                      "note": "one trajectory per instance from the standing states, no rollout boundaries (--horizon 0)"}
+
     if rank == 0:
         m = sc["world"].model.contents
         has_contacts = m.ncand > 0
@@ -315,6 +364,7 @@ def main():
         launches_per_step = nlaunch / timed_steps
         spl = args.split / launches_per_step   # steps one launch carries
         achieved = alg * per_launch * spl / (kernel_ms * 1e-3) / 1e9
+        traffic, traffic_note = measured_traffic(args.workload, per_launch)
         res = {
             "metric": "sim-steps/sec (node), 30-DoF humanoid + ground contact, batch=4096",
             "value": Bn * world * timed_steps / elapsed, "unit": "sim-steps/sec",
@@ -328,7 +378,7 @@ def main():
                        "parallelism": f"instances sharded over {world} GPU(s), no data-path collective; {args.split} launches per step on internal streams",
                        "step_kernel": "compiled for this world (rkfdBatchSpecialize)" if specialized else "generic"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload, per_launch),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "kernel": "rkfd_step_kernel_spec" if specialized else "rkfd_step_kernel", "kernel_ms": kernel_ms,
                          "alg_bytes_per_instance_step": alg, "friction_pivot_dofs": n_fric,
                          "instances_per_launch": per_launch, "launches_per_step": launches_per_step, "steps_per_launch": spl, "step_ms_hip_events": step_ms,
@@ -336,6 +386,8 @@ def main():
                          "achieved_all_launches_of_a_step": alg * Bn / (step_ms * 1e-3) / 1e9},
             "device_status": st,
         }
+        if continuous is not None:
+            res["continuous_trajectory"] = continuous
         del steps_per_launch
         fl = counted_flops(args.workload, H)
         if fl is not None and args.workload != "config4v":
@@ -346,13 +398,15 @@ def main():
             tf = fl * Bn / (step_ms * 1e-3) / 1e12      # whole step: the launches of one step overlap
             res["roofline_valu"] = {"bound": "valu_fp64", "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6,
                                     "alg_flops_per_instance_step": fl, "flops_counted_on": "the reference's formulation (oracle), same rollout window"}
-        vi = valu_issue(args.workload)
-        if vi is not None:
+        vi, vi_note = valu_issue(args.workload)
+        if vi is None:
+            res["valu_issue"] = None; res["valu_issue_source"] = vi_note
+        else:
             # what bounds the kernel: VALU instruction issue.  Instructions per instance-step from the rocprofv3
             # SQ_INSTS_VALU pass on file; one wave-wide VALU instruction occupies its SIMD for 4 cycles (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.02
             # quad-cycles measured); 256 CUs x 4 SIMDs.  The clock under this kernel is ~1.8-2.0 GHz, the nominal 2.4 GHz is used.
             ips = vi * Bn / (step_ms * 1e-3)
-            res["valu_issue"] = {"valu_insts_per_instance_step": vi, "simd_busy_fraction_at_2.4GHz": ips * 4.0 / (256 * 4 * 2.4e9)}
+            res["valu_issue"] = {"valu_insts_per_instance_step": vi, "simd_busy_fraction_at_2.4GHz": ips * 4.0 / (256 * 4 * 2.4e9), "source": vi_note}
         if world == 1 and not args.no_cpu_baseline:      # the CPU baseline is a single-GPU-run figure (rank 0, N = 1)
             res["cpu_baseline"] = cpu_baseline(R, args.workload, H)
             res["cpu_baseline_all_cores"] = cpu_baseline_all_cores(R, args.workload, H)

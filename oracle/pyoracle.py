@@ -41,6 +41,8 @@ def _bind(path):
     L.rkfdOracleVolumePairs.argtypes = [vp]
     L.rkfdOracleGetVolumePair.argtypes = [vp, C.c_int, vp, C.c_int]
     L.rkfdOracleVolumeLP.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp]
+    if hasattr(L, "rkfdOracleRolloutsMT"):          # (not in the flop-counting build)
+        L.rkfdOracleRolloutsMT.argtypes = [vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_double, vp]; L.rkfdOracleRolloutsMT.restype = C.c_long
     return L
 
 
@@ -191,3 +193,14 @@ def volume_lp(A, b, c=None):
     cc = None if c is None else np.ascontiguousarray(c, dtype=np.float64)
     ok = lib().rkfdOracleVolumeLP(mr, n, _p(A), _p(b), _p(cc), _p(x))
     return x if ok else None
+
+
+def rollouts_mt(model_ptr, dis, vel, horizon, seconds, nthreads=1):
+    """bench.py's CPU baseline, timed inside C: `nthreads` OS threads (each its own oracle) doing rollouts of `horizon` steps from
+    the states dis / vel [ninst, ndof] for `seconds`; returns (steps done by all threads, wall seconds of the longest thread)"""
+    dis = np.ascontiguousarray(dis, dtype=np.float64); vel = np.ascontiguousarray(vel, dtype=np.float64)
+    el = C.c_double(0.0)
+    n = lib().rkfdOracleRolloutsMT(C.cast(model_ptr, C.c_void_p), int(nthreads), int(dis.shape[0]), _p(dis), _p(vel), int(horizon), float(seconds), C.byref(el))
+    if n < 0:
+        raise RuntimeError("rkfdOracleRolloutsMT failed")
+    return int(n), float(el.value)

@@ -62,6 +62,10 @@ int  rkfdOracleGetVolumePair(const rkfdOracle *o, int k, double *out, int cap);
 int  rkfdOracleVolumeLP(int mr, int n, const double *A, const double *b, const double *c, double *x);
 /* nsteps x rkFDUpdate */
 int  rkfdOracleUpdateN(rkfdOracle *o, int nsteps);
+/* bench.py's CPU baselines, threads and clock inside C (rkfd_oracle_mt.c): nthreads OS threads, each with its own oracle, doing
+ * rollouts of `horizon` steps from the states dis / vel [ninst][ndof] (thread t takes instances t, t + nthreads, ...; horizon 0: one
+ * trajectory of up to 1000 steps per instance) for `seconds`; returns the steps done, *elapsed = the longest thread's wall time */
+long rkfdOracleRolloutsMT(const rkfdModel *m, int nthreads, int ninst, const double *dis, const double *vel, int horizon, double seconds, double *elapsed);
 /* one dynamics evaluation at the current state: _rkFDUpdate / _rkFDUpdateRef
  * (reference src/rkfd_sim.c:533-549); result in acc */
 int  rkfdOracleEval(rkfdOracle *o, int doUpRef);

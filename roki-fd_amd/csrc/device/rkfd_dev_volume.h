@@ -45,8 +45,11 @@ RKFD_DEV void d_vol_frame(const rkfdLds &L, int i, double *R, double *p)
 }
 
 /* one polygon (n vertices at P, capacity cap) against the half space pl.x - d <= 0, in place (Sutherland-Hodgman: the
- * vertex read next is always ahead of the one written) */
-RKFD_DEV int d_vol_clip(double *P, int n, int cap, const double *pl, double d)
+ * vertex read next is always ahead of the one written).  ovf is set when a vertex was due beyond the capacity (vol_pv = the
+ * longest face loop + the faces of the larger shape bounds a convex polygon clipped by that many planes, so this should be
+ * unreachable - but a truncated polygon would silently change centre, normal and Q, so it is reported like every other
+ * capacity: status 2). */
+RKFD_DEV int d_vol_clip(double *P, int n, int cap, const double *pl, double d, bool &ovf)
 {
   if( n < 1 ) return 0;
   /* most planes of the other shape do not touch a given face: look first, rewrite the polygon only when the plane cuts it */
@@ -65,11 +68,13 @@ RKFD_DEV int d_vol_clip(double *P, int n, int cap, const double *pl, double d)
   for( int i=0; i<n; i++ ){
     double n0 = f0, n1 = f1, n2 = f2, sn = sf;
     if( i+1 < n ){ n0 = P[3*i+3]; n1 = P[3*i+4]; n2 = P[3*i+5]; sn = pl[0]*n0 + pl[1]*n1 + pl[2]*n2 - d; }
-    if( sc <= 0 && k < cap ){ P[3*k] = c0; P[3*k+1] = c1; P[3*k+2] = c2; k++; }
-    if( ( ( sc < 0 && sn > 0 ) || ( sc > 0 && sn < 0 ) ) && k < cap ){
-      const double t = sc*RKFD_RCP( sc - sn );
-      P[3*k] = c0 + t*( n0-c0 ); P[3*k+1] = c1 + t*( n1-c1 ); P[3*k+2] = c2 + t*( n2-c2 );
-      k++;
+    if( sc <= 0 ){ if( k < cap ){ P[3*k] = c0; P[3*k+1] = c1; P[3*k+2] = c2; k++; } else ovf = true; }
+    if( ( sc < 0 && sn > 0 ) || ( sc > 0 && sn < 0 ) ){
+      if( k < cap ){
+        const double t = sc*RKFD_RCP( sc - sn );
+        P[3*k] = c0 + t*( n0-c0 ); P[3*k+1] = c1 + t*( n1-c1 ); P[3*k+2] = c2 + t*( n2-c2 );
+        k++;
+      } else ovf = true;
     }
     c0 = n0; c1 = n1; c2 = n2; sc = sn;
   }
@@ -332,7 +337,9 @@ template<bool prof> RKFD_DEV void rkfd_phase_volcol(const rkfdDevModel &m, const
         P[3*i] = x[0]+ps[0]; P[3*i+1] = x[1]+ps[1]; P[3*i+2] = x[2]+ps[2];
       }
       const int g0 = isA ? na : 0, ng = isA ? nb : na;      /* the other shape's faces are lanes g0 .. g0+ng-1 */
-      for( int g=g0; g<g0+ng && n>=3; g++ ) n = d_vol_clip( P, n, PV, &stg[4*g], stg[4*g+3] );
+      bool ovf = false;
+      for( int g=g0; g<g0+ng && n>=3; g++ ) n = d_vol_clip( P, n, PV, &stg[4*g], stg[4*g+3], ovf );
+      if( ovf ) L.cnt[CNT_OVF] = 1;      /* (lanes that write all write the same value) */
       if( n < 3 ) n = 0;
     }
     /* reference point of the signed tetrahedra: the first vertex of the first face that survived (a point ON the volume: with

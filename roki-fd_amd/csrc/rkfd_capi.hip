@@ -511,15 +511,33 @@ static int spec_compile(const rkfdDevModel &d, std::vector<char> &code)
   const rkfdRtc *rtc = rtc_api();
   if( !rtc ) return -1;
   const std::string src = spec_source( d );
+  /* one compile at a time: the environment snapshot below is per namespace, not per call */
+  static pthread_mutex_t cmu = PTHREAD_MUTEX_INITIALIZER;
+  struct Unlock { pthread_mutex_t *m; ~Unlock(){ pthread_mutex_unlock( m ); } } unlock = { &cmu };
+  pthread_mutex_lock( &cmu );
   if( rtc->priv ){
-    /* the private namespace carries its own copy of the C library, and that copy's `environ` still points at the array the
+    /* The private namespace carries its own copy of the C library, and that copy's `environ` still points at the array the
      * process had when the namespace was made.  The host's setenv (Python's os.environ, say) moves the real array and frees
      * the old one: the compiler's getenv would walk freed memory (seen: a segmentation fault in the 88th test of a pytest
-     * process that had set new variables between two specialisations).  Point the copy at the live array before every use. */
+     * process that had set new variables between two specialisations).  Round 2 pointed the copy at the host's live array
+     * before every compile - which the host can move again DURING the compile (another thread's setenv), and which helper
+     * threads or exit handlers of the namespace may still read after it.  Now the namespace gets an environment
+     * of its OWN: a deep copy (array and strings) taken under this mutex before every compile, which nothing but this
+     * function ever replaces.  Earlier snapshots are kept alive as long as the library is loaded (a thread of the namespace
+     * may still hold a pointer into one): a few kilobytes per compile, one compile per world. */
     char ***penv = (char ***)dlsym( rtc->h, "environ" );
     if( penv && penv != &environ ){
-      if( *penv != environ && getenv( "RKFD_SPEC_DEBUG" ) ) fprintf( stderr, "rkfd: the host's environment moved (%p -> %p): hipRTC's namespace follows\n", (void *)*penv, (void *)environ );
-      *penv = environ;
+      size_t n = 0, bytes = 0;
+      for( char **e = environ; e && *e; e++ ){ n++; bytes += strlen( *e ) + 1; }
+      char **arr = (char **)malloc( sizeof(char *)*( n+1 ) + bytes );
+      if( arr ){
+        char *p = (char *)( arr + n + 1 );
+        size_t k = 0;
+        for( char **e = environ; e && *e && k < n; e++, k++ ){ const size_t l = strlen( *e ) + 1; memcpy( p, *e, l ); arr[k] = p; p += l; }
+        arr[k] = NULL;
+        if( getenv( "RKFD_SPEC_DEBUG" ) ) fprintf( stderr, "rkfd: hipRTC's namespace gets its own snapshot of the environment (%zu variables)\n", k );
+        *penv = arr;      /* (the previous snapshot is deliberately not freed, see above) */
+      }
     }
   }
   if( const char *dump = getenv( "RKFD_SPEC_DUMP" ) ){ FILE *f = fopen( dump, "w" ); if( f ){ fputs( src.c_str(), f ); fclose( f ); } }   /* diagnostic */
@@ -658,7 +676,12 @@ extern "C" int rkfdBatchStatus(rkfdBatch *b, void *stream)
   HIPCHK( hipStreamSynchronize( (hipStream_t)stream ), -1 );
   int e = 0;
   HIPCHK( hipMemcpy( &e, b->d_err, sizeof(int), hipMemcpyDeviceToHost ), -1 );
-  if( e == 1 ) SETERR( "a rigid contact occurred but no rigid solver is set up on the device for this world (max_rigid = 0)" );
+  if( e == 1 ){
+    static const char *const sname[] = { "Vert", "MLCP", "Volume" };
+    SETERR( "a rigid contact occurred but no rigid solver is set up on the device for this world: plugin %s, max_rigid = %d "
+            "(a batch created with max_rigid = 0 carries no rigid path; so does a plugin / world combination the device does not solve)",
+            ( b->dm.solver >= 0 && b->dm.solver <= 2 ) ? sname[b->dm.solver] : "?", b->dm.maxrg );
+  }
   if( e == 2 && b->dm.vol_np > 0 )
     SETERR( "contact capacity exceeded in at least one instance: more rigid pairs in volumetric contact than %d, more than %d contact-plane "
             "conditions in one pair, or more elastic contact vertices than the %d active-contact slots; what was beyond the capacity was dropped",

@@ -261,8 +261,11 @@ def test_specialized_step_kernel_compiles_without_a_gpu(R):
 def test_specialisation_survives_the_host_changing_its_environment():
     """hipRTC lives in a private link namespace with its own copy of the C library; the host's setenv moves the environment
     array and frees the old one, which that copy still pointed at (a segmentation fault deep into a pytest process, round 2).
-    rkfd_capi.hip re-points it before every compile: compile, set 200 new variables, compile again - in a child process,
-    so that a regression fails this test instead of killing the test run"""
+    rkfd_capi.hip gives the namespace a deep copy of the environment of its own before every compile (round 2 re-pointed it at
+    the host's live array, which the host can move again at any time: ADVICE r02): compile, set 200 new variables, compile
+    again, then change the environment once more AFTER the last compile - while threads of the namespace may still be alive -
+    and exit cleanly through the interpreter's normal shutdown (exit handlers of the namespace included).  In a child
+    process, so that a regression fails this test instead of killing the test run"""
     import subprocess
     import sys
     code = (
@@ -275,6 +278,11 @@ def test_specialisation_survives_the_host_changing_its_environment():
         "    os.environ['RKFD_TEST_FILLER_%d' % i] = 'x' * 100\n"
         "n2 = R.lib().rkfdSpecializeCompile(sc['world'].model, sc['max_rigid'])\n"
         "print('sizes', n1, n2)\n"
-        "assert n1 > 10000 and n1 == n2\n")
+        "assert n1 > 10000 and n1 == n2\n"
+        "for i in range(400):\n"
+        "    os.environ['RKFD_TEST_LATE_%d' % i] = 'y' * 300\n"
+        "for i in range(200):\n"
+        "    del os.environ['RKFD_TEST_FILLER_%d' % i]\n"
+        "print('done')\n")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.returncode == 0 and r.stdout.strip().endswith("done"), r.stdout + r.stderr

@@ -2,7 +2,7 @@
 # everything profiles/ holds for one round, on the GPU box: rocprofv3 evidence per workload, phase cycles, bench lines
 # usage: bash tools/collect_all.sh [tag]      (then, in the build container: python3 tools/copy_profiles.py [tag])
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 for W in ${WORKLOADS:-config4 config3 config2}; do

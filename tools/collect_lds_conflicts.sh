@@ -10,8 +10,10 @@ for W in ${@:-config4}; do
   rm -rf $OUT
   rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAVES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES --output-format csv -d $OUT -- python3 bench.py --workload $W --steps 20 --warmup 5 --no-cpu-baseline --min-seconds 0 > $OUT.log 2>&1
   python3 - "$OUT" "$W" <<'PY'
-import csv, glob, json, sys
+import csv, glob, json, os, sys
 from collections import defaultdict
+sys.path.insert(0, os.getcwd())
+import rkfd_pkg
 d, w = sys.argv[1], sys.argv[2]
 acc = defaultdict(list)
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
@@ -19,7 +21,7 @@ for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         if "rkfd_step_kernel" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 med = {k: sorted(v)[len(v) // 2] for k, v in acc.items()}
-med["workload"] = w
+med["workload"] = w; med["device_source_sha256"] = rkfd_pkg.device_source_hash()
 if med.get("SQ_LDS_IDX_ACTIVE"):
     med["lds_bank_conflict_ratio"] = med["SQ_LDS_BANK_CONFLICT"] / med["SQ_LDS_IDX_ACTIVE"]
 if med.get("SQ_WAVES"):

@@ -3,7 +3,7 @@
 #   kernel trace + stats, then FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes, then SQ counters.
 # usage: tools/collect_traffic.sh <workload> <tag>
 set -e
-W=${1:-config4}; TAG=${2:-r02}
+W=${1:-config4}; TAG=${2:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_${TAG}_${W}
 rm -rf $OUT && mkdir -p $OUT

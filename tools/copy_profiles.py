@@ -1,7 +1,10 @@
 """copies what tools/collect_all.sh left under gpurun_out/ into profiles/ (run in the build container)"""
 import glob, json, os, shutil, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 import csv
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import rkfd_pkg
+HEAD = rkfd_pkg.git_head()
 
 
 def cal_factor():
@@ -25,6 +28,10 @@ for w in ("config2", "config3", "config4"):
     shutil.copy(ks, f"profiles/{tag}_{w}_kernel_stats.csv")
     dj = json.loads(open(f"gpurun_out/prof_{tag}_{w}.bench.json").read().strip().splitlines()[-1])
     hb = s["FETCH_SIZE"] * 1024.0 * CAL["fetch"] + s["WRITE_SIZE"] * 1024.0 * CAL["write"]
+    s["git_head_when_copied"] = HEAD
+    if s.get("device_source_sha256") != rkfd_pkg.device_source_hash():
+        print("WARNING: %s was collected on other device sources than this tree's (%s vs %s)" % (w, s.get("device_source_sha256"), rkfd_pkg.device_source_hash()))
+    tr["device_source_sha256"] = s.get("device_source_sha256"); tr["git_head_when_copied"] = HEAD
     s["hbm_bytes_per_launch"] = hb; s["hbm_bytes_per_launch_note"] = "FETCH_SIZE*1024*%.4f + WRITE_SIZE*1024*%.4f (calibrated on tools/ubench/traffic_cal.hip; hbm_read_bytes_x2 is the uncalibrated 16 B-per-lane rule, kept for reference)" % (CAL["fetch"], CAL["write"])
     json.dump(s, open(f"profiles/{tag}_{w}_rocprof_summary.json", "w"), indent=1)
     tr[w] = {"batch": dj["roofline"].get("instances_per_launch", 4096), "hbm_bytes_per_launch": hb, "fetch_size_raw_kib": s["FETCH_SIZE"], "write_size_kib": s["WRITE_SIZE"],
