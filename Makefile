@@ -34,7 +34,7 @@ DEVSRC = include/rkfd_model.h $(CSRC)/rkfd_devmodel.h $(CSRC)/rkfd_device.h $(so
 $(BUILD)/rkfd_device_src.inc: $(DEVSRC) tools/embed_sources.py | $(BUILD)
 	python3 tools/embed_sources.py $@ $(DEVSRC)
 
-$(BUILD)/rkfd_capi.o: $(CSRC)/rkfd_capi.hip $(BUILD)/rkfd_device_src.inc $(CSRC)/*.h $(CSRC)/device/*.h include/*.h | $(BUILD)
+$(BUILD)/rkfd_capi.o: $(CSRC)/rkfd_capi.hip $(CSRC)/rkfd_capi_node.inc $(BUILD)/rkfd_device_src.inc $(CSRC)/*.h $(CSRC)/device/*.h include/*.h | $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(BUILD)/rkfd_capi.remarks || ( cat $(BUILD)/rkfd_capi.remarks; exit 1 )
 	@grep -E "Function Name|VGPRs:|ScratchSize|Occupancy|VGPRs Spill|SGPRs Spill" $(BUILD)/rkfd_capi.remarks | sed 's/.*remark: *//; s/ \[-Rpass.*//' > $(PKG)/kernel_resources.txt
 	@grep -vE "remark:|^ +[0-9]+ \||^ +\||\^" $(BUILD)/rkfd_capi.remarks || true

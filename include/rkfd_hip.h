@@ -137,6 +137,44 @@ int rkfdBatchResidency(const rkfdBatch *b);
 /* the same figure computed on the host for a model and contact capacity (no GPU needed) */
 int rkfdLdsBytesFor(const rkfdModel *m, int max_rigid);
 
+/* ---- the node level: all the GPUs of one node from ONE process, host code in C -------------------------------------
+ * SURVEY 8e / north star: "independent MPC-style rollouts shard embarrassingly across the 8 GPUs of one node with an
+ * RCCL-over-xGMI gather of final states only".  The instances of a batch are independent (one rkFD never references another),
+ * so device k simulates the contiguous block [lo, hi) of the `total` instances (remainders to the low devices), model constants
+ * replicated, NO per-step communication; every device has its own host thread and HIP stream inside the library, and the only
+ * collective is one ncclAllGather of the final {dis, vel} per rollout (librccl is bound at run time; RKFD_RCCL_LIB names
+ * another file).  The reference is single-threaded C on one core and has no counterpart; a caller of the reference would run
+ * one rkFD per instance (reference example/chain/boxdrop_test.c:22-54).
+ * ndev <= 0: all visible devices; devices: their HIP ordinals, or NULL for 0 .. ndev-1.  Calls return 0 / negative like the
+ * rkfdBatch calls (rkfdHipLastError names the device); rkfdNodeStatus returns the largest rkfdBatchStatus of the devices. */
+typedef struct rkfdNode rkfdNode;
+rkfdNode *rkfdNodeCreate(const rkfdModel *m, int total, int max_rigid, int ndev, const int *devices);
+void rkfdNodeDestroy(rkfdNode *n);
+int rkfdNodeDevices(const rkfdNode *n);
+int rkfdNodeSize(const rkfdNode *n);
+/* shard k: its HIP device and its block of instances [lo, hi); the rkfdBatch behind it (for the per-batch accessors) */
+int rkfdNodeShard(const rkfdNode *n, int k, int *device, int *lo, int *hi);
+rkfdBatch *rkfdNodeBatch(rkfdNode *n, int k);
+/* host arrays over ALL instances, [total][ndof] / [total][nlink]: scattered to / collected from the devices' shards */
+int rkfdNodeSetState(rkfdNode *n, const double *dis, const double *vel);
+int rkfdNodeSetMotorInput(rkfdNode *n, const double *input);
+int rkfdNodeGetState(rkfdNode *n, double *dis, double *vel, double *acc);      /* plain copies, no collective; any may be NULL */
+/* rkfdBatchSpecialize / SetSplit / UpdateInit / Update / Snapshot / Restore / Status on every device, each issued by the
+ * device's own host thread on the device's own stream; the call returns when every thread has issued its launches (the GPUs run
+ * on; Status and Gather wait for them) */
+int rkfdNodeSpecialize(rkfdNode *n);
+int rkfdNodeSetSplit(rkfdNode *n, int nsplit);
+int rkfdNodeUpdateInit(rkfdNode *n);
+int rkfdNodeUpdate(rkfdNode *n, int nsteps);
+int rkfdNodeSnapshot(rkfdNode *n);
+int rkfdNodeRestore(rkfdNode *n);
+int rkfdNodeStatus(rkfdNode *n);
+/* one ncclAllGather of the final {dis, vel}: afterwards every device holds all `total` final states (rkfdNodeGatherDev: on
+ * device k, [ndev][mx][2 ndof] doubles - block j = shard j's instances, dis | vel per instance, padded to the largest shard mx),
+ * and dis / vel ([total][ndof], either may be NULL) receive them on the host in instance order */
+int rkfdNodeGather(rkfdNode *n, double *dis, double *vel);
+const double *rkfdNodeGatherDev(const rkfdNode *n, int k, int *mx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,7 +6,7 @@ tests and by bench.py; it contains no numerics of its own and never falls back t
 CPU implementation: without the built library or without a GPU the device calls raise.
 """
 from .binding import (  # noqa: F401
-    LIB_PATH, lib, RkfdModel, World, Batch, RkfdError,
+    LIB_PATH, lib, RkfdModel, World, Batch, Node, RkfdError,
     JOINT_FIXED, JOINT_REVOL, JOINT_PRISM, JOINT_FLOAT,
     SOLVER_VERT, SOLVER_MLCP, SOLVER_VOLUME, CONTACT_RIGID, CONTACT_ELASTIC, SF, KF,
 )

@@ -104,6 +104,17 @@ def lib():
     for f in ("rkfdBatchDevDis", "rkfdBatchDevVel", "rkfdBatchDevAcc"):
         getattr(L, f).argtypes = [vp]
         getattr(L, f).restype = vp
+    L.rkfdNodeCreate.argtypes = [C.POINTER(RkfdModel), C.c_int, C.c_int, C.c_int, vp]; L.rkfdNodeCreate.restype = vp
+    L.rkfdNodeDestroy.argtypes = [vp]
+    for f in ("rkfdNodeDevices", "rkfdNodeSize", "rkfdNodeSpecialize", "rkfdNodeUpdateInit", "rkfdNodeSnapshot", "rkfdNodeRestore", "rkfdNodeStatus"):
+        getattr(L, f).argtypes = [vp]
+    L.rkfdNodeShard.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.rkfdNodeBatch.argtypes = [vp, C.c_int]; L.rkfdNodeBatch.restype = vp
+    L.rkfdNodeSetState.argtypes = [vp, vp, vp]; L.rkfdNodeSetMotorInput.argtypes = [vp, vp]
+    L.rkfdNodeGetState.argtypes = [vp, vp, vp, vp]
+    L.rkfdNodeSetSplit.argtypes = [vp, C.c_int]; L.rkfdNodeUpdate.argtypes = [vp, C.c_int]
+    L.rkfdNodeGather.argtypes = [vp, vp, vp]
+    L.rkfdNodeGatherDev.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]; L.rkfdNodeGatherDev.restype = vp
     _lib = L
     return L
 
@@ -320,3 +331,87 @@ class Batch:
 
     def dev_ptrs(self):
         return (self._L.rkfdBatchDevDis(self._b), self._L.rkfdBatchDevVel(self._b), self._L.rkfdBatchDevAcc(self._b))
+
+
+class Node:
+    """`total` instances of one world over the GPUs of one node from ONE process (include/rkfd_hip.h: rkfdNode*): device k
+    simulates its contiguous shard with its own host thread and stream inside the library, no per-step communication; the
+    only collective is gather(): one RCCL all-gather of the final {dis, vel}."""
+
+    def __init__(self, world, total, max_rigid=8, ndev=0, devices=None):
+        self._L = lib()
+        self.world = world
+        m = world.model.contents
+        self.total, self.ndof, self.nlink = total, m.ndof, m.nlink
+        dv = None
+        if devices is not None:
+            dv = (C.c_int * len(devices))(*devices); ndev = len(devices)
+        self._n = self._L.rkfdNodeCreate(world.model, total, max_rigid, ndev, C.cast(dv, C.c_void_p) if dv is not None else None)
+        if not self._n:
+            raise RkfdError(self._L.rkfdHipLastError().decode())
+        self.ndev = self._L.rkfdNodeDevices(self._n)
+
+    def close(self):
+        if getattr(self, "_n", None):
+            self._L.rkfdNodeDestroy(self._n)
+            self._n = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, r):
+        if r < 0:
+            raise RkfdError(self._L.rkfdHipLastError().decode())
+        return r
+
+    def shards(self):
+        out = []
+        for k in range(self.ndev):
+            d, lo, hi = C.c_int(), C.c_int(), C.c_int()
+            self._chk(self._L.rkfdNodeShard(self._n, k, C.byref(d), C.byref(lo), C.byref(hi)))
+            out.append((d.value, lo.value, hi.value))
+        return out
+
+    def set_state(self, dis, vel):
+        dis = np.ascontiguousarray(dis, dtype=np.float64).reshape(self.total, self.ndof)
+        vel = np.ascontiguousarray(vel, dtype=np.float64).reshape(self.total, self.ndof)
+        self._chk(self._L.rkfdNodeSetState(self._n, _ptr(dis), _ptr(vel)))
+
+    def set_motor_input(self, inp):
+        inp = np.ascontiguousarray(inp, dtype=np.float64).reshape(self.total, self.nlink)
+        self._chk(self._L.rkfdNodeSetMotorInput(self._n, _ptr(inp)))
+
+    def get_state(self):
+        dis = np.empty((self.total, self.ndof)); vel = np.empty_like(dis); acc = np.empty_like(dis)
+        self._chk(self._L.rkfdNodeGetState(self._n, _ptr(dis), _ptr(vel), _ptr(acc)))
+        return dis, vel, acc
+
+    def specialize(self):
+        self._chk(self._L.rkfdNodeSpecialize(self._n))
+
+    def set_split(self, nsplit):
+        self._chk(self._L.rkfdNodeSetSplit(self._n, nsplit))
+
+    def update_init(self):
+        self._chk(self._L.rkfdNodeUpdateInit(self._n))
+
+    def update(self, nsteps=1):
+        self._chk(self._L.rkfdNodeUpdate(self._n, nsteps))
+
+    def snapshot(self):
+        self._chk(self._L.rkfdNodeSnapshot(self._n))
+
+    def restore(self):
+        self._chk(self._L.rkfdNodeRestore(self._n))
+
+    def status(self):
+        return self._chk(self._L.rkfdNodeStatus(self._n))
+
+    def gather(self):
+        """one RCCL all-gather of the final {dis, vel}; returns them on the host, [total, ndof] each"""
+        dis = np.empty((self.total, self.ndof)); vel = np.empty_like(dis)
+        self._chk(self._L.rkfdNodeGather(self._n, _ptr(dis), _ptr(vel)))
+        return dis, vel

@@ -766,3 +766,5 @@ extern "C" int rkfdBatchRestore(rkfdBatch *b, void *stream)
   b->pending = 1;
   return 0;
 }
+
+#include "rkfd_capi_node.inc"      /* the node level: one host thread + stream per device, one RCCL all-gather of final states */

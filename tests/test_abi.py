@@ -48,6 +48,19 @@ def test_no_cpu_fallback(R):
     raise AssertionError("rkfdBatchCreate must fail without a GPU")
 
 
+def test_node_level_has_no_cpu_fallback_either(R):
+    """rkfdNodeCreate (all the GPUs of a node from one process, include/rkfd_hip.h) fails loudly without a GPU"""
+    if R.lib().rkfdHipDeviceCount() > 0:
+        return
+    sc = R.scenarios.config2(batch=4)
+    try:
+        R.Node(sc["world"], 4, max_rigid=0)
+    except R.RkfdError as e:
+        assert "no HIP device" in str(e)
+        return
+    raise AssertionError("rkfdNodeCreate must fail without a GPU")
+
+
 def test_lds_budget_and_limits_on_host(R):
     """rkfdLdsBytesFor works without a GPU: the humanoid workloads fit 8 workgroups per CU
     (<= 20 480 B of LDS per instance), oversize worlds are rejected with a message"""

@@ -603,3 +603,50 @@ def test_spherical_joints(R, oracle_cls, contact):
             assert _rel(d[i], od) < tol and _rel(v[i], ov) < tol and _rel(a[i], oa) < tol and _rel(f[i], of) < tol, (s, i)
             seen += int(oact.sum())
     assert (seen > 0) == contact
+
+
+def test_node_level_matches_one_batch(R):
+    """the node level of the C ABI (rkfdNode*: every GPU of a node from one process, one host thread and stream per device, no
+    per-step communication, one RCCL all-gather of the final states): 37 instances of config 4 as THREE uneven shards
+    (13 / 12 / 12 - on one GPU box the three shards share device 0: the sharding, the threads, the packing and the plain
+    copies are the ones an 8-GPU node runs) give bit for bit the states of one batch of 37; the all-gather itself runs through
+    librccl on a one-device node (RCCL refuses two ranks on one device)."""
+    B, nsteps = 37, 6
+    sc = R.scenarios.config4(batch=B)
+    b = R.Batch(sc["world"], B, max_rigid=sc["max_rigid"])
+    b.set_state(sc["dis"], sc["vel"]); b.update_init(); b.update(nsteps)
+    assert b.status() == 0
+    d0, v0, a0 = b.get_state()
+    n3 = R.Node(sc["world"], B, max_rigid=sc["max_rigid"], devices=[0, 0, 0])
+    assert [(lo, hi) for _d, lo, hi in n3.shards()] == [(0, 13), (13, 25), (25, 37)]
+    n3.set_state(sc["dis"], sc["vel"]); n3.update_init(); n3.update(nsteps)
+    assert n3.status() == 0
+    d3, v3, a3 = n3.get_state()
+    assert (d3 == d0).all() and (v3 == v0).all() and (a3 == a0).all()
+    with pytest.raises(R.RkfdError, match="ncclCommInitAll"):
+        n3.gather()                                    # three ranks on one device: refused by RCCL, reported, nothing hangs
+    n3.close()
+    n1 = R.Node(sc["world"], B, max_rigid=sc["max_rigid"], ndev=1)
+    n1.specialize(); n1.set_split(3)
+    n1.set_state(sc["dis"], sc["vel"]); n1.update_init(); n1.snapshot(); n1.update(nsteps)
+    gd, gv = n1.gather()                               # ncclAllGather (one rank), then device 0's copy to the host
+    assert n1.status() == 0
+    assert (gd == d0).all() and (gv == v0).all()
+    n1.restore(); n1.update(nsteps)                    # a second rollout from the snapshot ends in the same states
+    gd2, gv2 = n1.gather()
+    assert (gd2 == d0).all() and (gv2 == v0).all()
+    n1.close()
+
+
+def test_node_level_from_a_c_program(R, tmp_path):
+    """host code stays C: tests/c/node_driver.c (gcc, no HIP headers) drives the node level - create over every visible GPU,
+    set state, steps, status, rkfdNodeGather - and the gathered states equal the plain copies"""
+    import subprocess
+    root = os.path.join(os.path.dirname(__file__), "..")
+    exe = str(tmp_path / "node_driver")
+    subprocess.run(["gcc", "-O1", "-Wall", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "c", "node_driver.c"),
+                    "-L" + os.path.join(root, "roki-fd_amd"), "-lrkfd_amd", "-Wl,-rpath," + os.path.join(root, "roki-fd_amd"), "-o", exe], check=True)
+    r = subprocess.run([exe, os.path.join(root, "models"), "50", "8"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = r.stdout.splitlines()
+    assert out[0].startswith("devices ") and out[-1] == "identical", r.stdout
