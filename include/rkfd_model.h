@@ -26,9 +26,12 @@ extern "C" {
 #endif
 
 /* SPHER: 3 DoF, displacement = angle-axis vector, rate = angular velocity, both in the joint-origin frame (the rotational half of
- * the float joint's convention).  BRFLOAT (RoKi's breakable float joint: 6 DoF, rigid until a force / torque threshold is passed)
- * is read by the loader so that every model the reference ships can be inspected; it has no device path (rkfdBatchCreate
- * refuses a world that holds one, with a message) */
+ * the float joint's convention).  BRFLOAT: RoKi's breakable float joint (reference example/model/wall.ztk:51-53, example/chain/arm_wall_test.c) - six
+ * coordinates like a float joint; until it breaks the link is rigidly attached to its parent (coordinates and rates stay as
+ * set, accelerations zero); at every COMMITTING evaluation (the reference runs rkChainUpdateABIWrench / ...CachedABIWrench only
+ * there, src/rkfd_sim.c:507-514) the wrench the joint transmits is compared with the thresholds brk_f / brk_t (norm of the
+ * force, norm of the torque about the link origin); beyond either the joint is broken from the next evaluation on and is a
+ * float joint for good.  [UNVERIFIED-DEP: RoKi's rk_joint_brfloat is not here; DEVIATIONS.md] */
 enum { RKFD_JOINT_FIXED = 0, RKFD_JOINT_REVOL = 1, RKFD_JOINT_PRISM = 2, RKFD_JOINT_FLOAT = 3, RKFD_JOINT_SPHER = 4, RKFD_JOINT_BRFLOAT = 5 };
 enum { RKFD_MOTOR_NONE = 0, RKFD_MOTOR_TRQ = 1, RKFD_MOTOR_DC = 2 };
 /* contact-info type, cf. RK_CONTACT_RIGID / RK_CONTACT_ELASTIC (reference src/rkfd_cd.c:39-46) */
@@ -96,6 +99,8 @@ typedef struct {
   int max_iter;
   int solver;              /* RKFD_SOLVER_*                                 */
   int pyramid;             /* faces of the friction pyramid of the Vert plugin (rkFDPrp pyramid, default 8) */
+  /* ---- breakable float joints (zero elsewhere) -------------------------- */
+  const double *brk_f, *brk_t;   /* [nlink] force / torque threshold (ZTK forcethreshold / torquethreshold) */
 } rkfdModel;
 
 #ifdef __cplusplus

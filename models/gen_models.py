@@ -236,6 +236,24 @@ def arm_fold():
     return s
 
 
+def wall(name, nbrick, thresholds, upright=True, stuff="wall"):
+    """SYNTHETIC, after the reference's example/model/wall.ztk: a base block fixed to the world and `nbrick` bricks in a row, each
+    hanging on its predecessor by a BREAKABLE FLOAT joint (jointtype: breakablefloat, forcethreshold / torquethreshold); every
+    link carries the same brick shape.  upright: the row stands as a column (the base frame turns the links' x axis up, as in
+    the reference's file), else it sticks out horizontally (a cantilever: the joints carry bending moments)."""
+    inertia = "inertia: {\n 0.0002604166667, 0, 0\n 0, 0.0004166666667, 0\n 0, 0, 0.0002604166667\n}\n"
+    s = f"[roki::chain]\nname : {name}\n\n"
+    s += "[zeo::shape]\ntype : box\nname : brick\ncenter: ( 0.05 0 0 )\ndepth: 0.099\nwidth: 0.049\nheight: 0.099\n\n"
+    base = " 0, 0, -1, 0\n 0, 1, 0, 0.55\n 1, 0, 0, 0\n" if upright else " 1, 0, 0, 0\n 0, 1, 0, 0.55\n 0, 0, 1, 0.5\n"
+    s += f"[roki::link]\nname: base\njointtype: fixed\nmass: 0.25\nCOM: ( 0.05 0 0 )\n{inertia}stuff: {stuff}\nframe: {{\n{base}}}\nshape: brick\n\n"
+    for k in range(nbrick):
+        f, t = thresholds[k]
+        par = "base" if k == 0 else f"brick{k}"
+        s += (f"[roki::link]\nname: brick{k+1}\njointtype: breakablefloat\nforcethreshold: {f}\ntorquethreshold: {t}\nmass: 0.25\n"
+              f"COM: ( 0.05 0 0 )\n{inertia}stuff: {stuff}\nframe: {{\n 1, 0, 0, 0.1\n 0, 1, 0, 0\n 0, 0, 1, 0\n}}\nshape: brick\nparent: {par}\n\n")
+    return s
+
+
 def humanoid(ref_root):
     src = os.path.join(ref_root, "example", "model", "mighty.ztk")
     text = open(src).read()
@@ -325,6 +343,8 @@ def main():
     w("arm_fixedroot.ztk", arm("arm_fixedroot", "fixed"))
     w("arm_revroot.ztk", arm("arm_revroot", "revolute"))
     w("arm_fold.ztk", arm_fold())
+    w("wall.ztk", wall("wall", 3, [(200.0, 200.0), (10.0, 10.0), (10.0, 10.0)]))          # the reference's wall.ztk: same structure and thresholds
+    w("wall_cantilever.ztk", wall("wall_cantilever", 2, [(100.0, 0.4), (100.0, 100.0)], upright=False))
     ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
     if os.path.isdir(ref):
         humanoid(ref)

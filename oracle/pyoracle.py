@@ -29,6 +29,7 @@ def _bind(path):
     L.rkfdOracleSetContact.argtypes = [vp, vp, vp, vp]
     L.rkfdOracleGetPivot.argtypes = [vp, vp, vp]
     L.rkfdOracleSetPivot.argtypes = [vp, vp, vp]
+    L.rkfdOracleGetBroken.argtypes = [vp, vp]; L.rkfdOracleSetBroken.argtypes = [vp, vp]
     L.rkfdOracleUpdateInit.argtypes = [vp]
     L.rkfdOracleUpdate.argtypes = [vp]
     L.rkfdOracleUpdateN.argtypes = [vp, C.c_int]
@@ -121,6 +122,7 @@ class Oracle:
         """forget all contact-vertex and friction-pivot state (a fresh world at the state set next)"""
         self.set_contact(np.zeros(self.ncand, dtype=np.int32), np.zeros(self.ncand, dtype=np.int32), np.zeros((self.ncand, 3)))
         self.set_pivot(np.zeros(self.nlink, dtype=np.int32), np.zeros(self.nlink))
+        self.set_broken(np.zeros(self.nlink, dtype=np.int32))
 
     def get_pivot(self):
         typ = np.empty(self.nlink, dtype=np.int32); prev = np.empty(self.nlink)
@@ -130,6 +132,15 @@ class Oracle:
     def set_pivot(self, typ, prev):
         typ = np.ascontiguousarray(typ, dtype=np.int32); prev = np.ascontiguousarray(prev, dtype=np.float64)
         self._L.rkfdOracleSetPivot(self._o, _p(typ), _p(prev))
+
+    def get_broken(self):
+        b = np.empty(self.nlink, dtype=np.int32)
+        self._L.rkfdOracleGetBroken(self._o, _p(b))
+        return b
+
+    def set_broken(self, broken):
+        b = np.ascontiguousarray(broken, dtype=np.int32)
+        self._L.rkfdOracleSetBroken(self._o, _p(b))
 
     def update_init(self):
         self._L.rkfdOracleUpdateInit(self._o)

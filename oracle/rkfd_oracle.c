@@ -136,6 +136,7 @@ struct rkfdOracle {
   double t;
   double *dis, *vel, *acc, *motor_in;
   int *piv_type; double *piv_prev;
+  int *broken;           /* [nl] breakable float joints: 1 once the joint has broken (state, like the friction pivots) */
   int *cv_active, *cv_type; double *cv_ref, *cv_f;
   Link *lk;
   /* bias arrays (SoA so that save / restore are memcpy) */
@@ -168,8 +169,6 @@ rkfdOracle *rkfdOracleCreate(const rkfdModel *m)
   rkfdOracle *o;
   int i, j, nl = m->nlink, n = m->ndof, nc = m->ncand, k;
 
-  for( i=0; i<nl; i++ )      /* joint types the loader reads but this restatement (like the device path) does not cover */
-    if( m->jtype[i] == RKFD_JOINT_BRFLOAT ) return NULL;
   if( m->solver == RKFD_SOLVER_VOLUME )      /* the Volume plugin's intersection volumes are formed by clipping CONVEX shapes */
     for( i=0; i<m->npair; i++ ){
       if( m->ci_type[m->pair_ci[i]] != RKFD_CONTACT_RIGID ) continue;
@@ -186,6 +185,7 @@ rkfdOracle *rkfdOracleCreate(const rkfdModel *m)
   o->dis = zalloc( sizeof(double)*n ); o->vel = zalloc( sizeof(double)*n ); o->acc = zalloc( sizeof(double)*n );
   o->motor_in = zalloc( sizeof(double)*nl );
   o->piv_type = zalloc( sizeof(int)*nl ); o->piv_prev = zalloc( sizeof(double)*nl );
+  o->broken = zalloc( sizeof(int)*nl );
   o->cv_active = zalloc( sizeof(int)*nc ); o->cv_type = zalloc( sizeof(int)*nc );
   o->cv_ref = zalloc( sizeof(double)*3*nc ); o->cv_f = zalloc( sizeof(double)*3*nc );
   o->lk = zalloc( sizeof(Link)*nl );
@@ -230,7 +230,7 @@ void rkfdOracleDestroy(rkfdOracle *o)
   int k;
   if( !o ) return;
   free( o->qp_q ); free( o->qp_c ); free( o->qp_nf ); free( o->qp_ans ); free( o->qp_idx );
-  free( o->dis ); free( o->vel ); free( o->acc ); free( o->motor_in ); free( o->piv_type ); free( o->piv_prev );
+  free( o->dis ); free( o->vel ); free( o->acc ); free( o->motor_in ); free( o->piv_type ); free( o->piv_prev ); free( o->broken );
   free( o->cv_active ); free( o->cv_type ); free( o->cv_ref ); free( o->cv_f ); free( o->lk );
   free( o->beta0 ); free( o->ext ); free( o->pA ); free( o->u ); free( o->contrib ); free( o->csum );
   free( o->s_beta0 ); free( o->s_pA ); free( o->s_u ); free( o->s_contrib ); free( o->s_csum );
@@ -283,6 +283,23 @@ void rkfdOracleSetPivot(rkfdOracle *o, const int *type, const double *prev_trq)
   memcpy( o->piv_type, type, sizeof(int)*o->nl );
   memcpy( o->piv_prev, prev_trq, sizeof(double)*o->nl );
 }
+void rkfdOracleGetBroken(const rkfdOracle *o, int *broken){ memcpy( broken, o->broken, sizeof(int)*o->nl ); }
+void rkfdOracleSetBroken(rkfdOracle *o, const int *broken){ int i; for( i=0; i<o->nl; i++ ) o->broken[i] = broken[i] != 0 && o->m->jtype[i] == RKFD_JOINT_BRFLOAT; }
+
+/* BREAKABLE FLOAT JOINT [RoKi rk_joint_brfloat, un-vendored; UNVERIFIED-DEP - restated from the model files and drivers that use it:
+ * reference example/model/wall.ztk:51-53 (jointtype: breakablefloat, forcethreshold, torquethreshold), example/chain/arm_wall_test.c].
+ * Six coordinates like a float joint.  Unbroken, the link is rigidly attached to its parent: in the ABA it is a fixed joint (its
+ * whole articulated inertia and bias pass to the parent, its joint acceleration is zero, so its rates and coordinates stay as
+ * set); broken, it is a float joint.  The joint type the dynamics see: */
+static int ejt(const rkfdOracle *o, int i)
+{
+  const int jt = o->m->jtype[i];
+  if( jt != RKFD_JOINT_BRFLOAT ) return jt;
+  return o->broken[i] ? RKFD_JOINT_FLOAT : RKFD_JOINT_FIXED;
+}
+/* the kinematics see a float joint either way (a rigidly attached link sits where its six coordinates put it) */
+static int kjt(const rkfdOracle *o, int i){ return o->m->jtype[i] == RKFD_JOINT_BRFLOAT ? RKFD_JOINT_FLOAT : o->m->jtype[i]; }
+
 void rkfdOracleGetLinkFrames(const rkfdOracle *o, double *R, double *p)
 {
   int i;
@@ -321,7 +338,7 @@ static void connect_state(rkfdOracle *o, const double *dis, const double *vel)
     double wp[3], vp[3], t[3];
 
     /* adjacent frame = org frame * joint transform */
-    switch( m->jtype[i] ){
+    switch( kjt( o, i ) ){
     case RKFD_JOINT_REVOL: {
       double s = sin(q[0]), c = cos(q[0]);
       double Rz[9] = { c,-s,0, s,c,0, 0,0,1 };
@@ -373,7 +390,7 @@ static void connect_state(rkfdOracle *o, const double *dis, const double *vel)
       m3_tmulv( l->Ra, cen, l->gam );
       v3_zero( l->gam+3 );
       v3_copy( l->v+3, wl ); /* w' = Ra' w_p, before the joint's own rate is added */
-      switch( m->jtype[i] ){
+      switch( kjt( o, i ) ){
       case RKFD_JOINT_REVOL: {
         double zq[3] = { 0, 0, l->qd };
         v3_cross( wl, zq, l->gam+3 );
@@ -574,7 +591,7 @@ static void aba_bias_link(rkfdOracle *o, int i, double *newcontrib)
   double *pA = &o->pA[6*i], *u = &o->u[6*i], pa[6], t[6];
   int k;
   for( k=0; k<6; k++ ) pA[k] = o->beta0[6*i+k] - o->ext[6*i+k] + o->csum[6*i+k];
-  switch( m->jtype[i] ){
+  switch( ejt( o, i ) ){
   case RKFD_JOINT_REVOL: case RKFD_JOINT_PRISM: {
     int ax = m->jtype[i] == RKFD_JOINT_REVOL ? 5 : 2;
     double ud;
@@ -631,7 +648,7 @@ static void aba_backward_full(rkfdOracle *o)
     Link *l = &o->lk[i];
     double Ia[36], nc[6];
     int par = m->parent[i];
-    switch( m->jtype[i] ){
+    switch( ejt( o, i ) ){
     case RKFD_JOINT_REVOL: case RKFD_JOINT_PRISM: {
       int ax = m->jtype[i] == RKFD_JOINT_REVOL ? 5 : 2;
       for( k=0; k<6; k++ ) l->U[k] = l->IA[6*k+ax];
@@ -669,7 +686,7 @@ static void aba_backward_full(rkfdOracle *o)
     aba_bias_link( o, i, nc );
     memcpy( &o->contrib[6*i], nc, sizeof(nc) );
     if( par >= 0 ){
-      if( m->jtype[i] != RKFD_JOINT_FLOAT ) congruence_add( l, Ia, o->lk[par].IA );
+      if( ejt( o, i ) != RKFD_JOINT_FLOAT ) congruence_add( l, Ia, o->lk[par].IA );
       for( k=0; k<6; k++ ) o->csum[6*par+k] += nc[k];
     }
   }
@@ -702,7 +719,7 @@ static void aba_forward(rkfdOracle *o, double *acc)
     double y[6];
     xform_acc( l, par < 0 ? zero6 : o->lk[par].a, y );
     for( k=0; k<6; k++ ) y[k] += l->gam[k];
-    switch( m->jtype[i] ){
+    switch( ejt( o, i ) ){
     case RKFD_JOINT_REVOL: case RKFD_JOINT_PRISM: {
       int ax = m->jtype[i] == RKFD_JOINT_REVOL ? 5 : 2;
       double uy = 0, qdd;
@@ -734,7 +751,27 @@ static void aba_forward(rkfdOracle *o, double *acc)
     } break;
     default:
       memcpy( l->a, y, sizeof(y) );
+      if( m->jtype[i] == RKFD_JOINT_BRFLOAT ) for( k=0; k<6; k++ ) acc[m->dofoff[i]+k] = 0;      /* (unbroken: rigidly attached) */
     }
+  }
+}
+
+/* the break test of the unbroken breakable float joints, at a committing evaluation, after the accelerations are final: the
+ * wrench the joint transmits to its link - articulated inertia x acceleration + articulated bias, which for a rigidly attached
+ * subtree is the momentum balance of everything that hangs on the joint, contact and penalty wrenches included - in the link
+ * frame about the link origin; beyond either threshold the joint is broken from the next evaluation on.
+ * [UNVERIFIED-DEP: where RoKi evaluates it (rkJointUpdateWrench inside rkChainUpdateABIWrench, called by the reference only when
+ * doUpRef, src/rkfd_sim.c:511-512), the norms and the strict comparison are this restatement's reading] */
+static void break_test(rkfdOracle *o)
+{
+  const rkfdModel *m = o->m;
+  int i;
+  for( i=0; i<o->nl; i++ ){
+    double w[6];
+    if( m->jtype[i] != RKFD_JOINT_BRFLOAT || o->broken[i] ) continue;
+    m6_mulv( o->lk[i].IA, o->lk[i].a, w );
+    { int k; for( k=0; k<6; k++ ) w[k] += o->pA[6*i+k]; }
+    if( v3_norm( w ) > m->brk_f[i] || v3_norm( w+3 ) > m->brk_t[i] ) o->broken[i] = 1;
   }
 }
 
@@ -1412,6 +1449,7 @@ static int evaluate(rkfdOracle *o, const double *dis, const double *vel, double 
     aba_backward_full( o );
     aba_forward( o, acc );
   }
+  if( doUpRef ) break_test( o );
   return 0;
 }
 
@@ -1454,7 +1492,7 @@ static void cat_dis(const rkfdOracle *o, const double *x, double k, const double
   int i, j;
   for( i=0; i<o->nl; i++ ){
     int off = m->dofoff[i];
-    switch( m->jtype[i] ){
+    switch( kjt( o, i ) ){
     case RKFD_JOINT_FLOAT: {
       double aa[3], Rk[9], R0[9], Rn[9];
       for( j=0; j<3; j++ ) xn[off+j] = x[off+j] + k*v[off+j];

@@ -40,6 +40,10 @@ void rkfdOracleSetContact(rkfdOracle *o, const int *active, const int *type, con
 void rkfdOracleGetPivot(const rkfdOracle *o, int *type, double *prev_trq);
 void rkfdOracleSetPivot(rkfdOracle *o, const int *type, const double *prev_trq);
 
+/* breakable float joints: 1 per link whose joint has broken (state; 0 for every other link) */
+void rkfdOracleGetBroken(const rkfdOracle *o, int *broken);
+void rkfdOracleSetBroken(rkfdOracle *o, const int *broken);
+
 /* rkFDUpdateInit (reference src/rkfd_sim.c:552-558): one committing evaluation at t */
 void rkfdOracleUpdateInit(rkfdOracle *o);
 /* rkFDUpdate (reference src/rkfd_sim.c:560-566): RKG stages + committing evaluation */

@@ -45,6 +45,7 @@ static void *worker(void *arg)
     rkfdOracleSetState( o, w->dis + (size_t)k*m->ndof, w->vel + (size_t)k*m->ndof );
     if( m->ncand > 0 ) rkfdOracleSetContact( o, zi, zi, zd );
     rkfdOracleSetPivot( o, zi, zd );
+    rkfdOracleSetBroken( o, zi );
     rkfdOracleUpdateInit( o );
     if( w->horizon > 0 ){
       rkfdOracleUpdateN( o, w->horizon );

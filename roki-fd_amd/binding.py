@@ -42,6 +42,7 @@ class RkfdModel(C.Structure):
         ("cand_pair", _pi), ("cand_side", _pi), ("cand_vert", _pi),
         ("dt", C.c_double), ("friction_weight", C.c_double),
         ("max_iter", C.c_int), ("solver", C.c_int), ("pyramid", C.c_int),
+        ("brk_f", _pd), ("brk_t", _pd),
     ]
 
     def arr(self, name, n, dtype=None):

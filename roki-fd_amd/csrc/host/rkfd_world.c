@@ -138,6 +138,7 @@ int rkfdWorldBuild(rkfdWorld *w)
   double *org = NULL, *mass = NULL, *com = NULL, *inertia = NULL;
   double *stiff = NULL, *visc = NULL, *coulomb = NULL, *sfric = NULL;
   double *mot_k = NULL, *mot_admit = NULL, *mot_vmax = NULL, *mot_vmin = NULL, *mot_gear = NULL, *mot_inertia = NULL;
+  double *brk_f = NULL, *brk_t = NULL;
   int *shape_link = NULL, *shape_voff = NULL, *shape_foff = NULL, *shape_chain = NULL, *shape_convex = NULL;
   int *shape_slide_mode = NULL; double *shape_slide_vel = NULL, *shape_slide_axis = NULL;
   double *verts = NULL, *planes = NULL;
@@ -199,6 +200,7 @@ int rkfdWorldBuild(rkfdWorld *w)
     GET( stiff, double, nlink ); GET( visc, double, nlink ); GET( coulomb, double, nlink ); GET( sfric, double, nlink );
     GET( mot_k, double, nlink ); GET( mot_admit, double, nlink ); GET( mot_vmax, double, nlink );
     GET( mot_vmin, double, nlink ); GET( mot_gear, double, nlink ); GET( mot_inertia, double, nlink );
+    GET( brk_f, double, nlink ); GET( brk_t, double, nlink );
     GET( shape_link, int, nshape ); GET( shape_voff, int, nshape+1 ); GET( shape_foff, int, nshape+1 );
     GET( shape_chain, int, nshape ); GET( shape_convex, int, nshape );
     GET( shape_slide_mode, int, nshape ); GET( shape_slide_vel, double, nshape ); GET( shape_slide_axis, double, nshape*3 );
@@ -223,6 +225,7 @@ int rkfdWorldBuild(rkfdWorld *w)
         mass[li] = l->mass;
         memcpy( &com[3*li], l->com, sizeof(double)*3 );
         memcpy( &inertia[9*li], l->inertia, sizeof(double)*9 );
+        if( l->jtype == RKFD_JOINT_BRFLOAT ){ brk_f[li] = l->ep_f; brk_t[li] = l->ep_t; }
         if( rkfd_joint_dof( l->jtype ) == 1 ){
           stiff[li] = l->stiff; visc[li] = l->visc; coulomb[li] = l->coulomb; sfric[li] = l->sfric;
           if( l->motor >= 0 ){
@@ -279,6 +282,7 @@ int rkfdWorldBuild(rkfdWorld *w)
   m->stiff = stiff; m->visc = visc; m->coulomb = coulomb; m->sfric = sfric;
   m->mtype = mtype; m->mot_k = mot_k; m->mot_admit = mot_admit; m->mot_vmax = mot_vmax;
   m->mot_vmin = mot_vmin; m->mot_gear = mot_gear; m->mot_inertia = mot_inertia;
+  m->brk_f = brk_f; m->brk_t = brk_t;
   m->nshape = nshape; m->shape_link = shape_link; m->shape_voff = shape_voff; m->shape_foff = shape_foff;
   m->shape_slide_mode = shape_slide_mode; m->shape_slide_vel = shape_slide_vel; m->shape_slide_axis = shape_slide_axis;
   m->verts = verts; m->planes = planes;
