@@ -59,6 +59,11 @@ int rkfdBatchSetContact(rkfdBatch *b, const int *active, const int *type, const 
 int rkfdBatchGetPivot(rkfdBatch *b, int *type, double *prev_trq);
 int rkfdBatchSetPivot(rkfdBatch *b, const int *type, const double *prev_trq);
 
+/* breakable float joints (reference example/model/wall.ztk:51-53; RoKi rk_joint_brfloat, include/rkfd_model.h): 1 per link whose
+ * joint has broken, 0 elsewhere, [batch][nlink].  State like the friction pivots: every launch reads it and writes it back. */
+int rkfdBatchGetBroken(rkfdBatch *b, int *broken);
+int rkfdBatchSetBroken(rkfdBatch *b, const int *broken);
+
 /* rkFDUpdateInit's committing evaluation _rkFDUpdateRef (reference src/rkfd_sim.c:542-549,556).
  * stream: hipStream_t (NULL = default stream).  Asynchronous. */
 int rkfdBatchUpdateInit(rkfdBatch *b, void *stream);

@@ -92,6 +92,7 @@ def lib():
     L.rkfdBatchSetContact.argtypes = [vp, vp, vp, vp]
     L.rkfdBatchGetPivot.argtypes = [vp, vp, vp]
     L.rkfdBatchSetPivot.argtypes = [vp, vp, vp]
+    L.rkfdBatchGetBroken.argtypes = [vp, vp]; L.rkfdBatchSetBroken.argtypes = [vp, vp]
     L.rkfdBatchUpdateInit.argtypes = [vp, vp]
     L.rkfdBatchUpdate.argtypes = [vp, C.c_int, vp]
     L.rkfdBatchEval.argtypes = [vp, C.c_int, vp]
@@ -255,6 +256,16 @@ class Batch:
     def set_pivot(self, typ, prev):
         typ = np.ascontiguousarray(typ, dtype=np.int32); prev = np.ascontiguousarray(prev, dtype=np.float64)
         self._chk(self._L.rkfdBatchSetPivot(self._b, _ptr(typ), _ptr(prev)))
+
+    def get_broken(self):
+        """breakable float joints: 1 per link whose joint has broken, [B, nlink]"""
+        br = np.empty((self.B, self.nlink), dtype=np.int32)
+        self._chk(self._L.rkfdBatchGetBroken(self._b, _ptr(br)))
+        return br
+
+    def set_broken(self, broken):
+        br = np.ascontiguousarray(broken, dtype=np.int32).reshape(self.B, self.nlink)
+        self._chk(self._L.rkfdBatchSetBroken(self._b, _ptr(br)))
 
     def update_init(self, stream=None):
         self._chk(self._L.rkfdBatchUpdateInit(self._b, stream))

@@ -359,6 +359,7 @@ typedef struct {
   unsigned short *CFO;            /* [NC] first plane of the candidate's partner shape    */
   unsigned short *CHP;            /* [NL] children lists (CSR values; offsets in the schedule): child | ( its pool slot + 1 ) << 8 */
   unsigned char *PL;              /* [NL*nlevel] ancestor at depth d (MLCP only), one byte each */
+  unsigned char *BRK;             /* [NL] worlds with breakable float joints only: 0 no such joint, 1 unbroken, 2 broken (rkfd_dev_brf.h) */
   /* Volume plugin (kernel variant sv == 2 only; rkfd_dev_volume.h): per colliding pair VD [np*48] and its contact-plane
    * conditions VPL [np*ncp*8]; face polygons VPOLY [nf*pv*3] and reduction scratch VRED [16*nf+16] of the collision phase, sharing
    * their storage with the solve's:
@@ -371,7 +372,7 @@ typedef struct {
   int *GC;
 } rkfdLds;
 RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int M, int nlevel, int npool, int nfloat, int maxact, int nside, int pu_alias, int npurow, int vert_rigid, int has_slide, int ma_size,
-                             int vol_np, int vol_ncp, int vol_pv, int vol_nf, int pyramid)
+                             int vol_np, int vol_ncp, int vol_pv, int vol_nf, int pyramid, int has_pl)
 /* must match the byte count computed in rkfd_devmodel.cpp */
 {
   double *d = (double *)base;
@@ -431,7 +432,8 @@ RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int
   unsigned char *bp = (unsigned char *)sp;
   L->act = bp; bp += NC; L->typ = bp; bp += NC; L->asl = bp; bp += NC;
   L->CRC = bp; if( vert_rigid ) bp += M;
-  L->PL = bp;
+  L->PL = bp; if( has_pl ) bp += NL*( nlevel+3 );
+  L->BRK = bp;
 }
 
 /* the contact frame of a slot: normal and first tangent are stored, the second tangent is their cross product
@@ -466,6 +468,11 @@ typedef struct { double min, pivp; int pivt;
  * level pu_d0, and every stride is a dimension of the WORLD (a literal in the kernels compiled for one world), not of the
  * evaluation's contact count. */
 #define RKFD_PU_AT(m, s, col, d) ( ( (s)*3*(m).maxrg + (col) )*(m).npurow + (d) - (m).pu_d0 )
+
+/* L->BRK: breakable float joints (rkfd_dev_brf.h) */
+#define RKFD_BRF_NONE     0
+#define RKFD_BRF_ATTACHED 1
+#define RKFD_BRF_BROKEN   2
 
 /* counters in L->cnt */
 #define CNT_NRG 0

@@ -693,6 +693,7 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
     const int jt = RKFD_LI_JT( L.LI[lane] );
     if( RKFD_JT_IS1( jt ) ) L.MS[3*lane+2] = sqrt( L.MS[3*lane+0] );
   }
+  if( m.has_brf ) rkfd_brf_before_probes( m, L );
   SYNC();
   /* many contacts on several independent bodies: the grouped layout (rkfd_pgs_group_layout) serves the matrix build and the
    * Gauss-Seidel below; its table lives in the link accelerations' storage, free from here to the delta sweep */

@@ -16,7 +16,9 @@ template<bool prof, int vqp, bool pk> RKFD_DEV int rkfd_evaluate(const rkfdDevMo
   unsigned long long t0 = 0, t1;
 #define STAMP(k) do{ if( prof ){ t1 = RKFD_CLOCK(); pc[k] += t1 - t0; t0 = t1; } }while(0)
   if( prof ) t0 = RKFD_CLOCK();
+  if( m.has_brf ) rkfd_brf_before_kinematics( m, L );
   rkfd_phase_kinematics<prof>( m, L, ll, pc );
+  if( m.has_brf ) rkfd_brf_after_kinematics( m, L );
   STAMP(0);
   /* commit joint friction pivots (the reference does so inside rkFDJointFrictionRevolDC) */
   if( doUpRef && lane < m.nlink ){
@@ -48,6 +50,8 @@ template<bool prof, int vqp, bool pk> RKFD_DEV int rkfd_evaluate(const rkfdDevMo
   STAMP(2);
   rkfd_phase_sweep3<false>( m, L );
   STAMP(3);
+  bool solved = false;      /* rigid contact forces were solved in this evaluation */
+  if( m.has_brf && doUpRef ) rkfd_brf_wrench_part( m, L );      /* bias + Ia x free acceleration */
   if( vqp == 2 ){
     if( L.cnt[CNT_NVP] > 0 ){
       SYNC();
@@ -56,6 +60,8 @@ template<bool prof, int vqp, bool pk> RKFD_DEV int rkfd_evaluate(const rkfdDevMo
       STAMP(4);
       rkfd_phase_sweep3<true>( m, L );
       SYNC();
+      solved = true;
+      if( m.has_brf && doUpRef ) rkfd_brf_wrench_part( m, L );
       if( lane < m.ndof ) L.acc[lane] += afree;
       SYNC();
       STAMP(3);
@@ -70,12 +76,18 @@ template<bool prof, int vqp, bool pk> RKFD_DEV int rkfd_evaluate(const rkfdDevMo
       STAMP(4);
       rkfd_phase_sweep3<true>( m, L );
       SYNC();
+      solved = true;
+      if( m.has_brf && doUpRef ) rkfd_brf_wrench_part( m, L );      /* + Ia x the change of the acceleration */
       if( lane < m.ndof ) L.acc[lane] += afree;
       SYNC();
       STAMP(3);
     } else {
       err = 1;
     }
+  }
+  if( m.has_brf && doUpRef ){
+    if( vqp == 2 ) rkfd_brf_break_test_vol( m, L, solved );
+    else rkfd_brf_break_test( m, L, solved );
   }
   /* rkFDUpdateJointPrevDrivingTrq (reference src/rkfd_util.c:289-311), committing evaluation only */
   if( doUpRef && lane < m.nlink ){
@@ -133,7 +145,7 @@ template<bool prof, int vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDevM
   m.npurow = RKFD_SPEC_NPUROW; m.pu_d0 = RKFD_SPEC_PU_D0; m.pu_alias = RKFD_SPEC_PU_ALIAS; m.vert_rigid = RKFD_SPEC_VERT_RIGID; m.qscr_alias = RKFD_SPEC_QSCR_ALIAS;
   m.has_slide = RKFD_SPEC_HAS_SLIDE; m.ma_size = RKFD_SPEC_MA_SIZE; m.ma_packed = RKFD_SPEC_MA_PACKED;
   m.max_iter = RKFD_SPEC_MAX_ITER; m.solver = RKFD_SPEC_SOLVER; m.pyramid = RKFD_SPEC_PYRAMID; m.anchor = RKFD_SPEC_ANCHOR;
-  m.mlcp_mfma = RKFD_SPEC_MLCP_MFMA;
+  m.mlcp_mfma = RKFD_SPEC_MLCP_MFMA; m.has_brf = RKFD_SPEC_HAS_BRF;
   m.vol_npair = RKFD_SPEC_VOL_NPAIR; m.vol_np = RKFD_SPEC_VOL_NP; m.vol_ncp = RKFD_SPEC_VOL_NCP; m.vol_pv = RKFD_SPEC_VOL_PV; m.vol_nf = RKFD_SPEC_VOL_NF;
 #else
   const rkfdDevModel &m = m_;
@@ -142,7 +154,7 @@ template<bool prof, int vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDevM
   const int ND = m.ndof, NL = m.nlink, NC = m.ncand;
   rkfdLds L;
   rkfd_lds_carve( &L, ldsbase, NL, ND, NC, 3*m.maxrg, m.nlevel, m.npool, m.nfloat, m.maxact, m.nside, m.pu_alias, m.npurow, m.vert_rigid, m.has_slide, m.ma_size,
-                  vqp == 2 ? m.vol_np : 0, m.vol_ncp, m.vol_pv, m.vol_nf, m.pyramid );
+                  vqp == 2 ? m.vol_np : 0, m.vol_ncp, m.vol_pv, m.vol_nf, m.pyramid, m.maxrg > 0 );
   if( m.lds_poison > 0 ){      /* (RKFD_DEBUG_POISON_LDS: see rkfd_devmodel.h) */
     for( int i=lane; i<m.lds_poison; i+=RKFD_WAVE ) ( (unsigned *)ldsbase )[i] = 0xffffffffu;
     SYNC();
@@ -178,6 +190,7 @@ template<bool prof, int vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDevM
   if( m.maxrg > 0 ){
     for( int k=lane; k<NL*( m.nlevel+3 ); k+=RKFD_WAVE ) L.PL[k] = (unsigned char)m.pathlink[k];
   }
+  if( m.has_brf ) rkfd_brf_load( m, st, L, b );
   for( int c0=0, base=0; c0<NC; c0+=RKFD_WAVE ){
     const int j = c0 + lane;
     const bool onj = j < NC;
@@ -272,6 +285,7 @@ template<bool prof, int vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDevM
     st.piv_type[(size_t)b*m.nlink_model+lm] = ll.pivt;
     st.piv_prev[(size_t)b*m.nlink_model+lm] = ll.pivp;
   }
+  if( m.has_brf ) rkfd_brf_store( m, st, L, b );
   /* contact state: the flag of every candidate, the rest only for those in contact (a candidate out of
    * contact has no state: type and anchor are re-initialised at its next first contact, and the
    * boundary reports zeros for it) */

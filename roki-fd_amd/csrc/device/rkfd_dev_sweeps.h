@@ -145,9 +145,11 @@ template<bool prof> RKFD_DEV void rkfd_phase_sweep2(const rkfdDevModel &m, const
     const bool onl = rec.i >= 0;
     const bool on = onl && r < 6;
     const int i = onl ? rec.i : 0;
-    const int jt = onl ? RKFD_LI_JT( rec.li ) : RKFD_JOINT_FIXED;
+    /* (worlds with breakable float joints: what such a joint is in this evaluation stands in the link info in LDS, rkfd_dev_brf.h) */
+    const int jt = onl ? RKFD_LI_JT( m.has_brf ? L.LI[i] : rec.li ) : RKFD_JOINT_FIXED;
     const bool is1 = RKFD_JT_IS1( jt );
     const bool isf = jt == RKFD_JOINT_FLOAT;
+    const bool isb = m.has_brf && onl && L.BRK[i] == RKFD_BRF_ATTACHED;      /* an attached breakable joint: a fixed joint today */
     double row[6], pr = pre.pb;
 #pragma unroll
     for( int k=0; k<6; k++ ) row[k] = pre.row[k];
@@ -202,13 +204,15 @@ template<bool prof> RKFD_DEV void rkfd_phase_sweep2(const rkfdDevModel &m, const
       /* Ia goes to LDS only where somebody will read it: a gathering parent (pool slot REC_POOL( rec ))
        * or the Cholesky of a float joint (slot REC_FSLOT( rec )) */
       if( REC_POOL( rec ) >= 0 ){
+        /* (a float joint hands nothing to its parent; it owns a pool slot only as a breakable joint that has broken) */
 #pragma unroll
-        for( int k=0; k<6; k++ ) L.POOL[36*REC_POOL( rec )+6*rr+k] = row[k];
+        for( int k=0; k<6; k++ ) L.POOL[36*REC_POOL( rec )+6*rr+k] = isf ? 0.0 : row[k];
       }
-      if( isf ){
+      if( isf || isb ){
 #pragma unroll
         for( int k=0; k<6; k++ ) if( k <= rr ) L.CHOL[21*REC_FSLOT( rec )+RKFD_TRI( rr, k )] = row[k];
       }
+      if( isb ) L.XF[12*REC_FSLOT( rec )+rr] = pr;      /* the bias force, for the break test (the frame slot's rotation is not needed today) */
       if( is1 ) L.U[6*i+rr] = U_r;
       L.PA[6*i+rr] = pa;
       if( isf ) L.U[6*i+rr] = pr;   /* float: the U slot keeps the bias pA */
@@ -260,7 +264,7 @@ template<bool delta> RKFD_DEV void rkfd_phase_sweep3(const rkfdDevModel &m, cons
     const bool onl = rec.i >= 0;
     const bool on = onl && r < 6;
     const int i = onl ? rec.i : 0;
-    const int jt = onl ? RKFD_LI_JT( rec.li ) : RKFD_JOINT_FIXED;
+    const int jt = onl ? RKFD_LI_JT( m.has_brf ? L.LI[i] : rec.li ) : RKFD_JOINT_FIXED;
     const bool is1 = RKFD_JT_IS1( jt );
     const int par = onl ? RKFD_LI_PAR( rec.li ) : -1;
     const int off = RKFD_LI_OFF( rec.li );
@@ -313,6 +317,7 @@ template<bool delta> RKFD_DEV void rkfd_phase_sweep3(const rkfdDevModel &m, cons
         L.acc[off+3] = o2[0]; L.acc[off+4] = o2[1]; L.acc[off+5] = o2[2];
       }
     }
+    if( m.has_brf && on && L.BRK[i] == RKFD_BRF_ATTACHED ) L.acc[off+rr] = 0.0;      /* rigidly attached: its six joint accelerations are zero */
     LDS_FENCE();
     if( jt == RKFD_JOINT_FLOAT ) a = L.AC[6*i+rr];
     if( on && jt != RKFD_JOINT_FLOAT ) L.AC[6*i+rr] = a;

@@ -1010,6 +1010,7 @@ template<bool prof> RKFD_DEV void rkfd_phase_volume(const rkfdDevModel &m, const
     const int jt = RKFD_LI_JT( L.LI[lane] );
     if( RKFD_JT_IS1( jt ) ) L.MS[3*lane+2] = sqrt( L.MS[3*lane+0] );
   }
+  if( m.has_brf ) rkfd_brf_before_probes( m, L );
   SYNC();
   VST(14);
   /* probes (reference :176-211): lane = column 6 c + i, a unit world force (i < 3) or torque at the centre of pair c, + on
@@ -1297,6 +1298,42 @@ template<bool prof> RKFD_DEV void rkfd_phase_volume(const rkfdDevModel &m, const
   SYNC();
   VST(23);
 #undef VST
+}
+
+/* the break test of the breakable float joints (rkfd_dev_brf.h) under the Volume plugin: the rigid pairs in volumetric contact
+ * act through one wrench each - force and torque about the pair's centre, + on cell[0], - on cell[1] (VD_W) */
+RKFD_DEV void rkfd_brf_break_test_vol(const rkfdDevModel &m, const rkfdLds &L, bool solved)
+{
+  const int lane = LANE();
+  if( lane < m.nlink && L.BRK[lane] == RKFD_BRF_ATTACHED ){
+    const double *XF = &L.XF[12*rkfd_brf_fslot( m, L, lane )];
+    double w[6];
+#pragma unroll
+    for( int k=0; k<6; k++ ) w[k] = XF[k];
+    if( solved ){
+      const int np = L.cnt[CNT_NVP];
+      for( int p=0; p<np; p++ ){
+        const double *vd = &L.VD[RKFD_VD*p];
+        const int *rec = &RELOAD( m.vol_pair )[8*L.VI[2*p+1]];
+        const double x[3] = { vd[RKFD_VD_C], vd[RKFD_VD_C+1], vd[RKFD_VD_C+2] }, f[3] = { vd[RKFD_VD_W], vd[RKFD_VD_W+1], vd[RKFD_VD_W+2] };
+        double t[3];
+        d_cross( x, f, t );
+        t[0] += vd[RKFD_VD_W+3]; t[1] += vd[RKFD_VD_W+4]; t[2] += vd[RKFD_VD_W+5];
+#pragma unroll
+        for( int sd=0; sd<2; sd++ ){
+          int k = sd == 0 ? RKFD_VP_LA( rec ) : RKFD_VP_LB( rec );
+          while( k != lane && k >= 0 && L.BRK[k] == RKFD_BRF_ATTACHED ) k = RKFD_LI_PAR( L.LI[k] );
+          if( k == lane ){
+            const double sg = sd == 0 ? -1.0 : 1.0;      /* the bias is minus the external wrench */
+            w[0] = fma( sg, t[0], w[0] ); w[1] = fma( sg, t[1], w[1] ); w[2] = fma( sg, t[2], w[2] );
+            w[3] = fma( sg, f[0], w[3] ); w[4] = fma( sg, f[1], w[4] ); w[5] = fma( sg, f[2], w[5] );
+          }
+        }
+      }
+    }
+    rkfd_brf_decide( m, L, lane, XF, w );
+  }
+  SYNC();
 }
 
 #endif /* RKFD_DEV_VOLUME_H */

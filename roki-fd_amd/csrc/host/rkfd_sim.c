@@ -169,11 +169,13 @@ static rkFDSolver *solver_create(rkFDSolver *s, int kind, rkFDSolverCom *com)
 rkFDSolver *rkFDSolverCreate_Vert(rkFDSolver *s){ return solver_create( s, RKFD_SOLVER_VERT, &rkfd_solver_Vert ); }
 rkFDSolver *rkFDSolverCreate_MLCP(rkFDSolver *s){ return solver_create( s, RKFD_SOLVER_MLCP, &rkfd_solver_MLCP ); }
 /* Volume (reference src/rkfd_volume.c): rigid pairs of convex shapes go by their intersection volumes on the device
- * (csrc/device/rkfd_dev_volume.h); max_rigid counts PAIRS in collision at once here (at most 10) */
+ * (csrc/device/rkfd_dev_volume.h); max_rigid counts PAIRS in collision at once here (at most 10).  Seven by default: pairs x
+ * ( 1 + contact-plane conditions per pair ) is bounded by 64, and with seven pairs every pair keeps the eight conditions a pair
+ * of boxes can produce (ten pairs would leave five, which the hand of an arm pressed flat against a brick exceeds) */
 rkFDSolver *rkFDSolverCreate_Volume(rkFDSolver *s)
 {
   rkFDSolver *r = solver_create( s, RKFD_SOLVER_VOLUME, &rkfd_solver_Volume );
-  if( r ) ( (rkFDSolverPrpAMD *)r->prp )->max_rigid = 10;
+  if( r ) ( (rkFDSolverPrpAMD *)r->prp )->max_rigid = 7;
   return r;
 }
 
@@ -495,8 +497,9 @@ int rkfdWorldRegFile(rkfdWorld *w, const char *filename)
 void rkfdWorldSetPrp(rkfdWorld *w, double dt, double friction_weight, int max_iter, int solver)
 {
   w->model.dt = dt; w->model.friction_weight = friction_weight; w->model.max_iter = max_iter; w->model.solver = solver;
-  /* default contact info follows the solver, as rkFDSetSolver does */
-  w->cidef.type = RKFD_CONTACT_RIGID; w->cidef.k = 1000.0; w->cidef.l = 1.0; w->cidef.sf = 0.5; w->cidef.kf = 0.3;
+  /* default contact info follows the solver, as rkFDSetSolver does (reference src/rkfd_vert.c:340-348, src/rkfd_mlcp.c:301-310:
+   * relaxation 1.0; src/rkfd_volume.c:961-969: 0.001) */
+  w->cidef.type = RKFD_CONTACT_RIGID; w->cidef.k = 1000.0; w->cidef.l = solver == RKFD_SOLVER_VOLUME ? 0.001 : 1.0; w->cidef.sf = 0.5; w->cidef.kf = 0.3;
   w->built = 0;
 }
 /* rkFDCDCellSetSlideMode / Vel / Axis (reference src/rkfd_sim.c:384-401) on shape number `shape` of a chain

@@ -79,6 +79,7 @@ rkfd_restore_kernel(rkfdDevState st, rkfdDevState sn, int first, int ND, int NLM
   }
   for( int j=threadIdx.x; j<NLM; j+=RKFD_WAVE ){
     st.piv_type[b*NLM+j] = sn.piv_type[b*NLM+j]; st.piv_prev[b*NLM+j] = sn.piv_prev[b*NLM+j];
+    st.brk[b*NLM+j] = sn.brk[b*NLM+j];
   }
   for( int j=threadIdx.x; j<NC; j+=RKFD_WAVE ){
     st.cv_active[b*NC+j] = sn.cv_active[b*NC+j]; st.cv_type[b*NC+j] = sn.cv_type[b*NC+j];
@@ -177,6 +178,7 @@ extern "C" rkfdBatch *rkfdBatchCreate(const rkfdModel *m, int batch, int device,
   int bad = 0;
   bad |= dalloc( &b->st.dis, B*ND ); bad |= dalloc( &b->st.vel, B*ND ); bad |= dalloc( &b->st.acc, B*ND );
   bad |= dalloc( &b->st.motor_in, B*NL ); bad |= dalloc( &b->st.piv_type, B*NL ); bad |= dalloc( &b->st.piv_prev, B*NL );
+  bad |= dalloc( &b->st.brk, B*NL );
   bad |= dalloc( &b->st.cv_active, B*NC ); bad |= dalloc( &b->st.cv_type, B*NC );
   bad |= dalloc( &b->st.cv_ref, B*NC*3 ); bad |= dalloc( &b->st.cv_f, B*NC*3 );
   bad |= dalloc( &b->st.stat, B*4 );
@@ -198,11 +200,11 @@ extern "C" void rkfdBatchDestroy(rkfdBatch *b)
 {
   if( !b ) return;
   (void)hipFree( b->st.dis ); (void)hipFree( b->st.vel ); (void)hipFree( b->st.acc );
-  (void)hipFree( b->st.motor_in ); (void)hipFree( b->st.piv_type ); (void)hipFree( b->st.piv_prev );
+  (void)hipFree( b->st.motor_in ); (void)hipFree( b->st.piv_type ); (void)hipFree( b->st.piv_prev ); (void)hipFree( b->st.brk );
   (void)hipFree( b->st.cv_active ); (void)hipFree( b->st.cv_type ); (void)hipFree( b->st.cv_ref ); (void)hipFree( b->st.cv_f );
   (void)hipFree( b->st.stat );
   (void)hipFree( b->snap.dis ); (void)hipFree( b->snap.vel ); (void)hipFree( b->snap.acc );
-  (void)hipFree( b->snap.piv_type ); (void)hipFree( b->snap.piv_prev );
+  (void)hipFree( b->snap.piv_type ); (void)hipFree( b->snap.piv_prev ); (void)hipFree( b->snap.brk );
   (void)hipFree( b->snap.cv_active ); (void)hipFree( b->snap.cv_type ); (void)hipFree( b->snap.cv_ref ); (void)hipFree( b->snap.cv_f );
   if( b->fork ){
     (void)hipEventDestroy( b->fork );
@@ -320,6 +322,23 @@ extern "C" int rkfdBatchGetPivot(rkfdBatch *b, int *type, double *prev_trq)
   D2H( type, b->st.piv_type, sizeof(int)*n ); D2H( prev_trq, b->st.piv_prev, sizeof(double)*n );
   return 0;
 }
+/* breakable float joints: 1 per link whose joint has broken, [batch][nlink] */
+extern "C" int rkfdBatchGetBroken(rkfdBatch *b, int *broken)
+{
+  if( !b || !broken ){ SETERR( "null argument" ); return -1; }
+  HIPCHK( hipSetDevice( b->device ), -1 );
+  if( sync_streams( b ) < 0 ) return -1;
+  D2H( broken, b->st.brk, sizeof(int)*(size_t)b->batch*b->nlink );
+  return 0;
+}
+extern "C" int rkfdBatchSetBroken(rkfdBatch *b, const int *broken)
+{
+  if( !b || !broken ){ SETERR( "null argument" ); return -1; }
+  HIPCHK( hipSetDevice( b->device ), -1 );
+  if( sync_streams( b ) < 0 ) return -1;
+  H2D( b->st.brk, broken, sizeof(int)*(size_t)b->batch*b->nlink );
+  return 0;
+}
 extern "C" int rkfdBatchSetPivot(rkfdBatch *b, const int *type, const double *prev_trq)
 {
   if( !b ){ SETERR( "null batch" ); return -1; }
@@ -426,6 +445,7 @@ static std::string spec_source(const rkfdDevModel &d)
     "#define RKFD_SPEC_NPUROW %d\n#define RKFD_SPEC_PU_D0 %d\n#define RKFD_SPEC_PU_ALIAS %d\n#define RKFD_SPEC_VERT_RIGID %d\n#define RKFD_SPEC_QSCR_ALIAS %d\n"
     "#define RKFD_SPEC_HAS_SLIDE %d\n#define RKFD_SPEC_MA_SIZE %d\n#define RKFD_SPEC_MA_PACKED %d\n"
     "#define RKFD_SPEC_MAX_ITER %d\n#define RKFD_SPEC_SOLVER %d\n#define RKFD_SPEC_PYRAMID %d\n#define RKFD_SPEC_ANCHOR %d\n#define RKFD_SPEC_MLCP_MFMA %d\n"
+    "#define RKFD_SPEC_HAS_BRF %d\n"
     "#define RKFD_SPEC_VOL_NPAIR %d\n#define RKFD_SPEC_VOL_NP %d\n#define RKFD_SPEC_VOL_NCP %d\n#define RKFD_SPEC_VOL_PV %d\n#define RKFD_SPEC_VOL_NF %d\n"
     "#include \"rkfd_device.h\"\n"
     "extern \"C\" __global__ void __launch_bounds__(64, %d)\n"
@@ -438,7 +458,7 @@ static std::string spec_source(const rkfdDevModel &d)
     "}\n",
     d.nlink, d.ndof, d.ncand, d.nlink_model, d.nlevel, d.nround, d.nsched, d.maxrg, d.npool, d.nfloat, d.maxact, d.nside,
     d.npurow, d.pu_d0, d.pu_alias, d.vert_rigid, d.qscr_alias, d.has_slide, d.ma_size, d.ma_packed, d.max_iter, d.solver, d.pyramid, d.anchor, d.mlcp_mfma,
-    d.vol_npair, d.vol_np, d.vol_ncp, d.vol_pv, d.vol_nf,
+    d.has_brf, d.vol_npair, d.vol_np, d.vol_ncp, d.vol_pv, d.vol_nf,
     d.vol_np > 0 ? 2 : 3, d.vol_np > 0 ? "2" : ( d.vert_rigid ? "1" : "0" ), d.ma_packed ? "true" : "false" );
   std::string src;
   if( const char *pre = getenv( "RKFD_SPEC_DEFINE" ) ){      /* diagnostic: NAME[,NAME...] defined as 1 in front of the source */
@@ -726,7 +746,7 @@ extern "C" int rkfdBatchSnapshot(rkfdBatch *b)
   if( !b->has_snap ){
     int bad = 0;
     bad |= dalloc( &b->snap.dis, B*ND ); bad |= dalloc( &b->snap.vel, B*ND ); bad |= dalloc( &b->snap.acc, B*ND );
-    bad |= dalloc( &b->snap.piv_type, B*NL ); bad |= dalloc( &b->snap.piv_prev, B*NL );
+    bad |= dalloc( &b->snap.piv_type, B*NL ); bad |= dalloc( &b->snap.piv_prev, B*NL ); bad |= dalloc( &b->snap.brk, B*NL );
     bad |= dalloc( &b->snap.cv_active, B*NC ); bad |= dalloc( &b->snap.cv_type, B*NC );
     bad |= dalloc( &b->snap.cv_ref, B*NC*3 ); bad |= dalloc( &b->snap.cv_f, B*NC*3 );
     if( bad ) return -1;
@@ -735,7 +755,7 @@ extern "C" int rkfdBatchSnapshot(rkfdBatch *b)
   }
 #define SNAPCP(f, n) HIPCHK( hipMemcpy( b->snap.f, b->st.f, (n), hipMemcpyDeviceToDevice ), -1 )
   SNAPCP( dis, sizeof(double)*B*ND ); SNAPCP( vel, sizeof(double)*B*ND ); SNAPCP( acc, sizeof(double)*B*ND );
-  SNAPCP( piv_type, sizeof(int)*B*NL ); SNAPCP( piv_prev, sizeof(double)*B*NL );
+  SNAPCP( piv_type, sizeof(int)*B*NL ); SNAPCP( piv_prev, sizeof(double)*B*NL ); SNAPCP( brk, sizeof(int)*B*NL );
   SNAPCP( cv_active, sizeof(int)*B*NC ); SNAPCP( cv_type, sizeof(int)*B*NC );
   SNAPCP( cv_ref, sizeof(double)*B*NC*3 ); SNAPCP( cv_f, sizeof(double)*B*NC*3 );
 #undef SNAPCP

@@ -34,6 +34,7 @@
 #include "device/rkfd_dev_base.h"
 #include "device/rkfd_dev_kinematics.h"
 #include "device/rkfd_dev_sweeps.h"
+#include "device/rkfd_dev_brf.h"
 #include "device/rkfd_dev_contact.h"
 #include "device/rkfd_dev_vertqp.h"
 #include "device/rkfd_dev_mlcp.h"

@@ -36,10 +36,20 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   if( NC > RKFD_MAX_CAND ) FAIL( "ncand %d exceeds the per-wave limit %d", NC, RKFD_MAX_CAND );
   if( max_rigid < 0 ) max_rigid = 0;
   if( 3*max_rigid > RKFD_MAX_ROWS ) FAIL( "3*max_rigid %d exceeds the per-wave limit %d", 3*max_rigid, RKFD_MAX_ROWS );
+  int has_brf = 0;
   for( int i=0; i<NLm; i++ ){
-    if( m->jtype[i] == RKFD_JOINT_BRFLOAT )
-      FAIL( "link %d has a breakable float joint: read by the loader, but without a device path (DESIGN.md, out of scope)", i );
     if( m->parent[i] >= i ) FAIL( "link %d: parent index must be smaller than the link index", i );
+    if( m->jtype[i] == RKFD_JOINT_BRFLOAT ) has_brf = 1;
+  }
+  if( has_brf ){
+    /* breakable float joints (device/rkfd_dev_brf.h): whatever hangs on one must be attached by breakable float or fixed joints
+     * only - then an unbroken joint carries a RIGID subtree, and the wrench it transmits is that body's momentum balance */
+    for( int i=0; i<NLm; i++ ){
+      if( m->jtype[i] == RKFD_JOINT_BRFLOAT || m->jtype[i] == RKFD_JOINT_FIXED ) continue;
+      for( int a=m->parent[i]; a>=0; a=m->parent[a] )
+        if( m->jtype[a] == RKFD_JOINT_BRFLOAT )
+          FAIL( "link %d hangs below the breakable float joint of link %d on a joint that can move: only breakable float and fixed joints may follow a breakable float joint on the device", i, a );
+    }
   }
 
   /* ---- merge rigidly attached links ------------------------------------------------------
@@ -95,7 +105,7 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
       Acc a; a.m = 0; a.mc[0] = a.mc[1] = a.mc[2] = 0; a.parts.push_back( i );
       accs.push_back( a );
       R_parent.push_back( sph ? r-1 : ( p < 0 ? -1 : rep[p] ) );
-      R_jtype.push_back( sph ? RKFD_DJT_SPHZ : m->jtype[i] ); R_dofoff.push_back( m->dofoff[i] + ( sph ? 2 : 0 ) ); R_mtype.push_back( sph ? RKFD_MOTOR_NONE : m->mtype[i] );
+      R_jtype.push_back( sph ? RKFD_DJT_SPHZ : ( m->jtype[i] == RKFD_JOINT_BRFLOAT ? (int)RKFD_JOINT_FLOAT : m->jtype[i] ) ); R_dofoff.push_back( m->dofoff[i] + ( sph ? 2 : 0 ) ); R_mtype.push_back( sph ? RKFD_MOTOR_NONE : m->mtype[i] );
       if( sph ){
         const double id[12] = { 1,0,0, 0,1,0, 0,0,1, 0,0,0 };
         R_org.insert( R_org.end(), id, id+12 );
@@ -158,6 +168,14 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
     R_mot_gear[r] = m->mot_gear[i];
     /* the device keeps the inertia reflected through the gear (same product order as the oracle's), 0 without a DC motor */
     R_mot_inertia[r] = ( ( m->jtype[i] == RKFD_JOINT_REVOL || m->jtype[i] == RKFD_JOINT_PRISM ) && m->mtype[i] == RKFD_MOTOR_DC ) ? m->mot_inertia[i]*m->mot_gear[i]*m->mot_gear[i] : 0.0;
+  }
+
+  /* breakable float joints of the surviving links */
+  std::vector<int> R_brf( NL, 0 );
+  std::vector<double> R_brk_f( NL, 0.0 ), R_brk_t( NL, 0.0 );
+  for( int r=0; r<NL; r++ ){
+    const int i = orig[r];
+    if( m->jtype[i] == RKFD_JOINT_BRFLOAT && R_jtype[r] == RKFD_JOINT_FLOAT ){ R_brf[r] = 1; R_brk_f[r] = m->brk_f[i]; R_brk_t[r] = m->brk_t[i]; }
   }
 
   /* depth, levels */
@@ -467,7 +485,7 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
       }
       for( int i=0; i<NL; i++ ){
         pslot[i] = -1;
-        if( R_parent[i] >= 0 && R_jtype[i] != RKFD_JOINT_FLOAT && !carried[i] ) pslot[i] = npool++;
+        if( R_parent[i] >= 0 && ( R_jtype[i] != RKFD_JOINT_FLOAT || R_brf[i] ) && !carried[i] ) pslot[i] = npool++;
         fslot[i] = -1;
         if( R_jtype[i] == RKFD_JOINT_FLOAT ) fslot[i] = nfloat++;
       }
@@ -506,6 +524,7 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   dm.solver = m->solver; dm.max_iter = m->max_iter; dm.maxrg = max_rigid;
   dm.dt = m->dt; dm.fric_w = m->friction_weight;
   dm.nsched = nsched; dm.npool = npool; dm.nfloat = nfloat;
+  dm.has_brf = has_brf;
   dm.anchor = -1;
   for( int i=0; i<NL; i++ ) if( !is_static[i] ){ dm.anchor = i; break; }
   /* contact capacities */
@@ -548,7 +567,7 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   /* probe scratch: one row per tree level plus six for a float root, per side; it overlays the
    * C|PA block of the link arrays (dead while the contact problem is solved) when it fits */
   int pu_d0 = nlevel;
-  for( int i=0; i<NL; i++ ) if( RKFD_JT_IS1( R_jtype[i] ) && depth[i] < pu_d0 ) pu_d0 = depth[i];
+  for( int i=0; i<NL; i++ ) if( ( RKFD_JT_IS1( R_jtype[i] ) || R_brf[i] ) && depth[i] < pu_d0 ) pu_d0 = depth[i];      /* (an unbroken breakable float joint is a level a probe path passes) */
   if( pu_d0 == nlevel ) pu_d0 = nlevel > 0 ? nlevel-1 : 0;      /* (no 1-DoF joint at all: one unused row) */
   const int npurow = nlevel - pu_d0 + ( nfloat > 0 ? 6 : 0 );
   dm.npurow = npurow; dm.pu_d0 = pu_d0;
@@ -566,6 +585,7 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   PUT( parent, R_parent.data(), sizeof(int)*NL ); PUT( jtype, R_jtype.data(), sizeof(int)*NL );
   PUT( dofoff, R_dofoff.data(), sizeof(int)*NL ); PUT( mtype, R_mtype.data(), sizeof(int)*NL );
   PUT( orig, orig.data(), sizeof(int)*NL );
+  PUT( brf, R_brf.data(), sizeof(int)*NL ); PUT( brk_f, R_brk_f.data(), sizeof(double)*NL ); PUT( brk_t, R_brk_t.data(), sizeof(double)*NL );
   PUT( dofkind, dofkind.data(), sizeof(int)*( ND ? ND : 1 ) );
   PUT( depth, depth.data(), sizeof(int)*NL ); PUT( is_static, is_static.data(), sizeof(int)*NL );
   PUT( org, R_org.data(), sizeof(double)*12*NL ); PUT( mass, R_mass.data(), sizeof(double)*NL );
@@ -635,7 +655,8 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
     const size_t ints = (size_t)NC + (size_t)nside*maxact + ( vol_np > 0 ? 12 + 2*vol_np : ( NC > 0 ? 8 : 4 ) ) + (size_t)NL     /* CIp, tgt, cnt (VI), LI */
                       + ( RKFD_GC_NEEDED( (int)M ) ? RKFD_GC_INTS : 0 );                                                            /* GC */
     const size_t bytes = (size_t)2*NL + (size_t)5*NC + (size_t)4*maxact + ( dm.vert_rigid ? M : 0 )                                     /* CHP (16 bit), act typ asl (bytes) */
-                       + ( max_rigid > 0 ? (size_t)NL*( nlevel+3 ) : 0 );                /* PL */
+                       + ( max_rigid > 0 ? (size_t)NL*( nlevel+3 ) : 0 )                 /* PL */
+                       + ( has_brf ? (size_t)NL : 0 );                                   /* BRK */
     out->lds_bytes = dbl*sizeof(double) + ints*sizeof(int) + bytes;
     out->lds_bytes = ( out->lds_bytes + 15 ) & ~(size_t)15;
     if( pass == 0 ) lds_full = out->lds_bytes;
@@ -665,7 +686,7 @@ extern "C" void rkfd_devmodel_rebase(rkfdDevModel *dm, const void *from, const v
   RB(parent); RB(jtype); RB(dofoff); RB(mtype); RB(depth); RB(is_static);
   RB(org); RB(mass); RB(com); RB(inertia); RB(stiff); RB(visc); RB(coulomb); RB(sfric);
   RB(mot_k); RB(mot_admit); RB(mot_vmax); RB(mot_vmin); RB(mot_gear); RB(mot_inertia);
-  RB(anc); RB(level_off); RB(level_link); RB(child_off); RB(child_idx); RB(pathlink); RB(linfo); RB(sched); RB(cinfo); RB(pslot); RB(orig); RB(dofkind);
+  RB(anc); RB(level_off); RB(level_link); RB(child_off); RB(child_idx); RB(pathlink); RB(linfo); RB(sched); RB(cinfo); RB(pslot); RB(orig); RB(dofkind); RB(brf); RB(brk_f); RB(brk_t);
   RB(cand_linkA); RB(cand_linkB); RB(cand_foff); RB(cand_nf); RB(cand_ci); RB(cand_vert); RB(cand_bs); RB(cs_mode); RB(cs_par); RB(planes);
   RB(vol_pair); RB(vol_loop); RB(vol_lplane); RB(vol_lvert); RB(vol_slide);
   RB(ci_type); RB(ci_sf); RB(ci_kf); RB(ci_k); RB(ci_l); RB(ci_e); RB(ci_v);

@@ -10,7 +10,7 @@
 #define RKFD_WAVE        64
 #define RKFD_MAX_LINK    64
 #define RKFD_MAX_DOF     64
-#define RKFD_MAX_CAND    1024 /* candidate contact vertices per instance (swept 64 at a time; 9 bytes of LDS each) */
+#define RKFD_MAX_CAND    4096 /* candidate contact vertices per instance (swept 64 at a time; 9 bytes of LDS each) */
 #define RKFD_MAX_ROWS    128  /* 3 * (rigid contact vertices): two MLCP rows per lane at most */
 
 typedef struct {
@@ -40,6 +40,10 @@ typedef struct {
                             bit 3 (RKFD_PGS_GROUPED=0): the grouped Gauss-Seidel of rkfd_dev_mlcp.h switched off (A/B test);
                             bit 5 (RKFD_PGS_SW=0): its sweep-order matrix storage switched off (packed triangle instead; A/B test);
                             measurement switch RKFD_MLCP_MFMA, see DESIGN.md "MFMA") */
+  int has_brf;           /* the world holds breakable float joints (rkfd_dev_brf.h): device links with brf[] != 0 are float joints in the
+                            tables and take the part of a fixed joint in every evaluation in which they are not broken */
+  const int *brf;        /* [nlink] 1: the link hangs on a breakable float joint */
+  const double *brk_f, *brk_t;   /* [nlink] its force / torque thresholds */
   int lds_poison;        /* debugging switch RKFD_DEBUG_POISON_LDS=1: 4-byte words of LDS every instance fills with all ones (NaN / -1) before it
                             starts, so that a read of storage nobody wrote shows in the results whatever ran on the CU before; 0: off */
   /* Volume plugin (solver == RKFD_SOLVER_VOLUME and rigid pairs exist; device/rkfd_dev_volume.h) */
@@ -142,6 +146,7 @@ typedef struct {
   double *piv_prev;              /* [B][nlink]  */
   int    *cv_active, *cv_type;   /* [B][ncand]  */
   double *cv_ref, *cv_f;         /* [B][ncand*3]*/
+  int    *brk;                   /* [B][nlink]  breakable float joints: 1 once broken (state) */
   unsigned int *stat;            /* optional [B][4] running sums over the committing evaluations of rkFDUpdate steps:
                                     rigid contact vertices, elastic contact vertices, steps, unused; may be NULL */
   unsigned long long *prof;      /* optional [B][8] phase cycle counters, may be NULL */

@@ -343,6 +343,32 @@ def arm_fold(batch=8, seed=0x5EED00E1, solver=B.SOLVER_MLCP, unreg=False):
     return dict(name="arm_fold" + ("_unreg" if unreg else ""), world=w, dis=dis, vel=vel, motor_in=inp, max_rigid=8, steps=200)
 
 
+def wall_hit(batch=4, seed=0x5EED00F1, solver=B.SOLVER_MLCP, speed=1.0):
+    """TEST scenario (BREAKABLE FLOAT JOINTS): models/wall.ztk - the structure and thresholds of the reference's wall.ztk: a base
+    fixed to the world and three bricks, each on a breakable float joint (200 N / N m, then 10 and 10) - and a free box flying
+    at the column's upper bricks: the rigid contact forces of the impact pass the thresholds, the joints break in the order the
+    forces dictate, the bricks come loose, tumble, and collide with each other (cells of ONE chain: the wall's own pairs stay
+    registered, as in reference example/chain/arm_wall_test.c, which makes no rkCDPairChainUnreg call for the wall)."""
+    w = B.World(solver=solver)
+    w.contact_info(_m("contactinfo.ztk"))
+    wl = w.reg_file(_m("wall.ztk"))
+    bx = w.reg_file(_m("box.ztk"))
+    w.reg_file(_m("floor.ztk"))
+    m = w.model.contents
+    u = splitmix64_uniform(seed, batch * 6).reshape(batch, 6)
+    dis = np.zeros((batch, m.ndof)); vel = np.zeros((batch, m.ndof))
+    o = w.dof_offset(bx)
+    dis[:, o + 0] = -0.0997                                  # 0.2 mm in front of the bricks' face at x = -0.0495
+    dis[:, o + 1] = 0.55 + 0.01 * (u[:, 0] - 0.5)
+    dis[:, o + 2] = 0.22 + 0.16 * u[:, 1]                    # at the height of the second / third brick
+    dis[:, o + 5] = 0.1 * (u[:, 2] - 0.5)
+    # slow enough that the joints break one after the other (the 200 N joint of the first brick holds below ~0.5 m/s): a brick
+    # still attached to one that has come loose moves with it, and the forces on it load the joints further down
+    vel[:, o + 0] = speed * (0.05 + 0.35 * u[:, 3])
+    vel[:, o + 2] = 0.1 * (u[:, 4] - 0.5)
+    return dict(name="wall_hit", world=w, dis=dis, vel=vel, max_rigid=6 if solver == B.SOLVER_VOLUME else 16, steps=200)
+
+
 def config3_26(batch=4096, first=0):
     """config 3 on the 26-DoF model with mighty.ztk's own topology (reported alongside)"""
     d = config3(batch, model="humanoid26.ztk", first=first); d["name"] = "config3_humanoid26_penalty"; return d

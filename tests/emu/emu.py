@@ -15,7 +15,7 @@ _lib = None
 class DevState(C.Structure):
     _fields_ = [("dis", C.c_void_p), ("vel", C.c_void_p), ("acc", C.c_void_p), ("motor_in", C.c_void_p),
                 ("piv_type", C.c_void_p), ("piv_prev", C.c_void_p), ("cv_active", C.c_void_p), ("cv_type", C.c_void_p),
-                ("cv_ref", C.c_void_p), ("cv_f", C.c_void_p), ("stat", C.c_void_p), ("prof", C.c_void_p), ("dbg", C.c_void_p), ("dbg_stride", C.c_int), ("batch", C.c_int)]
+                ("cv_ref", C.c_void_p), ("cv_f", C.c_void_p), ("brk", C.c_void_p), ("stat", C.c_void_p), ("prof", C.c_void_p), ("dbg", C.c_void_p), ("dbg_stride", C.c_int), ("batch", C.c_int)]
 
 
 def lib():
@@ -43,12 +43,13 @@ class EmuBatch:
         self.piv_type = np.zeros((B, self.nlink), dtype=np.int32); self.piv_prev = np.zeros((B, self.nlink))
         self.cv_active = np.zeros((B, max(self.ncand, 1)), dtype=np.int32); self.cv_type = np.zeros_like(self.cv_active)
         self.cv_ref = np.zeros((B, max(self.ncand, 1), 3)); self.cv_f = np.zeros_like(self.cv_ref)
+        self.brk = np.zeros((B, self.nlink), dtype=np.int32)
         self.dbg = np.zeros((B, 18 * self.nlink))
         self.err = 0
 
     def _run(self, mode, nsteps):
         st = DevState()
-        for k in ("dis", "vel", "acc", "motor_in", "piv_type", "piv_prev", "cv_active", "cv_type", "cv_ref", "cv_f", "dbg"):
+        for k in ("dis", "vel", "acc", "motor_in", "piv_type", "piv_prev", "cv_active", "cv_type", "cv_ref", "cv_f", "brk", "dbg"):
             setattr(st, k, getattr(self, k).ctypes.data)
         st.dbg_stride = 18 * self.nlink
         st.batch = self.B
@@ -81,6 +82,12 @@ class EmuBatch:
 
     def get_pivot(self):
         return self.piv_type.copy(), self.piv_prev.copy()
+
+    def get_broken(self):
+        return self.brk.copy()
+
+    def set_broken(self, broken):
+        self.brk[...] = np.asarray(broken).reshape(self.B, self.nlink)
 
     def update_init(self):
         self._run(1, 0)

@@ -419,3 +419,47 @@ def test_emulated_self_collision_matches_oracle(R, oracle_cls, solver):
     assert o.get_contact()[0].sum() == 0
     o.update_n(2)
     assert o.get_contact()[0].sum() == 0
+
+
+def test_emulated_breakable_float_joints(R, oracle_cls):
+    """BREAKABLE FLOAT JOINTS on the device (device/rkfd_dev_brf.h) against the oracle's restatement: the wall of the reference's
+    wall.ztk (three bricks, thresholds 200 / 10 / 10) hit by a slow box - rigid contact forces pass the thresholds, the joints
+    break one after the other (a brick still attached to one that came loose moves with it), the loose bricks touch their
+    neighbours (cells of one chain); and the cantilever whose bending moment alone breaks its first joint at rkFDUpdateInit.
+    Broken flags identical at every step, states to 1e-9."""
+    import os
+    M = R.scenarios.MODELS
+    w = R.World(solver=R.SOLVER_MLCP); w.contact_info(os.path.join(M, "contactinfo.ztk"))
+    w.reg_file(os.path.join(M, "wall_cantilever.ztk")); w.reg_file(os.path.join(M, "floor.ztk"))
+    n = w.model.contents.ndof
+    eb = EmuBatch(w, 1, max_rigid=8); eb.set_state(np.zeros((1, n)), np.zeros((1, n))); eb.update_init()
+    o = oracle_cls(w.model); o.set_state(np.zeros(n), np.zeros(n)); o.update_init()
+    assert eb.get_broken()[0].tolist() == o.get_broken().tolist() == [0, 1, 0, 0]
+    eb.update(3); o.update_n(3)
+    assert np.abs(eb.get_state()[2][0] - o.get_state()[2]).max() < 1e-12 and abs(o.get_state()[2][2] + 9.80665) < 1e-12
+
+    B, nsteps = 2, 18
+    sc = R.scenarios.wall_hit(batch=10)
+    pick = [2, 9]                 # two instances whose joints break in stages: the second brick's at once, the third's 14 / 2 steps later
+    sc["dis"] = sc["dis"][pick]; sc["vel"] = sc["vel"][pick]
+    eb = EmuBatch(sc["world"], B, max_rigid=sc["max_rigid"])
+    eb.set_state(sc["dis"], sc["vel"]); eb.update_init()
+    os_ = []
+    for i in range(B):
+        o = oracle_cls(sc["world"].model); o.set_state(sc["dis"][i], sc["vel"][i]); o.update_init(); os_.append(o)
+    assert eb.get_broken().tolist() == [o.get_broken().tolist() for o in os_]
+    events = 0; last = [o.get_broken().tolist() for o in os_]
+    for k in range(nsteps):
+        eb.update(1)
+        assert eb.status() == 0
+        dis, vel, acc = eb.get_state(); act, typ, ref, f = eb.get_contact(); br = eb.get_broken()
+        for i, o in enumerate(os_):
+            o.update()
+            od, ov, oa = o.get_state(); oact, otyp, oref, of = o.get_contact()
+            assert br[i].tolist() == o.get_broken().tolist(), (k, i)
+            events += int(last[i] != br[i].tolist()); last[i] = br[i].tolist()
+            for x, y in ((dis[i], od), (vel[i], ov), (acc[i], oa)):
+                assert np.abs(x - y).max() / max(1.0, np.abs(y).max()) < 1e-9, (k, i)
+            assert (act[i] == oact).all()
+            assert np.abs(f[i] - of).max() / max(1.0, np.abs(of).max()) < 1e-9
+    assert events >= 2 and all(sum(l) == 2 for l in last)          # the third brick's joint broke DURING the run, the first brick's held

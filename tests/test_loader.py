@@ -167,8 +167,7 @@ def test_reference_drivers_compile_and_link_unmodified(R, tmp_path):
 def test_reader_loads_the_reference_shipped_models(R):
     """the independent ZTK reader against the reference's own example models (read as data): all 12 load - curved
     primitives (sphere / cylinder / cone) as convex polyhedra, `COM: auto` / `inertia: auto` from the shapes,
-    spherical (3 DoF) and breakable-float (6 DoF) joints with their sizes.  A world with a breakable-float joint is
-    refused by the device path with a message, not mis-simulated."""
+    spherical (3 DoF) and breakable-float (6 DoF) joints with their sizes and thresholds."""
     expect = {"arm_2DoF.ztk": (3, 2), "arm_2DoF_trq.ztk": (3, 2), "box.ztk": (1, 6), "box_small.ztk": (1, 6), "crawler.ztk": (3, 6),
               "floor.ztk": (1, 0), "floor_hardsoft.ztk": (2, 0), "mighty.ztk": (25, 26), "puma.ztk": (7, 6),
               "arm.ztk": (6, 12), "dualarm.ztk": None, "wall.ztk": None}
@@ -200,9 +199,10 @@ def test_reader_loads_the_reference_shipped_models(R):
     for f in ("arm.ztk", "dualarm.ztk"):
         w = R.World(); w.pair_chain_unreg(w.reg_file(os.path.join(REF_MODELS, f)))      # (own pairs off, as the reference's arm drivers do)
         assert R.lib().rkfdLdsBytesFor(w.model, 0) > 0, R.lib().rkfdHipLastError()
-    w = R.World(); w.reg_file(os.path.join(REF_MODELS, "wall.ztk"))
-    assert R.lib().rkfdLdsBytesFor(w.model, 0) < 0
-    assert b"breakable float" in R.lib().rkfdHipLastError()
+    # wall.ztk: three bricks on breakable float joints - round 3: read, carried by the model (thresholds), run by device and oracle
+    w = R.World(); w.reg_file(os.path.join(REF_MODELS, "wall.ztk")); m = w.model.contents
+    assert (m.arr("jtype", m.nlink) == [0, 5, 5, 5]).all() and m.arr("brk_f", m.nlink).tolist() == [0.0, 200.0, 10.0, 10.0]
+    assert R.lib().rkfdLdsBytesFor(w.model, 8) > 0, R.lib().rkfdHipLastError()
 
 
 def test_auto_mass_properties_of_a_box(R, tmp_path):
@@ -286,3 +286,39 @@ def test_specialisation_survives_the_host_changing_its_environment():
         "print('done')\n")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("done"), r.stdout + r.stderr
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_MODELS), reason="reference checkout not present (it never is on the GPU box)")
+def test_the_worlds_of_the_reference_drivers_build_device_tables(R):
+    """the worlds the reference's five example drivers set up (example/chain/*_test.c: the models read where they lie, registered
+    in the drivers' order, rkCDPairChainUnreg where the driver calls it, the plugin the driver selects): the host-side device tables
+    build for all five under MLCP / Vert; under the Volume plugin, which the drivers select, for four - arm_wall_test.c keeps the
+    arm's own pairs (no unreg call), among them motor cylinder against motor cylinder: 34 + 34 faces, and the Volume kernel takes
+    one lane per face of a pair (64), so that world is refused there with that message.  Its breakable float joints (wall.ztk) are
+    not the obstacle any more."""
+    L = R.lib()
+    M = REF_MODELS
+
+    def world(solver, chains, unreg):
+        w = R.World(solver=solver); w.contact_info(os.path.join(M, "contactinfo.ztk"))
+        ids = [w.reg_file(os.path.join(M, c)) for c in chains]
+        for k in unreg:
+            w.pair_chain_unreg(ids[k])
+        return w
+    drivers = {
+        "boxdrop_test": (["box.ztk"] * 3 + ["floor.ztk"], [0, 1, 2], 8),
+        "boxdrop_hardsoft_test": (["box.ztk"] * 3 + ["floor_hardsoft.ztk"], [0, 1, 2], 8),
+        "arm_box_test": (["arm_2DoF.ztk", "box.ztk", "floor.ztk"], [0], 6),
+        "arm_box_trq_test": (["arm_2DoF_trq.ztk", "box.ztk", "floor.ztk"], [0], 6),
+        "arm_wall_test": (["arm_2DoF.ztk", "wall.ztk", "floor.ztk"], [], 10),
+    }
+    for name, (chains, unreg, cap) in drivers.items():
+        for solver in (R.SOLVER_MLCP, R.SOLVER_VERT):
+            w = world(solver, chains, unreg)
+            assert L.rkfdLdsBytesFor(w.model, 4 if solver == R.SOLVER_VERT else 24) > 0, (name, solver, L.rkfdHipLastError())
+        w = world(R.SOLVER_VOLUME, chains, unreg)
+        n = L.rkfdLdsBytesFor(w.model, cap)
+        if name == "arm_wall_test":
+            assert n < 0 and b"68 faces" in L.rkfdHipLastError(), L.rkfdHipLastError()
+        else:
+            assert n > 0, (name, L.rkfdHipLastError())
