@@ -16,7 +16,7 @@ HIPFLAGS = --offload-arch=$(ARCH) -O3 -fPIC $(INC) -Wno-unused-value -mllvm -dis
 HOST_OBJS = $(BUILD)/rkfd_ztk.o $(BUILD)/rkfd_world.o $(BUILD)/rkfd_sim.o $(BUILD)/rkfd_devmodel.o
 LIB = $(PKG)/librkfd_amd.so
 
-all: $(LIB) oracle emu
+all: $(LIB) oracle emu spec
 
 $(BUILD):
 	mkdir -p $(BUILD)
@@ -45,13 +45,18 @@ $(LIB): $(HOST_OBJS) $(BUILD)/rkfd_capi.o
 oracle:
 	$(MAKE) -C oracle
 
+# ahead-of-time specialised kernels: the code objects of the worlds of BASELINE.json's configurations, made now (hipRTC works
+# without a GPU) and only LOADED at run time (rkfd_capi.hip: the store under $(PKG)/spec)
+spec: $(LIB)
+	python3 tools/make_spec.py
+
 emu: tests/emu/librkfd_emu.so
 
 tests/emu/librkfd_emu.so: tests/emu/rkfd_emu.cpp $(CSRC)/rkfd_device.h $(CSRC)/rkfd_devmodel.cpp $(CSRC)/*.h $(CSRC)/device/*.h include/*.h
 	$(CXX) -std=c++20 -O2 -Wall -Wno-unknown-pragmas -fPIC -shared -pthread $(INC) -o $@ tests/emu/rkfd_emu.cpp $(CSRC)/rkfd_devmodel.cpp
 
 clean:
-	rm -rf $(BUILD) $(LIB) tests/emu/librkfd_emu.so
+	rm -rf $(BUILD) $(LIB) $(PKG)/spec tests/emu/librkfd_emu.so
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle emu clean
+.PHONY: all oracle emu spec clean

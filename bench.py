@@ -237,11 +237,12 @@ def main():
     assert hi - lo == Bn
     sc = R.scenarios.CONFIGS[args.workload](batch=Bn, first=lo)      # this rank's shard only (the seeded stream is index-addressable)
     b = R.Batch(sc["world"], Bn, device=local, max_rigid=sc["max_rigid"])
-    specialized = False
+    specialized = False; aot = False
     if not args.no_specialize and b.lds_bytes <= 64 * 1024:
         try:
             b.specialize()
             specialized = True
+            aot = bool(R.lib().rkfdSpecializeLastFromStore())
         except R.RkfdError as e:              # an optimisation, not a correctness path: say so and keep the generic kernel
             print("bench.py: %s" % e, file=sys.stderr)
     b.set_state(sc["dis"], sc["vel"])
@@ -376,7 +377,7 @@ def main():
                        "rollout_horizon": H, "timed_steps": timed_steps, "blocks": reps,
                        "mean_rigid_contacts": mean_rg if has_contacts else 0.0, "mean_elastic_contacts": mean_el if has_contacts else 0.0,
                        "parallelism": f"instances sharded over {world} GPU(s), no data-path collective; {args.split} launches per step on internal streams",
-                       "step_kernel": "compiled for this world (rkfdBatchSpecialize)" if specialized else "generic"},
+                       "step_kernel": ("compiled for this world ahead of time (make spec), loaded from roki-fd_amd/spec" if aot else "compiled for this world at run time (hipRTC)") if specialized else "generic"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "kernel": "rkfd_step_kernel_spec" if specialized else "rkfd_step_kernel", "kernel_ms": kernel_ms,

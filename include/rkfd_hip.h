@@ -90,6 +90,15 @@ int rkfdBatchSetSplit(rkfdBatch *b, int nsplit);
  * of code object, or -1. */
 int rkfdBatchSpecialize(rkfdBatch *b);
 int rkfdSpecializeCompile(const rkfdModel *m, int max_rigid);
+/* Ahead-of-time kernels: a specialised kernel is a function of the world's dimensions and the device sources only, so its code
+ * object is kept in a directory beside the library (`spec/`; RKFD_SPEC_DIR overrides, RKFD_SPEC_STORE=0 switches the store off),
+ * keyed by a hash of everything that goes into it.  `make spec` fills it for the worlds of BASELINE.json's configurations at
+ * build time, so that those need no run-time compiler at all; other worlds are compiled on first use and kept.  1 when the
+ * last rkfdBatchSpecialize / rkfdSpecializeCompile was served from the store, else 0 (measurement / test aid). */
+int rkfdSpecializeLastFromStore(void);
+/* test aid: XOR mask over the kernel variants of the batches created AFTER the call (4: the Vert QP's Q = A'A off the matrix
+ * cores, 8: grouped Gauss-Seidel off, 32: its sweep-order storage off); returns the previous mask.  0 = the product's defaults. */
+int rkfdDebugVariants(int mask);
 int rkfdBatchJoin(rkfdBatch *b, void *stream);
 /* measurement aid: with on = 1 every launch is bracketed by HIP events on the stream it runs on;
  * rkfdBatchLaunchTiming synchronises the device and returns their number and summed duration */

@@ -540,74 +540,12 @@ for( int it=0; it<max_iter; it++ ){
   }
 }
 
-#ifndef RKFD_EMU
-/* The contact-space matrix as a Gram product on the matrix cores (the "MFMA ... for the dense J M^-1 J' GEMM" of the north
- * star; measurement variant, see DESIGN.md "MFMA").  In innovations form A = N'N, where column k of N holds the scaled
- * innovations probe k leaves at the joints of its path.  The probe scratch PU is indexed by tree LEVEL, and two probes
- * share a level without sharing the joint (the two legs), so the K dimension of the product is the JOINT: row j of the
- * expanded panel N' is PU[depth(j)] where joint j lies on the probe's path and 0 elsewhere, then six rows per float
- * joint.  N' is never stored: each lane builds its operand element for a k-step of four joints on the fly
- * (v_mfma_f64_16x16x4_f64: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15], one double per lane each;
- * C/D col = lane & 15, row = ( lane >> 4 ) + 4 reg).  Up to 32 rows: tiles (0,0), (0,1), (1,1), the fourth by symmetry. */
-typedef double rkfd_d4 __attribute__((ext_vector_type(4)));
-RKFD_DEV void rkfd_mlcp_matrix_mfma(const rkfdDevModel &m, const rkfdLds &L, int nc, int ld, bool vert)
-{
-  const int lane = LANE();
-  const int M = 3*nc, NLV = m.nlevel, NL = m.nlink, NSD = m.nside;
-  const unsigned char *TOP = L.PL + NL*NLV, *FSL = TOP + NL;
-  const int kk = lane >> 4, cc = lane & 15;
-  const int col0 = cc, col1 = 16 + cc;
-  unsigned e00 = 0, e01 = 0, e10 = 0, e11 = 0;      /* [column block][side] */
-  if( col0 < M ){ e00 = (unsigned)L.tgt[( col0/3 )*NSD]; if( NSD > 1 ) e01 = (unsigned)L.tgt[( col0/3 )*NSD+1]; }
-  if( col1 < M ){ e10 = (unsigned)L.tgt[( col1/3 )*NSD]; if( NSD > 1 ) e11 = (unsigned)L.tgt[( col1/3 )*NSD+1]; }
-  rkfd_d4 c00 = { 0, 0, 0, 0 }, c01 = { 0, 0, 0, 0 }, c11 = { 0, 0, 0, 0 };
-  /* element of N' for (joint j at depth d, column col) from one side's packed path record */
-#define RKFD_NP_ELEM(e, s, col) ( ( RKFD_CS_VALID( e ) && d >= RKFD_CS_D0( e ) && d <= RKFD_CS_DEPTH( e ) && L.PL[RKFD_CS_LINK( e )*NLV+d] == j ) ? L.PU[RKFD_PU_AT( m, s, col, d )] : 0.0 )
-  for( int j0=0; j0<NL; j0+=4 ){
-    const int j = j0 + kk;
-    const int lij = j < NL ? L.LI[j] : 0, jt = RKFD_LI_JT( lij ), d = RKFD_LI_DEPTH( lij );
-    double a0 = 0, a1 = 0;
-    if( j < NL && RKFD_JT_IS1( jt ) ){
-      a0 = RKFD_NP_ELEM( e00, 0, col0 ) + RKFD_NP_ELEM( e01, 1, col0 );
-      a1 = RKFD_NP_ELEM( e10, 0, col1 ) + RKFD_NP_ELEM( e11, 1, col1 );
-    }
-    c00 = __builtin_amdgcn_mfma_f64_16x16x4f64( a0, a0, c00, 0, 0, 0 );
-    c01 = __builtin_amdgcn_mfma_f64_16x16x4f64( a0, a1, c01, 0, 0, 0 );
-    if( M > 16 ) c11 = __builtin_amdgcn_mfma_f64_16x16x4f64( a1, a1, c11, 0, 0, 0 );
-  }
-#undef RKFD_NP_ELEM
-#define RKFD_NP_FLT(e, s, col) ( ( RKFD_CS_VALID( e ) && RKFD_CS_FLOAT( e ) && FSL[RKFD_CS_TOP( e )] == f ) ? L.PU[RKFD_PU_AT( m, s, col, NLV+q )] : 0.0 )
-  for( int f=0; f<m.nfloat; f++ )
-    for( int q0=0; q0<8; q0+=4 ){
-      const int q = q0 + kk;
-      double a0 = 0, a1 = 0;
-      if( q < 6 ){
-        a0 = RKFD_NP_FLT( e00, 0, col0 ) + RKFD_NP_FLT( e01, 1, col0 );
-        a1 = RKFD_NP_FLT( e10, 0, col1 ) + RKFD_NP_FLT( e11, 1, col1 );
-      }
-      c00 = __builtin_amdgcn_mfma_f64_16x16x4f64( a0, a0, c00, 0, 0, 0 );
-      c01 = __builtin_amdgcn_mfma_f64_16x16x4f64( a0, a1, c01, 0, 0, 0 );
-      if( M > 16 ) c11 = __builtin_amdgcn_mfma_f64_16x16x4f64( a1, a1, c11, 0, 0, 0 );
-    }
-#undef RKFD_NP_FLT
-  /* store: lane holds rows kk + 4 reg of column cc of each tile; relaxation on the diagonal (MLCP plugin) */
-#pragma unroll
-  for( int rg=0; rg<4; rg++ ){
-    const int r = kk + 4*rg;
-    if( r < M && cc < M ){
-      double v = c00[rg];
-      if( r == cc && !vert ) v += m.ci_l[RKFD_CI_CI( L.CIp[L.lrg[r/3]] )];
-      L.MA[r*ld + cc] = v;
-    }
-    if( r < M && col1 < M ){ L.MA[r*ld + col1] = c01[rg]; L.MA[col1*ld + r] = c01[rg]; }
-    if( 16+r < M && col1 < M ){
-      double v = c11[rg];
-      if( 16+r == col1 && !vert ) v += m.ci_l[RKFD_CI_CI( L.CIp[L.lrg[col1/3]] )];
-      L.MA[( 16+r )*ld + col1] = v;
-    }
-  }
-}
-#endif
+/* (The contact-space matrix was also built as a Gram product A = N'N on the matrix cores - v_mfma_f64_16x16x4_f64, K = the joints -
+ * in round 2, measured against the block loops below, and found slower: 25.1 k -> 61.1 k cycles per instance-step on config 4, the
+ * padded 32 x 32 x 31 product does 37 k FMAs where 2.9 k are useful and building the masked operands costs as many VALU
+ * instructions as the loops it replaces (profiles/r02_mfma_ab.txt, r02_mfma_counters.json).  The variant was removed in round 3 -
+ * dead code in the product; git history keeps it: rkfd_mlcp_matrix_mfma.  The matrix cores do serve the Vert plugin's Q = A'A,
+ * rkfd_dev_vertqp.h.) */
 
 /* ------------------------------------------------------------------------ */
 /* MLCP rigid branch (reference src/rkfd_mlcp.c:287-297).  Preconditions: sweep 2 and sweep 3
@@ -787,10 +725,6 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
   const int gf0 = gfills & 255, gf1 = ( gfills >> 8 ) & 255, gf2 = ( gfills >> 16 ) & 255, gf3 = ( gfills >> 24 ) & 255;
   const int gb1 = ( gf0*( gf0+1 ) ) >> 1, gb2 = gb1 + ( ( gf1*( gf1+1 ) ) >> 1 ), gb3 = gb2 + ( ( gf2*( gf2+1 ) ) >> 1 ), gb4 = gb3 + ( ( gf3*( gf3+1 ) ) >> 1 );
   const int nblk = gfills >= 0 ? gb4 : ( pk ? ( nc*( nc+1 ) >> 1 ) : nc*nc );
-#ifndef RKFD_EMU
-  if( !pk && ( m.mlcp_mfma & 1 ) && M <= 32 ) rkfd_mlcp_matrix_mfma( m, L, nc, ld, vert );
-  else
-#endif
   {
   if( sw ){
     for( int i=lane; i<9*RKFD_SW_SLOTS*gmaxlen; i+=RKFD_WAVE ) L.MA[i] = 0.0;

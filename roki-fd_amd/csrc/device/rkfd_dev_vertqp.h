@@ -255,10 +255,8 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
     }
     SYNC();
     double *S = L.MA;
-#ifndef RKFD_EMU
-    if( ( m.mlcp_mfma & 2 ) && r <= 32 ) rkfd_vert_s_mfma( W, ldq, n, r, S, ld );
-    else
-#endif
+    /* (on the matrix cores this product gained nothing: 262 k -> 271 k cycles per step, profiles/r02_vert_mfma_ab.txt - with 2 .. 16
+     * of 24 rows active it is a few passes of latency either way; the switch was removed in round 3) */
     for( int t0=0; t0<( r*( r+1 ) >> 1 ); t0+=RKFD_WAVE ){
       /* lane = entry ( a, b <= a ) of the lower triangle, counted row by row: every lane of a pass has work */
       const int t = t0 + lane;

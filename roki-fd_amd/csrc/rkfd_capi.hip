@@ -8,6 +8,7 @@
 #include <link.h>
 #include <pthread.h>
 #include <unistd.h>
+#include <sys/stat.h>
 #include <string>
 #include <vector>
 #include <stdio.h>
@@ -525,12 +526,81 @@ static const rkfdRtc *rtc_api(void)
   pthread_mutex_unlock( &mu );
   return s == 1 ? &api : NULL;
 }
-/* compile for gfx950 from the sources the library carries (rkfd_device_src.inc): nothing is read from disk */
+/* ---- ahead-of-time specialised kernels ---------------------------------------------------------------------
+ * The world-specific kernel is a pure function of (the generated preamble, the device sources the library carries, the compiler
+ * options): its code object can be made when the library is built and merely LOADED at run time.  `make spec` does that for the
+ * worlds of BASELINE.json's configurations (tools/make_spec.py -> roki-fd_amd/spec/rkfd_spec_<key>.co, beside the library), so the
+ * headline needs no run-time compiler; any other world is compiled through hipRTC on first use and - when the directory is
+ * writable - kept there too.  The key is a 64-bit FNV-1a hash over preamble, sources and options: a stale file cannot be picked
+ * up after the device code changed.  RKFD_SPEC_DIR names another directory; RKFD_SPEC_STORE=0 switches the store off. */
+static unsigned long long spec_key(const std::string &src, const char *const *opts, int nopts)
+{
+  unsigned long long h = 1469598103934665603ull;
+  auto eat = [&h](const char *p){ for( ; *p; p++ ){ h ^= (unsigned char)*p; h *= 1099511628211ull; } h ^= 0xffu; h *= 1099511628211ull; };
+  eat( src.c_str() );
+  for( int i=0; i<rkfd_src_count; i++ ){ eat( rkfd_src_name[i] ); eat( rkfd_src_text[i] ); }
+  for( int i=0; i<nopts; i++ ) eat( opts[i] );
+  return h;
+}
+static std::string spec_dir(void)
+{
+  if( const char *e = getenv( "RKFD_SPEC_DIR" ) ) return e;
+  Dl_info di;
+  if( dladdr( (const void *)&spec_key, &di ) && di.dli_fname ){
+    std::string p( di.dli_fname );
+    const size_t k = p.rfind( '/' );
+    return ( k == std::string::npos ? std::string( "." ) : p.substr( 0, k ) ) + "/spec";
+  }
+  return "spec";
+}
+static bool spec_store_on(void){ const char *e = getenv( "RKFD_SPEC_STORE" ); return !( e && atoi( e ) == 0 ); }
+static std::string spec_path(unsigned long long key)
+{
+  char nm[64];
+  snprintf( nm, sizeof(nm), "/rkfd_spec_%016llx.co", key );
+  return spec_dir() + nm;
+}
+static int spec_from_store(unsigned long long key, std::vector<char> &code)
+{
+  if( !spec_store_on() ) return -1;
+  FILE *f = fopen( spec_path( key ).c_str(), "rb" );
+  if( !f ) return -1;
+  fseek( f, 0, SEEK_END ); const long n = ftell( f ); fseek( f, 0, SEEK_SET );
+  int r = -1;
+  if( n > 0 ){ code.resize( (size_t)n ); if( fread( code.data(), 1, (size_t)n, f ) == (size_t)n ) r = 0; }
+  fclose( f );
+  if( r == 0 && getenv( "RKFD_SPEC_DEBUG" ) ) fprintf( stderr, "rkfd: specialised kernel loaded from %s (no run-time compile)\n", spec_path( key ).c_str() );
+  return r;
+}
+static void spec_to_store(unsigned long long key, const std::vector<char> &code)
+{
+  if( !spec_store_on() ) return;
+  const std::string dir = spec_dir(), path = spec_path( key ), tmp = path + ".tmp";
+  (void)mkdir( dir.c_str(), 0777 );
+  FILE *f = fopen( tmp.c_str(), "wb" );
+  if( !f ) return;                                  /* (a read-only installation: compile every time) */
+  const bool ok = fwrite( code.data(), 1, code.size(), f ) == code.size();
+  fclose( f );
+  if( ok ) (void)rename( tmp.c_str(), path.c_str() ); else (void)remove( tmp.c_str() );
+}
+static int g_spec_last_from_store = 0;      /* diagnostic: did the last spec_compile of this thread's process hit the store */
+extern "C" int rkfdSpecializeLastFromStore(void){ return g_spec_last_from_store; }
+
+/* compile for gfx950 from the sources the library carries (rkfd_device_src.inc): nothing is read from disk but the store above */
 static int spec_compile(const rkfdDevModel &d, std::vector<char> &code)
 {
+  const std::string src = spec_source( d );
+  const char *opts[] = { "--offload-arch=gfx950", "-O3", "-Wno-unused-value", "-mllvm", "-disable-machine-licm" };
+  const int nopts = (int)( sizeof(opts)/sizeof(opts[0]) );
+  const unsigned long long key = spec_key( src, opts, nopts );
+  g_spec_last_from_store = 0;
+  if( !getenv( "RKFD_SPEC_DUMP" ) && spec_from_store( key, code ) == 0 ){
+    g_spec_last_from_store = 1;
+    if( const char *dump = getenv( "RKFD_SPEC_DUMP_CODE" ) ){ FILE *f = fopen( dump, "wb" ); if( f ){ fwrite( code.data(), 1, code.size(), f ); fclose( f ); } }
+    return 0;
+  }
   const rkfdRtc *rtc = rtc_api();
   if( !rtc ) return -1;
-  const std::string src = spec_source( d );
   /* one compile at a time: the environment snapshot below is per namespace, not per call */
   static pthread_mutex_t cmu = PTHREAD_MUTEX_INITIALIZER;
   struct Unlock { pthread_mutex_t *m; ~Unlock(){ pthread_mutex_unlock( m ); } } unlock = { &cmu };
@@ -561,10 +631,9 @@ static int spec_compile(const rkfdDevModel &d, std::vector<char> &code)
     }
   }
   if( const char *dump = getenv( "RKFD_SPEC_DUMP" ) ){ FILE *f = fopen( dump, "w" ); if( f ){ fputs( src.c_str(), f ); fclose( f ); } }   /* diagnostic */
-  const char *opts[] = { "--offload-arch=gfx950", "-O3", "-Wno-unused-value", "-mllvm", "-disable-machine-licm" };
   hiprtcProgram prog;
   if( rtc->create( &prog, src.c_str(), "rkfd_step_kernel_spec.hip", rkfd_src_count, (const char **)rkfd_src_text, (const char **)rkfd_src_name ) != HIPRTC_SUCCESS ){ SETERR( "hiprtcCreateProgram failed" ); return -1; }
-  const hiprtcResult r = rtc->compile( prog, (int)( sizeof(opts)/sizeof(opts[0]) ), opts );
+  const hiprtcResult r = rtc->compile( prog, nopts, opts );
   if( r != HIPRTC_SUCCESS ){
     size_t n = 0; rtc->logsize( prog, &n );
     std::string log( n ? n : 1, ' ' ); if( n ) rtc->log( prog, &log[0] );
@@ -576,6 +645,7 @@ static int spec_compile(const rkfdDevModel &d, std::vector<char> &code)
   rtc->codesize( prog, &n ); code.resize( n ); rtc->code( prog, code.data() );
   if( const char *dump = getenv( "RKFD_SPEC_DUMP_CODE" ) ){ FILE *f = fopen( dump, "wb" ); if( f ){ fwrite( code.data(), 1, n, f ); fclose( f ); } }   /* diagnostic */
   rtc->destroy( &prog );
+  if( rtc->priv ) spec_to_store( key, code );      /* (only what the compiler this library was built with produced: the private namespace) */
   return 0;
 }
 extern "C" int rkfdSpecializeCompile(const rkfdModel *m, int max_rigid)

@@ -13,6 +13,10 @@
 #include "rkfd_devmodel.h"
 #include "rkfd_devmodel_host.h"
 
+/* test switch, process-wide, applied to the batches created after the call: XORed into the variant mask (see below) */
+static int g_debug_variants = 0;
+extern "C" int rkfdDebugVariants(int mask){ const int old = g_debug_variants; g_debug_variants = mask & ( 4 | 8 | 32 ); return old; }
+
 namespace {
 struct Blob {
   std::vector<char> buf;
@@ -553,16 +557,10 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   dm.vol_npair = vol_np > 0 ? vol_npair : 0; dm.vol_np = vol_np; dm.vol_ncp = vol_ncp; dm.vol_pv = vol_pv; dm.vol_nf = vol_nf;
   if( vol_np > 0 ){ dm.vert_rigid = 0; dm.qscr_alias = 0; dm.ma_packed = 0; dm.ma_size = 6*vol_np*( 6*vol_np+1 ); }
   dm.maxact = maxact; dm.nside = nside;
-  { const char *e = getenv( "RKFD_MLCP_MFMA" ); dm.mlcp_mfma = ( e && atoi( e ) > 0 && 3*max_rigid <= 32 ) ? 1 : 0; }
-  /* the Vert QP's Gram products: Q = A'A on the matrix cores by default (bit 2; measured +5.5 % on config 4 under the Vert plugin,
-   * RKFD_VERT_MFMA=0 switches it off), S = W'W of the iterations only on request (bit 1, RKFD_VERT_MFMA_S=1: measured no gain) */
-  { const char *e = getenv( "RKFD_VERT_MFMA" ); if( !e || atoi( e ) > 0 ) dm.mlcp_mfma |= 4; }
-  { const char *e = getenv( "RKFD_VERT_MFMA_S" ); if( e && atoi( e ) > 0 ) dm.mlcp_mfma |= 2; }
-  /* bit 3: the grouped Gauss-Seidel (independent bodies side by side in DPP rows) switched off - for the A/B test of its claim
-   * that it reproduces the one-after-the-other loop bit for bit */
-  { const char *e = getenv( "RKFD_PGS_GROUPED" ); if( e && atoi( e ) == 0 ) dm.mlcp_mfma |= 8; }
-  /* bit 5: the sweep-order storage of the grouped solve's matrix blocks switched off (the packed triangle instead; A/B test) */
-  { const char *e = getenv( "RKFD_PGS_SW" ); if( e && atoi( e ) == 0 ) dm.mlcp_mfma |= 32; }
+  /* kernel variants: bit 2 the Vert QP's Q = A'A on the matrix cores (on: +5 % on config 4 under the Vert plugin), bit 3 the
+   * grouped Gauss-Seidel off, bit 5 its sweep-order storage off - the last two exist for the tests that show the grouped form
+   * reproduces the one-after-the-other loop bit for bit (rkfdDebugVariants; nothing is read from the environment) */
+  dm.mlcp_mfma = 4 ^ g_debug_variants;
   const size_t Mrows = 3*(size_t)max_rigid;
   /* probe scratch: one row per tree level plus six for a float root, per side; it overlays the
    * C|PA block of the link arrays (dead while the contact problem is solved) when it fits */

@@ -34,12 +34,10 @@ typedef struct {
   int pu_d0;             /* first tree level that holds a 1-DoF joint: the probe scratch has no rows above it     */
   int nside;             /* 1 when every rigid-capable pair has a static cell (probe walks one-sided) else 2 */
   int maxrg;             /* capacity: rigid contact vertices solved per instance (3*maxrg <= 128) */
-  int mlcp_mfma;         /* bit 0: the contact matrix A = N'N is formed with v_mfma_f64_16x16x4_f64 (worlds with at most 32 rows;
-                            bit 1 (switch RKFD_VERT_MFMA_S): the Vert QP's Schur complement S = W'W likewise; bit 2 (default on,
-                            RKFD_VERT_MFMA=0 switches it off): the Vert QP's Q = A'A likewise - the one product where it pays;
-                            bit 3 (RKFD_PGS_GROUPED=0): the grouped Gauss-Seidel of rkfd_dev_mlcp.h switched off (A/B test);
-                            bit 5 (RKFD_PGS_SW=0): its sweep-order matrix storage switched off (packed triangle instead; A/B test);
-                            measurement switch RKFD_MLCP_MFMA, see DESIGN.md "MFMA") */
+  int mlcp_mfma;         /* kernel variants (name kept from round 2): bit 2 (on) the Vert QP's Q = A'A with v_mfma_f64_16x16x4_f64 - the one
+                            product where the matrix cores pay; bit 3 the grouped Gauss-Seidel of rkfd_dev_mlcp.h switched off, bit 5 its
+                            sweep-order matrix storage switched off (packed triangle instead) - A/B switches of the bit-identity tests,
+                            set through rkfdDebugVariants, never from the environment */
   int has_brf;           /* the world holds breakable float joints (rkfd_dev_brf.h): device links with brf[] != 0 are float joints in the
                             tables and take the part of a fixed joint in every evaluation in which they are not broken */
   const int *brf;        /* [nlink] 1: the link hangs on a breakable float joint */

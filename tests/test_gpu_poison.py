@@ -59,14 +59,17 @@ def test_results_do_not_depend_on_what_lds_held_before(R, cfg, specialize, monke
 
 
 def test_packed_triangle_storage_of_the_grouped_solve(R, monkeypatch):
-    """config 5 with the row blocks in the packed triangle (RKFD_PGS_SW=0: the storage rows of more than 8 contacts use, and the
-    one that had the bug described above)"""
+    """config 5 with the row blocks in the packed triangle (rkfdDebugVariants( 32 ): the storage rows of more than 8 contacts use,
+    and the one that had the bug described above)"""
     B, nsteps = 256, 12
     sc = R.scenarios.CONFIGS["config5"](batch=B)
-    monkeypatch.setenv("RKFD_PGS_SW", "0")
-    monkeypatch.delenv("RKFD_DEBUG_POISON_LDS", raising=False)
-    (d0, v0, a0), (act0, typ0, ref0, f0) = _steps(R, sc, B, nsteps, False)
-    monkeypatch.setenv("RKFD_DEBUG_POISON_LDS", "1")
-    (d1, v1, a1), (act1, typ1, ref1, f1) = _steps(R, sc, B, nsteps, False)
+    R.lib().rkfdDebugVariants(32)
+    try:
+        monkeypatch.delenv("RKFD_DEBUG_POISON_LDS", raising=False)
+        (d0, v0, a0), (act0, typ0, ref0, f0) = _steps(R, sc, B, nsteps, False)
+        monkeypatch.setenv("RKFD_DEBUG_POISON_LDS", "1")
+        (d1, v1, a1), (act1, typ1, ref1, f1) = _steps(R, sc, B, nsteps, False)
+    finally:
+        R.lib().rkfdDebugVariants(0)
     assert np.isfinite(a1).all() and np.isfinite(f1).all()
     assert np.array_equal(d0, d1) and np.array_equal(v0, v1) and np.array_equal(a0, a1) and np.array_equal(f0, f1)

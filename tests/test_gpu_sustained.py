@@ -156,17 +156,17 @@ def test_status_is_reported_once(R):
 def test_grouped_gauss_seidel_is_bit_identical(R, specialize, monkeypatch):
     """config 5 (humanoid + four boxes: five independent bodies, 24 contacts): the grouped Gauss-Seidel - the bodies' update
     sequences side by side in DPP rows, 8 + 8 instead of 24 + 24 updates per sweep - gives bit for bit the states and forces of
-    the one-after-the-other loop (RKFD_PGS_GROUPED=0); an update never touches the residuals of another body.  Both storages of
-    the row blocks: sweep order (rows of at most 8 contacts, the default here) and the packed triangle (RKFD_PGS_SW=0: what
+    the one-after-the-other loop (rkfdDebugVariants( 8 )); an update never touches the residuals of another body.  Both storages of
+    the row blocks: sweep order (rows of at most 8 contacts, the default here) and the packed triangle (rkfdDebugVariants( 32 ): what
     longer rows use)"""
     sc = R.scenarios.config5(batch=32)
     out = []
-    for env in ({}, {"RKFD_PGS_SW": "0"}, {"RKFD_PGS_GROUPED": "0"}):
-        for k in ("RKFD_PGS_SW", "RKFD_PGS_GROUPED"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        b = R.Batch(sc["world"], 32, max_rigid=sc["max_rigid"])
+    for mask in (0, 32, 8):      # rkfdDebugVariants: product defaults / sweep-order storage off (packed triangle) / grouped form off
+        R.lib().rkfdDebugVariants(mask)
+        try:
+            b = R.Batch(sc["world"], 32, max_rigid=sc["max_rigid"])
+        finally:
+            R.lib().rkfdDebugVariants(0)
         if specialize:
             b.specialize()
         b.set_state(sc["dis"], sc["vel"]); b.update_init(); b.update(40)

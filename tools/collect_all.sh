@@ -13,11 +13,6 @@ done
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_${TAG}_cal/fetch -- tools/ubench/traffic_cal > gpurun_out/traffic_cal.txt 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_${TAG}_cal/write -- tools/ubench/traffic_cal >> gpurun_out/traffic_cal.txt 2>&1
 echo "traffic calibration done"
-# the MFMA variant of the contact-matrix build: instruction counters of the same command
-RKFD_MLCP_MFMA=1 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d gpurun_out/prof_${TAG}_mfma/on -- python3 bench.py --warmup 5 --steps 20 --no-cpu-baseline --min-seconds 0 > gpurun_out/mfma_on.json 2> gpurun_out/mfma_on.log || true
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d gpurun_out/prof_${TAG}_mfma/off -- python3 bench.py --warmup 5 --steps 20 --no-cpu-baseline --min-seconds 0 > gpurun_out/mfma_off.json 2> gpurun_out/mfma_off.log || true
-python3 tools/mfma_ab.py config4 > gpurun_out/mfma_ab.txt 2>&1
-echo "mfma done"
 ( echo "== rollout window (5 steps after 10) =="; WARM=10 python3 tools/prof_phases.py config2 config3 config4 config4v config5; echo "== rocking regime (5 steps after 100) =="; WARM=100 python3 tools/prof_phases.py config4 config5 ) > gpurun_out/phase_cycles.txt 2>&1
 echo "phases done"
 python3 bench.py --warmup 5 --steps 20 > gpurun_out/bench_driver_cmd.json 2> gpurun_out/bench_driver_cmd.log

@@ -49,49 +49,6 @@ shutil.copy("gpurun_out/phase_cycles.txt", f"profiles/{tag}_phase_cycles.txt")
 shutil.copy("gpurun_out/parity_report.txt", f"profiles/{tag}_parity_report.txt")
 shutil.copy("gpurun_out/traffic_cal.txt", f"profiles/{tag}_traffic_calibration.txt")
 open(f"profiles/{tag}_traffic_calibration.txt", "a").write("calibration (known bytes / counter bytes): read %.4f write %.4f\n" % (CAL["fetch"], CAL["write"]))
-for f in ("mfma_ab.txt", "ubench_pgs.txt"):
-    shutil.copy("gpurun_out/" + f, f"profiles/{tag}_" + f)
-mf = {}
-for k in ("on", "off"):
-    fs = glob.glob(f"gpurun_out/prof_{tag}_mfma/{k}/**/*counter_collection.csv", recursive=True)
-    acc = {}
-    if fs:
-        for r in csv.DictReader(open(fs[0])):
-            if "rkfd_step_kernel" in r["Kernel_Name"]:
-                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-    mf["RKFD_MLCP_MFMA=" + ("1" if k == "on" else "0")] = {c: sorted(v)[len(v) // 2] for c, v in acc.items()}
-    try:
-        mf["RKFD_MLCP_MFMA=" + ("1" if k == "on" else "0")]["steps_per_s"] = json.loads(open(f"gpurun_out/mfma_{k}.json").read().strip().splitlines()[-1])["value"]
-    except Exception:
-        pass
-json.dump(mf, open(f"profiles/{tag}_mfma_counters.json", "w"), indent=1)
-print("mfma counters", mf)
-for w in ("driver_cmd", "config4_h0", "config5_h0", "config3_26", "config4_26"):
-    try:
-        line = open(f"gpurun_out/bench_{w}.json").read().strip().splitlines()[-1]
-        open(f"profiles/{tag}_bench_{w}.json", "w").write(line + "\n"); d = json.loads(line)
-        print(w, "%.4g steps/s" % d["value"], "contacts %.2f" % d["config"]["mean_rigid_contacts"])
-    except Exception as e:
-        print(w, "missing:", e)
-for w in ("config5", "config4v"):
-    line = open(f"gpurun_out/bench_{w}.json").read().strip().splitlines()[-1]
-    open(f"profiles/{tag}_bench_{w}.json", "w").write(line + "\n"); d = json.loads(line)
-    print(w, "%.3g steps/s" % d["value"], "ms %.3f" % d["ms_per_step"], "cpu", d.get("cpu_baseline", {}).get("value"), d.get("cpu_baseline_all_cores", {}).get("value"))
-
-# Volume plugin
-for w in ("config1_volume", "config4_volume"):
-    try:
-        shutil.copy(f"gpurun_out/bench_{w}.json", f"profiles/{tag}_bench_{w}.json")
-    except OSError as e:
-        print("missing", e)
-try:
-    ks = sorted(glob.glob(f"gpurun_out/prof_{tag}_config4_volume/trace/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)[-1]
-    shutil.copy(ks, f"profiles/{tag}_config4_volume_kernel_stats.csv")
-    k5 = sorted(glob.glob(f"gpurun_out/prof_{tag}_config5/trace/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)
-    if k5:
-        shutil.copy(k5[-1], f"profiles/{tag}_config5_kernel_stats.csv")
-        if os.path.exists(f"gpurun_out/prof_{tag}_config5.bench.json"):
-            shutil.copy(f"gpurun_out/prof_{tag}_config5.bench.json", f"profiles/{tag}_config5_kernel_stats.bench.json")
-    shutil.copy("gpurun_out/phase_cycles_volume.txt", f"profiles/{tag}_phase_cycles_volume.txt")
-except (OSError, IndexError) as e:
-    print("missing", e)
+for f in ("ubench_pgs.txt",):
+    if os.path.exists("gpurun_out/" + f):
+        shutil.copy("gpurun_out/" + f, f"profiles/{tag}_" + f)

@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Ahead-of-time specialised step kernels (`make spec`): compiles the world-specific kernel of every workload bench.py knows -
+BASELINE.json's configurations and their variants - through the library's own hipRTC path (no GPU needed) and leaves the code
+objects in roki-fd_amd/spec/, where rkfdBatchSpecialize finds them by key instead of compiling at run time.
+usage: python tools/make_spec.py [workload ...]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import rkfd_pkg
+R = rkfd_pkg.load()
+L = R.lib()
+L.rkfdSpecializeLastFromStore.restype = int
+names = sys.argv[1:] or list(R.scenarios.CONFIGS)
+for nm in names:
+    sc = R.scenarios.CONFIGS[nm](batch=1)
+    if L.rkfdLdsBytesFor(sc["world"].model, sc["max_rigid"]) > 64 * 1024:
+        print("%-16s keeps the generic kernel (more than 64 KiB of LDS per instance)" % nm); continue
+    t0 = time.time()
+    n = L.rkfdSpecializeCompile(sc["world"].model, sc["max_rigid"])
+    if n <= 0:
+        print("%-16s FAILED: %s" % (nm, L.rkfdHipLastError().decode())); sys.exit(1)
+    print("%-16s %6d bytes  %s  (%.1f s)" % (nm, n, "already in the store" if L.rkfdSpecializeLastFromStore() else "compiled", time.time() - t0), flush=True)
