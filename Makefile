@@ -50,13 +50,17 @@ oracle:
 spec: $(LIB)
 	python3 tools/make_spec.py
 
-emu: tests/emu/librkfd_emu.so
+emu: tests/emu/librkfd_emu.so tests/emu/librkfd_emu_w2.so
 
 tests/emu/librkfd_emu.so: tests/emu/rkfd_emu.cpp $(CSRC)/rkfd_device.h $(CSRC)/rkfd_devmodel.cpp $(CSRC)/*.h $(CSRC)/device/*.h include/*.h
 	$(CXX) -std=c++20 -O2 -Wall -Wno-unknown-pragmas -fPIC -shared -pthread $(INC) -o $@ tests/emu/rkfd_emu.cpp $(CSRC)/rkfd_devmodel.cpp
 
+# the same harness with two instances per wavefront (RKFD_W = 2, rkfd_devmodel.h)
+tests/emu/librkfd_emu_w2.so: tests/emu/rkfd_emu.cpp $(CSRC)/rkfd_device.h $(CSRC)/rkfd_devmodel.cpp $(CSRC)/*.h $(CSRC)/device/*.h include/*.h
+	$(CXX) -std=c++20 -O2 -Wall -Wno-unknown-pragmas -fPIC -shared -pthread -DRKFD_W=2 $(INC) -o $@ tests/emu/rkfd_emu.cpp $(CSRC)/rkfd_devmodel.cpp
+
 clean:
-	rm -rf $(BUILD) $(LIB) $(PKG)/spec tests/emu/librkfd_emu.so
+	rm -rf $(BUILD) $(LIB) $(PKG)/spec tests/emu/librkfd_emu.so tests/emu/librkfd_emu_w2.so
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle emu spec clean

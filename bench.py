@@ -208,6 +208,9 @@ def main():
                     "the variation averages out")
     ap.add_argument("--no-specialize", action="store_true", help="keep the generic step kernel instead of compiling it for the "
                     "workload's world (rkfdBatchSpecialize: same results, the world's dimensions as literals)")
+    ap.add_argument("--ipw", type=int, default=0, choices=(0, 1, 2), help="instances per wavefront of the world-specific step kernel: 1 = one instance has the "
+                    "64 lanes; 2 = two instances share a wavefront, 32 lanes each (worlds of at most 32 links / joint coordinates; same results "
+                    "to the last bit); 0 (default) = measure both before the timed region and keep the faster (rkfdBatchTuneInstancesPerWave)")
     ap.add_argument("--split", type=int, default=3, help="launch each step as this many kernels over parts of the batch on internal HIP streams (1..8)")
     args = ap.parse_args()
 
@@ -240,6 +243,8 @@ def main():
     specialized = False; aot = False
     if not args.no_specialize and b.lds_bytes <= 64 * 1024:
         try:
+            if args.ipw == 2:
+                b.set_instances_per_wave(2)
             b.specialize()
             specialized = True
             aot = bool(R.lib().rkfdSpecializeLastFromStore())
@@ -251,6 +256,13 @@ def main():
     b.update_init(stream)
     assert b.status(stream) == 0
     H = args.horizon
+    ipw_tuning = None
+    if specialized and args.ipw == 0:
+        # untimed: which mapping is faster for THIS world (both give the same bits); the state comes back as it was
+        chosen, ms = b.tune_instances_per_wave(min(H, 50) if H > 0 else 50)
+        ipw_tuning = {"ms_1": round(ms[0], 4), "ms_2": round(ms[1], 4) if ms[1] >= 0 else None, "chosen": chosen}
+        aot = aot and bool(R.lib().rkfdSpecializeLastFromStore())
+        assert b.status(stream) == 0
     if H > 0:
         b.snapshot()                          # the rollouts' start: standing state + rkFDUpdateInit's committing evaluation
 
@@ -373,7 +385,7 @@ def main():
             "ms_per_step": 1e3 * elapsed / timed_steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": sc["name"] + (f", MPC-style rollouts of {H} steps from the standing states" if H > 0 else ", one continuous trajectory"),
-                       "instances_per_gpu": Bn, "ndof": m.ndof, "nlink": m.nlink,
+                       "instances_per_gpu": Bn, "instances_per_wavefront": b.instances_per_wave(), "instances_per_wavefront_tuning": ipw_tuning, "ndof": m.ndof, "nlink": m.nlink,
                        "rollout_horizon": H, "timed_steps": timed_steps, "blocks": reps,
                        "mean_rigid_contacts": mean_rg if has_contacts else 0.0, "mean_elastic_contacts": mean_el if has_contacts else 0.0,
                        "parallelism": f"instances sharded over {world} GPU(s), no data-path collective; {args.split} launches per step on internal streams",

@@ -90,6 +90,7 @@ int rkfdBatchSetSplit(rkfdBatch *b, int nsplit);
  * of code object, or -1. */
 int rkfdBatchSpecialize(rkfdBatch *b);
 int rkfdSpecializeCompile(const rkfdModel *m, int max_rigid);
+int rkfdSpecializeCompileW(const rkfdModel *m, int max_rigid, int ipw);      /* ipw: instances per wavefront, 1 or 2 (below) */
 /* Ahead-of-time kernels: a specialised kernel is a function of the world's dimensions and the device sources only, so its code
  * object is kept in a directory beside the library (`spec/`; RKFD_SPEC_DIR overrides, RKFD_SPEC_STORE=0 switches the store off),
  * keyed by a hash of everything that goes into it.  `make spec` fills it for the worlds of BASELINE.json's configurations at
@@ -99,6 +100,18 @@ int rkfdSpecializeLastFromStore(void);
 /* test aid: XOR mask over the kernel variants of the batches created AFTER the call (4: the Vert QP's Q = A'A off the matrix
  * cores, 8: grouped Gauss-Seidel off, 32: its sweep-order storage off); returns the previous mask.  0 = the product's defaults. */
 int rkfdDebugVariants(int mask);
+/* Instances per wavefront of the world-specific kernel: 1 (default: one instance has the 64 lanes) or 2 (two instances share a
+ * wavefront, 32 lanes each: half the instruction issue per instance where an instance leaves most of the 64 lanes idle).  Call
+ * before rkfdBatchSpecialize; needs a world of at most 32 device links, 32 joint coordinates, 32 contact slots and 16 rigid
+ * contact vertices under the MLCP plugin or with elastic contacts only (else -1 with a message, one per wavefront stays).
+ * Results are bit-identical to one instance per wavefront.  rkfdBatchInstancesPerWave: what the launches really use. */
+int rkfdBatchSetInstancesPerWave(rkfdBatch *b, int ipw);
+int rkfdBatchInstancesPerWave(const rkfdBatch *b);
+/* MEASURE which of the two is faster for this world, on this device, at this batch size, and keep it: nsteps steps under
+ * either from the batch's present state (set one and call rkfdBatchUpdateInit first), which is put back afterwards; an
+ * earlier rkfdBatchSnapshot stays as it was.  Returns the chosen count, -1 on error; ms[2] (may be NULL): the milliseconds
+ * measured for 1 and 2 (ms[1] < 0: the world is not eligible for two).  Safe by construction: both give the same bits. */
+int rkfdBatchTuneInstancesPerWave(rkfdBatch *b, int nsteps, double *ms);
 int rkfdBatchJoin(rkfdBatch *b, void *stream);
 /* measurement aid: with on = 1 every launch is bracketed by HIP events on the stream it runs on;
  * rkfdBatchLaunchTiming synchronises the device and returns their number and summed duration */

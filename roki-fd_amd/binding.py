@@ -93,6 +93,9 @@ def lib():
     L.rkfdBatchGetPivot.argtypes = [vp, vp, vp]
     L.rkfdBatchSetPivot.argtypes = [vp, vp, vp]
     L.rkfdBatchGetBroken.argtypes = [vp, vp]; L.rkfdBatchSetBroken.argtypes = [vp, vp]
+    L.rkfdBatchSetInstancesPerWave.argtypes = [vp, C.c_int]; L.rkfdBatchInstancesPerWave.argtypes = [vp]
+    L.rkfdBatchTuneInstancesPerWave.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
+    L.rkfdSpecializeCompileW.argtypes = [C.POINTER(RkfdModel), C.c_int, C.c_int]
     L.rkfdBatchUpdateInit.argtypes = [vp, vp]
     L.rkfdBatchUpdate.argtypes = [vp, C.c_int, vp]
     L.rkfdBatchEval.argtypes = [vp, C.c_int, vp]
@@ -322,6 +325,20 @@ class Batch:
     @property
     def lds_bytes(self):
         return self._L.rkfdBatchLdsBytes(self._b)
+
+    def set_instances_per_wave(self, ipw):
+        """1 (default) or 2 instances per wavefront in the world-specific kernel; call before specialize()"""
+        self._chk(self._L.rkfdBatchSetInstancesPerWave(self._b, int(ipw)))
+
+    def instances_per_wave(self):
+        return self._L.rkfdBatchInstancesPerWave(self._b)
+
+    def tune_instances_per_wave(self, nsteps=8):
+        """measure both mappings on the present state (kept), keep the faster; -> (chosen, (ms with 1, ms with 2))"""
+        ms = (C.c_double * 2)()
+        r = self._L.rkfdBatchTuneInstancesPerWave(self._b, int(nsteps), ms)
+        self._chk(r)
+        return r, (ms[0], ms[1])
 
     def specialize(self):
         """compile the step kernel for this world (hipRTC): same results, its dimensions as literals"""

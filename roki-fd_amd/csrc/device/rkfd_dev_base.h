@@ -12,6 +12,8 @@
    double rkfd_emu_bcast(double x, int src);
    unsigned long long rkfd_emu_ballot(int pred);
 #  define LANE()        rkfd_emu_lane()
+   int    rkfd_emu_half(void);
+#  define HALF()        rkfd_emu_half()
 #  define SYNC()        rkfd_emu_sync()
    double rkfd_emu_g8bcast(double x, int k);
 #  define G8SUM(x)      rkfd_emu_g8sum(x)
@@ -23,6 +25,7 @@
 #  define BCAST(x,l)    rkfd_emu_bcast(x,l)
 #  define BCASTI(x,l)   ( (int)rkfd_emu_bcast( (double)(x), l ) )
 #  define BALLOT(p)     rkfd_emu_ballot(p)
+#  define ANY(p)        ( rkfd_emu_ballot(p) != 0ull )
    double rkfd_emu_wsum(double x);
    double rkfd_emu_wmin(double x);
 #  define WSUM(x)       rkfd_emu_wsum(x)
@@ -33,7 +36,14 @@
 /* the lane index is read through an opaque asm in every phase: otherwise the compiler hoists dozens of
  * lane-derived addresses out of the step loop (loop-invariant code motion) and keeps them in registers
  * across all phases - ~100 VGPRs of the whole-kernel pressure that no single phase needs */
+#if RKFD_W == 1
 static __device__ __forceinline__ int rkfd_lane(void){ int l = (int)threadIdx.x; asm volatile( "" : "+v"(l) ); return l; }
+#  define HALF()        0
+#else
+/* two instances per wavefront: the lane within the instance's half, and which half */
+static __device__ __forceinline__ int rkfd_lane(void){ int l = (int)threadIdx.x & ( RKFD_WL-1 ); asm volatile( "" : "+v"(l) ); return l; }
+#  define HALF()        ( (int)threadIdx.x >> 5 )
+#endif
 #  define LANE()        rkfd_lane()
 /* One workgroup is one wavefront: lanes exchange data through LDS in program order, so a
  * "barrier" only has to (a) stop the compiler from moving LDS accesses across it and (b) wait
@@ -79,6 +89,7 @@ RKFD_DEV void rkfd_g8sum2(double &x, double &y)
   a = rkfd_dpp_hmirror( x ); b = rkfd_dpp_hmirror( y );
   x += a; y += b;
 }
+#if RKFD_W == 1
 /* broadcast lane src (wave-uniform) to every lane */
 RKFD_DEV double rkfd_bcast(double x, int src)
 {
@@ -86,6 +97,17 @@ RKFD_DEV double rkfd_bcast(double x, int src)
   int hi = __builtin_amdgcn_readlane( __double2hiint( x ), src );
   return __hiloint2double( hi, lo );
 }
+#else
+/* two instances per wavefront: lane src of the OWN half to every lane of the half (src the same within a half; the crossbar of
+ * ds_bpermute instead of a scalar register, which holds one value per wavefront) */
+RKFD_DEV int rkfd_bcasti(int x, int src){ return __builtin_amdgcn_ds_bpermute( ( ( (int)threadIdx.x & 32 ) + src ) << 2, x ); }
+RKFD_DEV double rkfd_bcast(double x, int src)
+{
+  int lo = rkfd_bcasti( __double2loint( x ), src );
+  int hi = rkfd_bcasti( __double2hiint( x ), src );
+  return __hiloint2double( hi, lo );
+}
+#endif
 /* broadcast lane k (compile-time 0..7) of every aligned 8-lane group to the whole group:
  * ds_swizzle in bit mode, lane' = ( lane & 0x18 ) | k within each half-wave; no LDS storage */
 template<int K> RKFD_DEV double rkfd_g8bcast(double x)
@@ -120,8 +142,17 @@ template<int C> RKFD_DEV void rkfd_rowbc_fmac(double &acc, double x, double a)
 /* the instruction scheduler does not move anything across this point */
 #  define RKFD_SCHED_BARRIER() __builtin_amdgcn_sched_barrier( 0 )
 #  define BCAST(x,l)    rkfd_bcast(x,l)
+/* does any lane of the WAVEFRONT vote yes: a wave-uniform branch condition whatever the number of instances in the wavefront */
+#  define ANY(p)        ( __ballot(p) != 0ull )
+#if RKFD_W == 1
 #  define BCASTI(x,l)   __builtin_amdgcn_readlane( (int)(x), l )      /* an int of lane l (wave-uniform l) */
 #  define BALLOT(p)     __ballot(p)
+#else
+#  define BCASTI(x,l)   rkfd_bcasti( (int)(x), l )
+/* the votes of the instance's own half, in bits 0 .. 31 (a per-lane value: what is branched on it diverges between the halves,
+ * which the compiler handles with the execution mask) */
+#  define BALLOT(p)     ( ( __ballot(p) >> ( (int)threadIdx.x & 32 ) ) & 0xffffffffull )
+#endif
 /* sum / minimum over the whole wave in registers, the same value in every lane: the 8-lane DPP butterfly, then the eight
  * group results through v_readlane (no LDS, no barrier: ~100 cycles where a tree through LDS takes ~2000) */
 RKFD_DEV double rkfd_wave_sum(double x)
@@ -400,7 +431,7 @@ RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int
   }
   L->CHOL = d; d += 21*nfloat; L->XF = d; d += 12*nfloat;
   L->CX = d; d += maxact*3; L->AX = d; d += maxact*6; L->RW = d; d += maxact*3; L->PRO = d; d += maxact*3;
-  L->REF = d; d += maxact*3; L->RTMP = d; if( NC > RKFD_WAVE ) d += maxact*3;
+  L->REF = d; d += maxact*3; L->RTMP = d; if( NC > RKFD_WAVE/2 ) d += maxact*3;      /* (more than one chunk of candidates at two instances per wavefront) */
   L->CF = d; d += maxact*3;
   L->SV = d; L->SD = d; if( has_slide ){ L->SV = d; d += maxact*3; L->SD = d; d += maxact*3; }
   /* PGS: a lane reads its three entries of b before it writes its three forces, so they share storage */

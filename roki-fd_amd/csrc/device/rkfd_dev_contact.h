@@ -30,13 +30,13 @@ RKFD_DEV void rkfd_phase_collision(const rkfdDevModel &m, const rkfdLds &L)
   int base_act = 0, base_rg = 0, base_el = 0, ovf = 0;
   /* slots are re-assigned chunk by chunk: with more than one chunk the old anchors are read from a copy */
   const double *oldref = L.REF;
-  if( m.ncand > RKFD_WAVE ){
-    for( int k=lane; k<3*m.maxact; k+=RKFD_WAVE ) L.RTMP[k] = L.REF[k];
+  if( m.ncand > RKFD_WL ){
+    for( int k=lane; k<3*m.maxact; k+=RKFD_WL ) L.RTMP[k] = L.REF[k];
     oldref = L.RTMP;
     SYNC();
   }
   /* candidates are swept 64 at a time; slots and list positions keep candidate order */
-  for( int c0=0; c0<m.ncand; c0+=RKFD_WAVE ){
+  for( int c0=0; c0<m.ncand; c0+=RKFD_WL ){
     const bool on = c0+lane < m.ncand;
     const int j = on ? c0+lane : 0;
     int is_act = 0, is_rg = 0, is_el = 0, fbest = -1;

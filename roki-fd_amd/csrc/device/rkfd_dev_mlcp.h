@@ -56,9 +56,11 @@ template<bool pk> RKFD_DEV void rkfd_pgs_registers(const double *MA, int r0, int
          * is evaluated only when contact c really slides */
         const bool zero = fnorm < RKFD_DEV_TOL || fs < RKFD_DEV_TOL;
         double n1 = zero ? 0.0 : ff0, n2 = zero ? 0.0 : ff1;
-        if( ( BALLOT( !zero && fnorm > fs ) >> c ) & 1ull ){
+        /* (a wave-uniform branch - does the contact whose turn it is slide, in any instance of the wavefront - and lane selects) */
+        const bool sl = !zero && fnorm > fs;
+        if( ANY( sl && lane == c ) ){
           const double sc = fs*RKFD_RCP( fnorm );
-          n1 = ff0*sc; n2 = ff1*sc;
+          n1 = sl ? ff0*sc : n1; n2 = sl ? ff1*sc : n2;
         }
         const double d1 = BCAST( n1 - f1, c ), d2 = BCAST( n2 - f2, c );
         if( lane == c ){ f1 = n1; f2 = n2; }
@@ -122,9 +124,10 @@ template<bool pk, int C0> RKFD_DEV void rkfd_pgs_dpp_tangent(const double *MA, i
     double n1 = zero ? 0.0 : ff0, n2 = zero ? 0.0 : ff1; \
     /* only the decision of lane c matters: branch on it wave-uniformly, so that the reciprocal is evaluated only \
      * when contact c really slides */ \
-    if( ( BALLOT( !zero && fnorm > fs ) >> ( C0+u ) ) & 1ull ){ \
+    const bool sl = !zero && fnorm > fs; \
+    if( ANY( sl && lane == C0+u ) ){ \
       const double sc = fs*RKFD_RCP( fnorm ); \
-      n1 = ff0*sc; n2 = ff1*sc; \
+      n1 = sl ? ff0*sc : n1; n2 = sl ? ff1*sc : n2; \
     } \
     const double d1 = n1 - f1, d2 = n2 - f2; \
     if( lane == C0+u ){ f1 = n1; f2 = n2; } \
@@ -215,7 +218,7 @@ template<bool pk, int C0> RKFD_DEV void rkfd_pgs_grp_tangent(const double *MA, c
      * lanes select: a per-lane branch would rewrite EXEC right in front of the DPP instructions below, which sit in inline asm where
      * the compiler does not see that they need their wait states after an EXEC write */
     const bool sl = !zero && fnorm > fs;
-    if( BALLOT( sl && pos == C0 ) != 0ull ){
+    if( ANY( sl && pos == C0 ) ){
       const double sc = fs*RKFD_RCP( fnorm );
       n1 = sl ? ff0*sc : n1; n2 = sl ? ff1*sc : n2;
     }
@@ -404,7 +407,7 @@ template<int C0> RKFD_DEV void rkfd_pgs_sw_tangent(const double *SWl, int maxlen
     const bool zero = fnorm < RKFD_DEV_TOL || fs < RKFD_DEV_TOL;
     double n1 = zero ? 0.0 : ff0, n2 = zero ? 0.0 : ff1;
     const bool sl = !zero && fnorm > fs;       /* (wave-uniform branch, lanes select: see rkfd_pgs_grp_tangent) */
-    if( BALLOT( sl && pos == C0 ) != 0ull ){
+    if( ANY( sl && pos == C0 ) ){
       const double sc = fs*RKFD_RCP( fnorm );
       n1 = sl ? ff0*sc : n1; n2 = sl ? ff1*sc : n2;
     }
@@ -492,9 +495,10 @@ template<bool pk> RKFD_DEV void rkfd_pgs_dpp8(const double *MA, int r0, int ld, 
       const double fnorm = ff0*ff0 + ff1*ff1; \
       const bool zero = fnorm < RKFD_DEV_TOL || fs < RKFD_DEV_TOL; \
       double n1 = zero ? 0.0 : ff0, n2 = zero ? 0.0 : ff1; \
-      if( ( BALLOT( !zero && fnorm > fs ) >> c ) & 1ull ){ \
+      const bool sl = !zero && fnorm > fs; \
+      if( ANY( sl && lane == c ) ){ \
         const double sc = fs*RKFD_RCP( fnorm ); \
-        n1 = ff0*sc; n2 = ff1*sc; \
+        n1 = sl ? ff0*sc : n1; n2 = sl ? ff1*sc : n2; \
       } \
       const double d1 = n1 - f1, d2 = n2 - f2; \
       if( lane == c ){ f1 = n1; f2 = n2; } \
@@ -653,7 +657,7 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
    * owner link (+) and the other link (-).  Every level between the contact link and the top of
    * its path carries a 1-DoF joint; the operands of the next level are fetched while this one is
    * computed. */
-  for( int cb=0; cb<M; cb+=RKFD_WAVE ){      /* 64 probe columns at a time */
+  for( int cb=0; cb<M; cb+=RKFD_WL ){      /* 64 probe columns at a time (32 with two instances per wavefront) */
     const int col = cb + lane;
     const bool on = col < M;
     const int c = on ? col/3 : 0, ia = on ? col%3 : 0;
@@ -727,11 +731,11 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
   const int nblk = gfills >= 0 ? gb4 : ( pk ? ( nc*( nc+1 ) >> 1 ) : nc*nc );
   {
   if( sw ){
-    for( int i=lane; i<9*RKFD_SW_SLOTS*gmaxlen; i+=RKFD_WAVE ) L.MA[i] = 0.0;
+    for( int i=lane; i<9*RKFD_SW_SLOTS*gmaxlen; i+=RKFD_WL ) L.MA[i] = 0.0;
     SYNC();
   }
   /* A, one 3x3 block per lane and pass: block ( cr, ck <= cr ) and its mirror image */
-  for( int e0=0; e0<nblk; e0+=RKFD_WAVE ){
+  for( int e0=0; e0<nblk; e0+=RKFD_WL ){
     const int e = e0 + lane;
     int cr, ck; bool one;
     int swr = 0, swk = 0, posr = 0, posk = 0;      /* sweep-order storage: slots and positions of the two contacts */
@@ -939,7 +943,9 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
     /* one side of one contact: its share of this lane's sum (e: the side's record, wave-uniform) */
 #define RKFD_DIN_ONP(e) ( isf ? RKFD_CS_TOP( e ) == link \
                              : ( RKFD_CS_DEPTH( e ) >= dpt && RKFD_CS_D0( e ) <= dpt && L.PL[RKFD_CS_LINK( e )*NLV+dpt] == link ) )
-    if( nc*NSD <= RKFD_WAVE ){
+    /* (with two instances per wavefront these broadcasts go through the LDS crossbar - ds_bpermute - instead of a scalar register;
+     *  still faster than the loop over LDS below: 11.03 against 10.52 M steps/s on config 4, profiles/r03_ipw_ab.txt) */
+    if( nc*NSD <= RKFD_WL ){
       /* the records and the forces wait in registers (lane = side, lane = contact) and reach everybody through v_readlane: the
        * loop over the sides that move (the floor's do not: half of the sides where contacts may have two moving ones) then holds
        * no LDS access that depends on another, two sides are in flight together, and the sum is still taken in the order of the

@@ -130,8 +130,11 @@ RKFD_DEV void rkfd_cat_dis(const rkfdDevModel &m, const rkfdLds &L, int dofkind,
 /* the whole step for one instance: load state, nsteps x rkFDUpdate (or a single evaluation),
  * store state.  mode 0: rkFDUpdate x nsteps; mode 1: rkFDUpdateInit (committing evaluation);
  * mode 2: evaluation without commit. */
+/* The instance of this lane: with RKFD_W instances per wavefront, half h of workgroup wg simulates instance first + wg RKFD_W + h
+ * and owns the h-th block of lds_instance bytes of the workgroup's LDS.  A half beyond the end of the batch part (odd count) keeps
+ * in step by simulating the instance before it once more - the halves share every branch and barrier - and stores nothing. */
 template<bool prof, int vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDevModel &m_, const rkfdDevState &st, int b, void *ldsbase,
-                            int mode, int nsteps, int *errflag)
+                            int mode, int nsteps, int *errflag, bool live = true)
 {
 #ifdef RKFD_SPEC
   /* kernel compiled for ONE world (rkfdBatchSpecialize, hipRTC): its dimensions are literals, so the LDS layout,
@@ -156,7 +159,7 @@ template<bool prof, int vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDevM
   rkfd_lds_carve( &L, ldsbase, NL, ND, NC, 3*m.maxrg, m.nlevel, m.npool, m.nfloat, m.maxact, m.nside, m.pu_alias, m.npurow, m.vert_rigid, m.has_slide, m.ma_size,
                   vqp == 2 ? m.vol_np : 0, m.vol_ncp, m.vol_pv, m.vol_nf, m.pyramid, m.maxrg > 0 );
   if( m.lds_poison > 0 ){      /* (RKFD_DEBUG_POISON_LDS: see rkfd_devmodel.h) */
-    for( int i=lane; i<m.lds_poison; i+=RKFD_WAVE ) ( (unsigned *)ldsbase )[i] = 0xffffffffu;
+    for( int i=lane; i<m.lds_poison; i+=RKFD_WL ) ( (unsigned *)ldsbase )[i] = 0xffffffffu;
     SYNC();
   }
   if( lane == 0 ){
@@ -188,10 +191,10 @@ template<bool prof, int vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDevM
     ll.pivp = st.piv_prev[(size_t)b*m.nlink_model+lm];
   }
   if( m.maxrg > 0 ){
-    for( int k=lane; k<NL*( m.nlevel+3 ); k+=RKFD_WAVE ) L.PL[k] = (unsigned char)m.pathlink[k];
+    for( int k=lane; k<NL*( m.nlevel+3 ); k+=RKFD_WL ) L.PL[k] = (unsigned char)m.pathlink[k];
   }
   if( m.has_brf ) rkfd_brf_load( m, st, L, b );
-  for( int c0=0, base=0; c0<NC; c0+=RKFD_WAVE ){
+  for( int c0=0, base=0; c0<NC; c0+=RKFD_WL ){
     const int j = c0 + lane;
     const bool onj = j < NC;
     int a = 0;
@@ -268,28 +271,28 @@ template<bool prof, int vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDevM
       stage++; if( stage == nst ) stage = 0;
     }
   }
-  if( prof && lane == 0 && st.prof ){
+  if( prof && live && lane == 0 && st.prof ){
     pc[prof ? 7 : 0] = RKFD_CLOCK() - tstart;
 #pragma unroll
     for( int k=0; k<( prof ? RKFD_NPROF : 1 ); k++ ) st.prof[(size_t)b*RKFD_NPROF+k] = pc[k];
   }
   /* store */
-  if( lane < ND ){
+  if( live && lane < ND ){
     st.dis[(size_t)b*ND+lane] = q; st.vel[(size_t)b*ND+lane] = qd;
     st.acc[(size_t)b*ND+lane] = L.acc[lane];
   }
   /* (a spherical joint is three device links of one model link: the real one writes - the pseudo-links in front of it hold the same
    * untouched values, but three lanes storing to one address is a race all the same; found by ThreadSanitizer on the emulator) */
-  if( lane < NL && RKFD_LI_JT( L.LI[lane] ) != RKFD_DJT_SPHX && RKFD_LI_JT( L.LI[lane] ) != RKFD_DJT_SPHY ){
+  if( live && lane < NL && RKFD_LI_JT( L.LI[lane] ) != RKFD_DJT_SPHX && RKFD_LI_JT( L.LI[lane] ) != RKFD_DJT_SPHY ){
     const int lm = m.orig[lane];
     st.piv_type[(size_t)b*m.nlink_model+lm] = ll.pivt;
     st.piv_prev[(size_t)b*m.nlink_model+lm] = ll.pivp;
   }
-  if( m.has_brf ) rkfd_brf_store( m, st, L, b );
+  if( m.has_brf && live ) rkfd_brf_store( m, st, L, b );
   /* contact state: the flag of every candidate, the rest only for those in contact (a candidate out of
    * contact has no state: type and anchor are re-initialised at its next first contact, and the
    * boundary reports zeros for it) */
-  for( int j=lane; j<NC; j+=RKFD_WAVE ){
+  for( int j=lane; live && j<NC; j+=RKFD_WL ){
     const int a = L.act[j];
     st.cv_active[(size_t)b*NC+j] = a;
     if( a ){
@@ -301,16 +304,16 @@ template<bool prof, int vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDevM
       }
     }
   }
-  if( st.dbg ){
+  if( st.dbg && live ){
     /* debug dump: spatial accelerations (6/link) */
     if( lane < NL ){
       double *o = st.dbg + (size_t)b*st.dbg_stride;
       for( int k=0; k<6; k++ ) o[6*lane+k] = L.AC[6*lane+k];
     }
   }
-  if( NC > 0 && mode == 0 && st.stat && lane < 3 )
+  if( live && NC > 0 && mode == 0 && st.stat && lane < 3 )
     st.stat[(size_t)b*4+lane] += (unsigned int)L.cnt[CNT_SRG+lane];
-  if( lane == 0 && errflag ){
+  if( live && lane == 0 && errflag ){
     if( err ) *errflag = 1;              /* rigid contact with a solver that has no device path */
     if( L.cnt[CNT_OVF] ) *errflag = 2;   /* more rigid contacts than the configured capacity   */
     if( L.cnt[CNT_QPF] ) *errflag = 3;   /* the Vert QP ran out of iterations / basis history   */

@@ -80,7 +80,8 @@ RKFD_DEV rkfdRec rkfd_rec_load(const rkfdDevModel &m, int t, int g)
 {
   /* t in [-2, nsched+1]: the schedule is padded with two empty iterations on both sides */
   rkfdRec r;
-  const int *p = m.sched + ( (size_t)( t+2 )*8 + g )*4;
+  /* (two instances per wavefront: four lane groups per iteration, the schedule built for that) */
+  const int *p = m.sched + ( (size_t)( t+2 )*( 8/RKFD_W ) + g )*4;
   r.i = p[0]; r.li = p[1]; r.w = p[2]; r.coff = p[3];
   return r;
 }

@@ -107,6 +107,13 @@ struct rkfdBatch {
   /* rkfdBatchSpecialize: the step kernel compiled for this world (hipRTC); NULL = the generic kernels above */
   hipModule_t spec_mod;
   hipFunction_t spec_fn;
+  /* rkfdBatchSetInstancesPerWave( b, 2 ): a second device model (sweep schedule with four links per iteration) for the
+   * world-specific kernel built with RKFD_W = 2 - two instances per wavefront, 32 lanes each */
+  int ipw;                           /* instances per wavefront of the specialised kernel: 1 or 2 */
+  const rkfdModel *model_for_w2;     /* the caller's model (must outlive the batch, as for rkfdBatchCreate's own use) */
+  rkfdDevModelHost host2;
+  rkfdDevModel dm2;
+  void *dblob2;
   /* split launches (rkfdBatchSetSplit): the batch goes out as nsplit kernels on internal streams, so that the
    * tail of one step of one part overlaps the next step of another (the instances are independent) */
   int nsplit;
@@ -174,6 +181,7 @@ extern "C" rkfdBatch *rkfdBatchCreate(const rkfdModel *m, int batch, int device,
   }
   b->dm = b->host.dm;
   rkfd_devmodel_rebase( &b->dm, b->host.blob, b->dblob );
+  b->ipw = 1; b->model_for_w2 = m;
 
   const size_t B = batch, ND = m->ndof, NL = m->nlink, NC = m->ncand;
   int bad = 0;
@@ -213,8 +221,8 @@ extern "C" void rkfdBatchDestroy(rkfdBatch *b)
   }
   if( b->tev ){ for( size_t i=0; i<b->tev->size(); i++ ) (void)hipEventDestroy( (*b->tev)[i] ); delete b->tev; }
   if( b->spec_mod ) (void)hipModuleUnload( b->spec_mod );
-  (void)hipFree( b->d_err ); (void)hipFree( b->dblob );
-  rkfd_devmodel_free( &b->host );
+  (void)hipFree( b->d_err ); (void)hipFree( b->dblob ); (void)hipFree( b->dblob2 );
+  rkfd_devmodel_free( &b->host ); rkfd_devmodel_free( &b->host2 );
   free( b );
 }
 
@@ -241,6 +249,13 @@ extern "C" int rkfdBatchResidency(const rkfdBatch *b)
    * (measured with tools/ubench/residency.hip, profiles/r01_lds_residency.txt), e.g. 16160 bytes -> 9, not 10 */
   const int pieces = (int)( ( b->lds_bytes + 1279 )/1280 );
   if( pieces > 0 && 128/pieces < n ) n = 128/pieces;
+  if( b->ipw == 2 && b->spec_fn ){
+    /* two instances per wavefront: workgroups of 2 x the LDS, at most two waves per SIMD (the kernel is built for that) */
+    const int p2 = (int)( ( 2*b->host2.lds_bytes + 1279 )/1280 );
+    int w = p2 > 0 ? 128/p2 : 0;
+    if( w > 8 ) w = 8;
+    n = 2*w;
+  }
   return n;
 }
 extern "C" double *rkfdBatchDevDis(rkfdBatch *b){ return b ? b->st.dis : NULL; }
@@ -388,6 +403,15 @@ static int sync_streams(rkfdBatch *b)
 static int launch_one(rkfdBatch *b, rkfdKernel kern, int count, int first, int mode, int nsteps, hipStream_t stream)
 {
   if( b->spec_fn && !b->st.prof ){
+    if( b->ipw == 2 ){
+      /* two instances per wavefront: half as many workgroups, each with the LDS of two instances; the kernel learns where the
+       * part ends through st.batch (a half beyond it is a stand-in that stores nothing) */
+      rkfdDevState st2 = b->st;
+      st2.batch = first + count;
+      void *args[] = { &b->dm2, &st2, &first, &mode, &nsteps, &b->d_err };
+      HIPCHK( hipModuleLaunchKernel( b->spec_fn, ( count+1 )/2, 1, 1, RKFD_WAVE, 1, 1, (unsigned)( 2*b->host2.lds_bytes ), stream, args, NULL ), -1 );
+      return 0;
+    }
     void *args[] = { &b->dm, &b->st, &first, &mode, &nsteps, &b->d_err };
     HIPCHK( hipModuleLaunchKernel( b->spec_fn, count, 1, 1, RKFD_WAVE, 1, 1, (unsigned)b->lds_bytes, stream, args, NULL ), -1 );
     return 0;
@@ -435,32 +459,34 @@ static int launch(rkfdBatch *b, int mode, int nsteps, void *stream)
 }
 /* ---- the step kernel compiled for one world (hipRTC) ---------------------------------------------------- */
 /* source of the specialised kernel: the dimensions of the world as literals in front of the same device code */
-static std::string spec_source(const rkfdDevModel &d)
+static std::string spec_source(const rkfdDevModel &d, int ipw = 1)
 {
   char buf[4096];
   snprintf( buf, sizeof(buf),
-    "#define RKFD_SPEC 1\n"
+    "#define RKFD_SPEC 1\n#define RKFD_W %d\n"
     "#define RKFD_SPEC_NLINK %d\n#define RKFD_SPEC_NDOF %d\n#define RKFD_SPEC_NCAND %d\n#define RKFD_SPEC_NLINK_MODEL %d\n"
     "#define RKFD_SPEC_NLEVEL %d\n#define RKFD_SPEC_NROUND %d\n#define RKFD_SPEC_NSCHED %d\n#define RKFD_SPEC_MAXRG %d\n"
     "#define RKFD_SPEC_NPOOL %d\n#define RKFD_SPEC_NFLOAT %d\n#define RKFD_SPEC_MAXACT %d\n#define RKFD_SPEC_NSIDE %d\n"
     "#define RKFD_SPEC_NPUROW %d\n#define RKFD_SPEC_PU_D0 %d\n#define RKFD_SPEC_PU_ALIAS %d\n#define RKFD_SPEC_VERT_RIGID %d\n#define RKFD_SPEC_QSCR_ALIAS %d\n"
     "#define RKFD_SPEC_HAS_SLIDE %d\n#define RKFD_SPEC_MA_SIZE %d\n#define RKFD_SPEC_MA_PACKED %d\n"
     "#define RKFD_SPEC_MAX_ITER %d\n#define RKFD_SPEC_SOLVER %d\n#define RKFD_SPEC_PYRAMID %d\n#define RKFD_SPEC_ANCHOR %d\n#define RKFD_SPEC_MLCP_MFMA %d\n"
-    "#define RKFD_SPEC_HAS_BRF %d\n"
+    "#define RKFD_SPEC_HAS_BRF %d\n#define RKFD_SPEC_LDS_INSTANCE %d\n"
     "#define RKFD_SPEC_VOL_NPAIR %d\n#define RKFD_SPEC_VOL_NP %d\n#define RKFD_SPEC_VOL_NCP %d\n#define RKFD_SPEC_VOL_PV %d\n#define RKFD_SPEC_VOL_NF %d\n"
     "#include \"rkfd_device.h\"\n"
     "extern \"C\" __global__ void __launch_bounds__(64, %d)\n"
     "rkfd_step_kernel_spec(rkfdDevModel m, rkfdDevState st, int first, int mode, int nsteps, int *errflag)\n"
     "{\n"
     "  extern __shared__ __attribute__((aligned(16))) char lds[];\n"
-    "  const int b = first + (int)blockIdx.x;\n"
-    "  if( b >= st.batch ) return;\n"
-    "  rkfd_instance<false, %s, %s>( m, st, b, lds, mode, nsteps, errflag );\n"
+    "  int b = first + (int)blockIdx.x*RKFD_W + HALF();\n"
+    "  if( RKFD_W == 1 && b >= st.batch ) return;\n"
+    "  const bool live = b < st.batch;\n"
+    "  if( !live ) b -= 1;\n"
+    "  rkfd_instance<false, %s, %s>( m, st, b, lds + HALF()*RKFD_SPEC_LDS_INSTANCE, mode, nsteps, errflag, live );\n"
     "}\n",
-    d.nlink, d.ndof, d.ncand, d.nlink_model, d.nlevel, d.nround, d.nsched, d.maxrg, d.npool, d.nfloat, d.maxact, d.nside,
+    ipw, d.nlink, d.ndof, d.ncand, d.nlink_model, d.nlevel, d.nround, d.nsched, d.maxrg, d.npool, d.nfloat, d.maxact, d.nside,
     d.npurow, d.pu_d0, d.pu_alias, d.vert_rigid, d.qscr_alias, d.has_slide, d.ma_size, d.ma_packed, d.max_iter, d.solver, d.pyramid, d.anchor, d.mlcp_mfma,
-    d.has_brf, d.vol_npair, d.vol_np, d.vol_ncp, d.vol_pv, d.vol_nf,
-    d.vol_np > 0 ? 2 : 3, d.vol_np > 0 ? "2" : ( d.vert_rigid ? "1" : "0" ), d.ma_packed ? "true" : "false" );
+    d.has_brf, d.lds_instance, d.vol_npair, d.vol_np, d.vol_ncp, d.vol_pv, d.vol_nf,
+    ( d.vol_np > 0 || ipw == 2 ) ? 2 : 3, d.vol_np > 0 ? "2" : ( d.vert_rigid ? "1" : "0" ), d.ma_packed ? "true" : "false" );
   std::string src;
   if( const char *pre = getenv( "RKFD_SPEC_DEFINE" ) ){      /* diagnostic: NAME[,NAME...] defined as 1 in front of the source */
     std::string names( pre ); size_t p0 = 0;
@@ -587,9 +613,9 @@ static int g_spec_last_from_store = 0;      /* diagnostic: did the last spec_com
 extern "C" int rkfdSpecializeLastFromStore(void){ return g_spec_last_from_store; }
 
 /* compile for gfx950 from the sources the library carries (rkfd_device_src.inc): nothing is read from disk but the store above */
-static int spec_compile(const rkfdDevModel &d, std::vector<char> &code)
+static int spec_compile(const rkfdDevModel &d, std::vector<char> &code, int ipw = 1)
 {
-  const std::string src = spec_source( d );
+  const std::string src = spec_source( d, ipw );
   const char *opts[] = { "--offload-arch=gfx950", "-O3", "-Wno-unused-value", "-mllvm", "-disable-machine-licm" };
   const int nopts = (int)( sizeof(opts)/sizeof(opts[0]) );
   const unsigned long long key = spec_key( src, opts, nopts );
@@ -648,16 +674,18 @@ static int spec_compile(const rkfdDevModel &d, std::vector<char> &code)
   if( rtc->priv ) spec_to_store( key, code );      /* (only what the compiler this library was built with produced: the private namespace) */
   return 0;
 }
-extern "C" int rkfdSpecializeCompile(const rkfdModel *m, int max_rigid)
+extern "C" int rkfdSpecializeCompileW(const rkfdModel *m, int max_rigid, int ipw)
 {
   rkfdDevModelHost h;
   char err[256];
-  if( !m || rkfd_devmodel_build( m, max_rigid, &h, err, sizeof(err) ) < 0 ){ SETERR( "rkfdSpecializeCompile: %s", m ? err : "null model" ); return -1; }
+  if( ipw != 1 && ipw != 2 ){ SETERR( "rkfdSpecializeCompileW: 1 or 2 instances per wavefront" ); return -1; }
+  if( !m || rkfd_devmodel_build_w( m, max_rigid, ipw == 2 ? 4 : 8, &h, err, sizeof(err) ) < 0 ){ SETERR( "rkfdSpecializeCompile: %s", m ? err : "null model" ); return -1; }
   std::vector<char> code;
-  const int r = spec_compile( h.dm, code );
+  const int r = spec_compile( h.dm, code, ipw );
   rkfd_devmodel_free( &h );
   return r < 0 ? -1 : (int)code.size();
 }
+extern "C" int rkfdSpecializeCompile(const rkfdModel *m, int max_rigid){ return rkfdSpecializeCompileW( m, max_rigid, 1 ); }
 extern "C" int rkfdBatchSpecialize(rkfdBatch *b)
 {
   if( !b ){ SETERR( "null batch" ); return -1; }
@@ -666,8 +694,9 @@ extern "C" int rkfdBatchSpecialize(rkfdBatch *b)
   HIPCHK( hipSetDevice( b->device ), -1 );
   if( sync_streams( b ) < 0 ) return -1;
   std::vector<char> code;
-  if( spec_compile( b->dm, code ) < 0 ) return -1;
+  if( spec_compile( b->ipw == 2 ? b->host2.dm : b->dm, code, b->ipw == 2 ? 2 : 1 ) < 0 ) return -1;
   HIPCHK( hipModuleLoadData( &b->spec_mod, code.data() ), -1 );
+
   HIPCHK( hipModuleGetFunction( &b->spec_fn, b->spec_mod, "rkfd_step_kernel_spec" ), -1 );
   {
     /* the compiler behind hipRTC is whichever libamd_comgr the process loaded first; a framework that bundles an older
@@ -675,7 +704,7 @@ extern "C" int rkfdBatchSpecialize(rkfdBatch *b)
     int regs = -1, scratch = -1;
     hipFuncGetAttribute( &regs, HIP_FUNC_ATTRIBUTE_NUM_REGS, b->spec_fn );
     hipFuncGetAttribute( &scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, b->spec_fn );
-    if( getenv( "RKFD_SPEC_DEBUG" ) ) fprintf( stderr, "rkfdBatchSpecialize: %d VGPRs, %d bytes of scratch per lane, %zu bytes of LDS\n", regs, scratch, b->lds_bytes );
+    if( getenv( "RKFD_SPEC_DEBUG" ) ) fprintf( stderr, "rkfdBatchSpecialize: %d instance(s) per wavefront, %d VGPRs, %d bytes of scratch per lane, %zu bytes of LDS per instance\n", b->ipw == 2 ? 2 : 1, regs, scratch, b->ipw == 2 ? b->host2.lds_bytes : b->lds_bytes );
     if( scratch > ( b->dm.vol_np > 0 ? 512 : 160 ) ){      /* (the Volume variant is built for two waves per SIMD and spills a few registers on purpose; worlds with two moving
                                                              * contact sides sit at the 168-register limit and spill a handful - tools/spec_resources.py; the wrong compiler: 912 B) */
       (void)hipModuleUnload( b->spec_mod ); b->spec_mod = NULL; b->spec_fn = NULL;
@@ -685,6 +714,102 @@ extern "C" int rkfdBatchSpecialize(rkfdBatch *b)
     }
   }
   return 0;
+}
+
+/* Two instances per wavefront (RKFD_W = 2, rkfd_devmodel.h): takes effect in the world-specific kernel - call before
+ * rkfdBatchSpecialize.  Builds the second device model (sweep schedule with four links per iteration); fails with a message
+ * when the world does not fit 32 lanes per instance. */
+extern "C" int rkfdBatchSetInstancesPerWave(rkfdBatch *b, int ipw)
+{
+  if( !b || ( ipw != 1 && ipw != 2 ) ){ SETERR( "rkfdBatchSetInstancesPerWave: 1 or 2" ); return -1; }
+  if( b->spec_fn ){ SETERR( "rkfdBatchSetInstancesPerWave: call it before rkfdBatchSpecialize" ); return -1; }
+  if( ipw == 1 ){ b->ipw = 1; return 0; }
+  HIPCHK( hipSetDevice( b->device ), -1 );
+  if( !b->dblob2 ){
+    char err[256];
+    if( rkfd_devmodel_build_w( b->model_for_w2, b->host.dm.maxrg, 4, &b->host2, err, sizeof(err) ) < 0 ){ SETERR( "rkfdBatchSetInstancesPerWave: %s", err ); return -1; }
+    if( b->host2.lds_bytes*2 > 160*1024 ){ SETERR( "rkfdBatchSetInstancesPerWave: two instances need %zu bytes of LDS (> 160 KiB)", 2*b->host2.lds_bytes ); rkfd_devmodel_free( &b->host2 ); return -1; }
+    HIPCHK( hipMalloc( &b->dblob2, b->host2.bytes ), -1 );
+    HIPCHK( hipMemcpy( b->dblob2, b->host2.blob, b->host2.bytes, hipMemcpyHostToDevice ), -1 );
+    b->dm2 = b->host2.dm;
+    rkfd_devmodel_rebase( &b->dm2, b->host2.blob, b->dblob2 );
+  }
+  b->ipw = 2;
+  return 0;
+}
+extern "C" int rkfdBatchInstancesPerWave(const rkfdBatch *b){ return b ? ( b->ipw == 2 && b->spec_fn ? 2 : 1 ) : -1; }
+
+
+/* rkfdBatchTuneInstancesPerWave: MEASURE which of the two mappings is faster for this world on this device at this batch
+ * size, and keep it.  The two give the same results to the last bit (tests/test_gpu_edge.py: two_instances_per_wavefront), so
+ * the choice changes the time of a step and nothing else.  The batch must hold a state to step from (rkfdBatchSetState +
+ * rkfdBatchUpdateInit); the state is put back as it was, an earlier rkfdBatchSnapshot is left alone.  Compiles both kernels
+ * (or takes them from the ahead-of-time store).  Returns the chosen count (1 or 2), -1 on error; ms[2] (may be NULL) gets
+ * the milliseconds of nsteps steps under either (ms[1] < 0: the world is not eligible for two - rkfdLastError says why).
+ * Which wins is a property of the world: two instances per wavefront halve the instructions issued per step, but not the
+ * LDS an instance holds, so they win where the step is bound by instruction issue (config 1b, 2, 3: +20 %, +16 %, +5 %) and
+ * lose where it is bound by how many instances the LDS lets a CU hold (config 4: -4 %); profiles/r03_ipw_ab.txt. */
+static int tune_time(rkfdBatch *b, int nsteps, double *ms)
+{
+  hipEvent_t e0, e1;
+  HIPCHK( hipEventCreate( &e0 ), -1 ); HIPCHK( hipEventCreate( &e1 ), -1 );
+  int r = 0;
+  float best = -1;
+  for( int rep=0; rep<3 && r == 0; rep++ ){      /* first pass: warm-up (code object upload, clocks); then the faster of two */
+    if( rkfdBatchRestore( b, NULL ) < 0 || rkfdBatchJoin( b, NULL ) < 0 ){ r = -1; break; }
+    if( hipEventRecord( e0, NULL ) != hipSuccess || rkfdBatchUpdate( b, nsteps, NULL ) < 0 || rkfdBatchJoin( b, NULL ) < 0
+        || hipEventRecord( e1, NULL ) != hipSuccess || hipEventSynchronize( e1 ) != hipSuccess ){ r = -1; break; }
+    float t = 0;
+    (void)hipEventElapsedTime( &t, e0, e1 );
+    if( rep > 0 && ( best < 0 || t < best ) ) best = t;
+  }
+  (void)hipEventDestroy( e0 ); (void)hipEventDestroy( e1 );
+  *ms = best;
+  return r;
+}
+extern "C" int rkfdBatchTuneInstancesPerWave(rkfdBatch *b, int nsteps, double *ms)
+{
+  if( !b || nsteps < 1 ){ SETERR( "rkfdBatchTuneInstancesPerWave: bad arguments" ); return -1; }
+  HIPCHK( hipSetDevice( b->device ), -1 );
+  double t[2] = { -1, -1 };
+  if( ms ){ ms[0] = ms[1] = -1; }
+  /* the caller's snapshot steps aside for the one the measurement restores from */
+  const rkfdDevState keep = b->snap;
+  const int had = b->has_snap;
+  b->has_snap = 0; memset( &b->snap, 0, sizeof(b->snap) );
+  int r = rkfdBatchSnapshot( b );
+  int chosen = -1;
+  if( r == 0 ){
+    /* (a) what the batch has now, brought to one instance per wavefront */
+    if( b->spec_fn && b->ipw == 2 ){ (void)hipModuleUnload( b->spec_mod ); b->spec_mod = NULL; b->spec_fn = NULL; }
+    b->ipw = 1;
+    r = rkfdBatchSpecialize( b );
+    if( r == 0 ) r = tune_time( b, nsteps, &t[0] );
+  }
+  if( r == 0 ){
+    /* (b) two: set the first kernel aside, build the second */
+    hipModule_t mod1 = b->spec_mod; hipFunction_t fn1 = b->spec_fn;
+    b->spec_mod = NULL; b->spec_fn = NULL;
+    int two = rkfdBatchSetInstancesPerWave( b, 2 );
+    if( two == 0 ) two = rkfdBatchSpecialize( b );
+    if( two == 0 ) r = tune_time( b, nsteps, &t[1] );
+    if( two == 0 && r == 0 && t[1] < t[0] ){ (void)hipModuleUnload( mod1 ); chosen = 2; }
+    else{
+      if( b->spec_mod ) (void)hipModuleUnload( b->spec_mod );
+      b->spec_mod = mod1; b->spec_fn = fn1; b->ipw = 1;
+      if( r == 0 ) chosen = 1;
+    }
+  }
+  /* the state as it was, and the caller's snapshot back in place */
+  if( b->has_snap ){
+    if( rkfdBatchRestore( b, NULL ) < 0 || rkfdBatchJoin( b, NULL ) < 0 || hipDeviceSynchronize() != hipSuccess ) chosen = -1;
+    (void)hipFree( b->snap.dis ); (void)hipFree( b->snap.vel ); (void)hipFree( b->snap.acc );
+    (void)hipFree( b->snap.piv_type ); (void)hipFree( b->snap.piv_prev ); (void)hipFree( b->snap.brk );
+    (void)hipFree( b->snap.cv_active ); (void)hipFree( b->snap.cv_type ); (void)hipFree( b->snap.cv_ref ); (void)hipFree( b->snap.cv_f );
+  }
+  b->snap = keep; b->has_snap = had;
+  if( ms ){ ms[0] = t[0]; ms[1] = t[1]; }
+  return chosen;
 }
 
 extern "C" int rkfdBatchSetSplit(rkfdBatch *b, int nsplit)

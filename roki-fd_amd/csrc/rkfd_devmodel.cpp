@@ -31,6 +31,10 @@ struct Blob {
 
 extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevModelHost *out, char *err, int errlen)
 {
+  return rkfd_devmodel_build_w( m, max_rigid, 8, out, err, errlen );
+}
+extern "C" int rkfd_devmodel_build_w(const rkfdModel *m, int max_rigid, const int NG, rkfdDevModelHost *out, char *err, int errlen)
+{
   const int NLm = m->nlink, ND = m->ndof, NC = m->ncand;
   std::vector<int> R_parent, R_jtype, R_dofoff, R_mtype;
   std::vector<double> R_org;
@@ -129,6 +133,7 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
     }
   }
   const int NL = (int)orig.size();
+  if( NG != 8 && NG != 4 ) FAIL( "ngroup must be 8 or 4" );
   if( NL > RKFD_MAX_LINK ) FAIL( "nlink %d (after merging fixed links) exceeds the per-wave limit %d", NL, RKFD_MAX_LINK );
   std::vector<double> R_mass( NL, 0.0 ), R_com( (size_t)3*NL, 0.0 ), R_inertia( (size_t)9*NL, 0.0 );
   for( int r=0; r<NL; r++ ){
@@ -446,34 +451,78 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   int nsched = 0, npool = 0, nfloat = 0;
   {
     std::vector<int> slot( NL, -1 ), iter( NL, -1 );
-    std::vector<std::vector<int> > iters;          /* iteration -> 8 slots -> link */
+    std::vector<std::vector<int> > iters;          /* iteration -> NG slots -> link */
     std::vector<int> level_first_iter( nlevel+1, 0 );
+    if( NG == 8 ){
     /* assign slots bottom-up */
-    std::vector<std::vector<std::vector<int> > > per_level( nlevel );
-    for( int d=nlevel-1; d>=0; d-- ){
-      const int n = level_off[d+1] - level_off[d];
-      const int nch = ( n + 7 ) / 8;
-      per_level[d].assign( nch, std::vector<int>( 8, -1 ) );
-      std::vector<int> rest;
-      for( int k=level_off[d]; k<level_off[d+1]; k++ ){
-        const int i = level_link[k];
-        int pref = -1;
-        if( child_off[i+1] > child_off[i] ) pref = slot[child_idx[child_off[i]]];
-        if( nch == 1 && pref >= 0 && per_level[d][0][pref] < 0 ){ per_level[d][0][pref] = i; slot[i] = pref; }
-        else rest.push_back( i );
+      std::vector<std::vector<std::vector<int> > > per_level( nlevel );
+      for( int d=nlevel-1; d>=0; d-- ){
+        const int n = level_off[d+1] - level_off[d];
+        const int nch = ( n + NG-1 ) / NG;
+        per_level[d].assign( nch, std::vector<int>( NG, -1 ) );
+        std::vector<int> rest;
+        for( int k=level_off[d]; k<level_off[d+1]; k++ ){
+          const int i = level_link[k];
+          int pref = -1;
+          if( child_off[i+1] > child_off[i] ) pref = slot[child_idx[child_off[i]]];
+          if( nch == 1 && pref >= 0 && per_level[d][0][pref] < 0 ){ per_level[d][0][pref] = i; slot[i] = pref; }
+          else rest.push_back( i );
+        }
+        int c = 0, sidx = 0;
+        for( size_t k=0; k<rest.size(); k++ ){
+          while( per_level[d][c][sidx] >= 0 ){ sidx++; if( sidx == NG ){ sidx = 0; c++; } }
+          per_level[d][c][sidx] = rest[k]; slot[rest[k]] = sidx;
+        }
       }
-      int c = 0, sidx = 0;
-      for( size_t k=0; k<rest.size(); k++ ){
-        while( per_level[d][c][sidx] >= 0 ){ sidx++; if( sidx == 8 ){ sidx = 0; c++; } }
-        per_level[d][c][sidx] = rest[k]; slot[rest[k]] = sidx;
-      }
-    }
-    for( int d=0; d<nlevel; d++ )
-      for( size_t c=0; c<per_level[d].size(); c++ ){
-        for( int g=0; g<8; g++ ) if( per_level[d][c][g] >= 0 ) iter[per_level[d][c][g]] = nsched;
-        iters.push_back( per_level[d][c] );
+      for( int d=0; d<nlevel; d++ )
+        for( size_t c=0; c<per_level[d].size(); c++ ){
+          for( int g=0; g<NG; g++ ) if( per_level[d][c][g] >= 0 ) iter[per_level[d][c][g]] = nsched;
+          iters.push_back( per_level[d][c] );
+          nsched++;
+        }
+    } else {
+      /* Fewer lane groups than the widest level has links (two instances per wavefront: four groups): a level-by-level schedule
+       * would split such levels over several iterations and break the register hand-offs along chains (a child's Ia stays in its
+       * group's registers only when its parent follows in the very next iteration, in the same group) - on the humanoid 22 of 25
+       * links would then stage their Ia in LDS (4.9 KB more per instance: 8 instead of 10 instances per CU).  The sweeps need no
+       * levels, only a topological order (a parent after all its children in sweep 2, before them in sweep 3), so the links are
+       * LIST-scheduled here: every group follows a chain as far as it goes - the link it processed last hands over to one of its
+       * children in the next iteration -, free groups take the ready link with the longest chain below it. */
+      std::vector<int> height( NL, 1 );
+      for( int i=NL-1; i>=0; i-- ) if( R_parent[i] >= 0 && height[i]+1 > height[R_parent[i]] ) height[R_parent[i]] = height[i]+1;
+      std::vector<int> prev( NG, -1 );
+      int left = NL;
+      while( left > 0 ){
+        std::vector<int> cur( NG, -1 );
+        /* continue the chains */
+        for( int g=0; g<NG; g++ ){
+          const int p = prev[g];
+          if( p < 0 ) continue;
+          int best = -1;
+          for( int c=child_off[p]; c<child_off[p+1]; c++ ){
+            const int ch = child_idx[c];
+            if( iter[ch] < 0 && ( best < 0 || height[ch] > height[best] ) ) best = ch;
+          }
+          if( best >= 0 ){ cur[g] = best; iter[best] = nsched; slot[best] = g; left--; }
+        }
+        /* free groups: ready links (parent done in an EARLIER iteration, or no parent), longest chain first */
+        for( int g=0; g<NG; g++ ){
+          if( cur[g] >= 0 ) continue;
+          int best = -1;
+          for( int i=0; i<NL; i++ ){
+            if( iter[i] >= 0 ) continue;
+            const int p = R_parent[i];
+            if( p >= 0 && ( iter[p] < 0 || iter[p] >= nsched ) ) continue;
+            if( best < 0 || height[i] > height[best] ) best = i;
+          }
+          if( best < 0 ) break;
+          cur[g] = best; iter[best] = nsched; slot[best] = g; left--;
+        }
+        iters.push_back( cur );
+        prev = cur;
         nsched++;
       }
+    }
     /* two empty iterations before and after the real ones: the sweeps prefetch records two
      * iterations ahead and read the padding instead of branching */
     /* pool slots: a non-float link with a parent needs its Ia staged in LDS unless the parent takes
@@ -495,7 +544,7 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
       }
     }
     for( int t=-2; t<nsched+2; t++ )
-      for( int g=0; g<8; g++ ){
+      for( int g=0; g<NG; g++ ){
         int rec[4] = { -1, 0, 0, 0 };
         const int i = ( t >= 0 && t < nsched ) ? iters[t][g] : -1;
         if( i >= 0 ){
@@ -527,7 +576,7 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   dm.nlink = NL; dm.nlink_model = NLm; dm.ndof = ND; dm.ncand = NC; dm.nlevel = nlevel; dm.nround = nround; dm.nci = m->nci;
   dm.solver = m->solver; dm.max_iter = m->max_iter; dm.maxrg = max_rigid;
   dm.dt = m->dt; dm.fric_w = m->friction_weight;
-  dm.nsched = nsched; dm.npool = npool; dm.nfloat = nfloat;
+  dm.nsched = nsched; dm.npool = npool; dm.nfloat = nfloat; dm.ngroup = NG;
   dm.has_brf = has_brf;
   dm.anchor = -1;
   for( int i=0; i<NL; i++ ) if( !is_static[i] ){ dm.anchor = i; break; }
@@ -639,7 +688,7 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
   for( int pass=0; pass<2; pass++ ){
     if( pass == 1 ){
       const size_t Mr = 3*(size_t)max_rigid;
-      if( dm.vert_rigid || max_rigid <= 0 || vol_np > 0 ) break;
+      if( dm.vert_rigid || max_rigid <= 0 || vol_np > 0 || NG != 8 ) break;      /* (two instances per wavefront: full rows) */
       dm.ma_packed = 1; dm.ma_size = (int)( Mr*( Mr+1 )/2 );
     }
     const size_t M = 3*(size_t)max_rigid;
@@ -647,7 +696,7 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
     size_t stage = (size_t)14*NL + pool;                         /* inertia staging + Ia pool ...   */
     if( (size_t)dm.ma_size > stage ) stage = (size_t)dm.ma_size;   /* ... shared with the contact matrix */
     const size_t dbl = (size_t)NL*( 5*6 + 3 ) + stage + (size_t)33*nfloat
-                     + (size_t)maxact*( 21 + ( NC > RKFD_WAVE ? 3 : 0 ) + ( dm.has_slide ? 6 : 0 ) ) + ( ( dm.vert_rigid || vol_np > 0 ) ? 2 : 1 )*M + ( dm.pu_alias ? 0 : (size_t)nside*npurow*M )
+                     + (size_t)maxact*( 21 + ( NC > RKFD_WAVE/2 ? 3 : 0 ) + ( dm.has_slide ? 6 : 0 ) ) + ( ( dm.vert_rigid || vol_np > 0 ) ? 2 : 1 )*M + ( dm.pu_alias ? 0 : (size_t)nside*npurow*M )
                      + ( dm.vert_rigid ? M*M + M*( M+1 )/2 + 5*M + ( dm.qscr_alias ? 0 : RKFD_WAVE ) + 3*M : 0 )   /* Vert QP: QL, QW, QV, CR */
                      + ( vol_np > 0 ? (size_t)RKFD_VOL_LDS_DOUBLES( vol_np, vol_ncp, vol_pv, vol_nf, dm.pyramid ) : 0 );
     const size_t ints = (size_t)NC + (size_t)nside*maxact + ( vol_np > 0 ? 12 + 2*vol_np : ( NC > 0 ? 8 : 4 ) ) + (size_t)NL     /* CIp, tgt, cnt (VI), LI */
@@ -667,6 +716,12 @@ extern "C" int rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevMod
                NL, ND, NC, nlevel, npool, nfloat, maxact, nside, npurow, dm.pu_alias, (int)M, stage, (size_t)14*NL + pool, dm.vert_rigid, out->lds_bytes );
   }
   out->dm.ma_packed = dm.ma_packed; out->dm.ma_size = dm.ma_size;
+  out->dm.lds_instance = (int)out->lds_bytes;
+  if( NG == 4 ){
+    /* two instances per wavefront: everything that is one lane per item must fit the 32 lanes of an instance */
+    if( NL > 32 || ND > 32 || dm.maxact > 32 || max_rigid > 16 || dm.vert_rigid || vol_np > 0 )
+      FAIL( "two instances per wavefront need a world of at most 32 links, 32 joint coordinates, 32 contact slots and 16 rigid contact vertices, without the Vert QP / the Volume plugin (this one: %d links, %d coordinates, %d slots, max_rigid %d)", NL, ND, dm.maxact, max_rigid );
+  }
   { const char *e = getenv( "RKFD_DEBUG_POISON_LDS" ); out->dm.lds_poison = ( e && atoi( e ) > 0 ) ? (int)( out->lds_bytes/4 ) : 0; }
   return 0;
 #undef FAIL

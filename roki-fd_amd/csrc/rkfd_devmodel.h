@@ -8,6 +8,16 @@
 #define RKFD_DEVMODEL_H
 
 #define RKFD_WAVE        64
+/* INSTANCES PER WAVEFRONT (round 3).  RKFD_W = 1: one instance has the wavefront's 64 lanes (every kernel of the library).
+ * RKFD_W = 2: two instances share a wavefront, 32 lanes each - a build of the SAME device code in which LANE() counts within the
+ * instance's half, loops stride over RKFD_WL lanes, BALLOT / BCAST act within the half, every LDS pointer and the instance index
+ * are per-lane values, and the sweeps take four links of a level per iteration (the device model is built with ngroup = 4).  It exists as a world-specific
+ * kernel only (rkfdBatchSpecialize with rkfdBatchSetInstancesPerWave( b, 2 )), for worlds whose links, joint coordinates and
+ * contact capacity fit 32 lanes and that do not use the Vert QP or the Volume plugin. */
+#ifndef RKFD_W
+#define RKFD_W 1
+#endif
+#define RKFD_WL ( RKFD_WAVE/RKFD_W )      /* lanes of one instance */
 #define RKFD_MAX_LINK    64
 #define RKFD_MAX_DOF     64
 #define RKFD_MAX_CAND    4096 /* candidate contact vertices per instance (swept 64 at a time; 9 bytes of LDS each) */
@@ -76,6 +86,8 @@ typedef struct {
    *   {link (-1 none), linfo[link], nchild | flags<<8 | (pool slot+1)<<16 | (float slot+1)<<24, child_off[link]} */
   int nsched;
   const int *sched;
+  int ngroup;            /* lane groups (links) per sweep iteration the schedule was built for: 8, or 4 for two instances per wavefront */
+  int lds_instance;      /* bytes of LDS one instance owns (the second instance of a wavefront starts that far in) */
   int npool;             /* links whose articulated inertia must be staged in LDS for a gathering parent */
   int nfloat;            /* float joints (each owns a 6x6 Cholesky slot and a saved frame)          */
   const int *pslot;      /* [nlink] pool slot of the link, -1 when its Ia is handed over in registers */

@@ -30,6 +30,10 @@ void rkfd_ref_to_model(const rkfdDevModelHost *h, double *ref, size_t n);
 
 /* max_rigid: capacity of rigid contact vertices solved per instance */
 int  rkfd_devmodel_build(const rkfdModel *m, int max_rigid, rkfdDevModelHost *out, char *err, int errlen);
+/* the same for a kernel with 8 / ngroup instances per wavefront: ngroup = 8 (one instance, the default) or 4 (two instances: the
+ * sweep schedule takes four links of a level per iteration; the world must fit 32 lanes - links, joint coordinates, contact
+ * slots - and use neither the Vert QP nor the Volume plugin, else the call fails with a message) */
+int  rkfd_devmodel_build_w(const rkfdModel *m, int max_rigid, int ngroup, rkfdDevModelHost *out, char *err, int errlen);
 void rkfd_devmodel_free(rkfdDevModelHost *h);
 /* shift every pointer of dm from the blob at `from` to its copy at `to` */
 void rkfd_devmodel_rebase(rkfdDevModel *dm, const void *from, const void *to);

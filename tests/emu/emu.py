@@ -10,6 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 LIB_PATH = os.environ.get("RKFD_EMU_LIB", os.path.join(HERE, "librkfd_emu.so"))      # (RKFD_EMU_LIB: a sanitizer build, tools/emu_asan.sh)
 _lib = None
+_lib_w2 = None
+LIB_PATH_W2 = os.path.join(HERE, "librkfd_emu_w2.so")
 
 
 class DevState(C.Structure):
@@ -29,11 +31,24 @@ def lib():
     return _lib
 
 
+def lib_w2():
+    """the harness built with RKFD_W = 2: two instances per emulated wavefront, 32 lanes each"""
+    global _lib_w2
+    if _lib_w2 is None:
+        if not os.path.exists(LIB_PATH_W2):
+            subprocess.run(["make", "-C", ROOT, "emu"], check=True, stdout=subprocess.DEVNULL)
+        L = C.CDLL(LIB_PATH_W2)
+        L.rkfd_emu_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(DevState), C.c_int, C.c_int]
+        _lib_w2 = L
+    return _lib_w2
+
+
 class EmuBatch:
     """Same surface as roki_fd_amd.Batch, backed by the emulator."""
 
-    def __init__(self, world, batch, max_rigid=8):
+    def __init__(self, world, batch, max_rigid=8, ipw=1):
         self.world = world
+        self.ipw = ipw                      # instances per emulated wavefront (1 or 2)
         m = world.model.contents
         self.B, self.ndof, self.nlink, self.ncand = batch, m.ndof, m.nlink, m.ncand
         self.max_rigid = max_rigid
@@ -53,7 +68,7 @@ class EmuBatch:
             setattr(st, k, getattr(self, k).ctypes.data)
         st.dbg_stride = 18 * self.nlink
         st.batch = self.B
-        self.err = lib().rkfd_emu_run(C.cast(self.world.model, C.c_void_p), self.max_rigid, C.byref(st), mode, nsteps)
+        self.err = (lib_w2() if self.ipw == 2 else lib()).rkfd_emu_run(C.cast(self.world.model, C.c_void_p), self.max_rigid, C.byref(st), mode, nsteps)
         if self.err < 0:
             raise RuntimeError("emulator: device model build failed")
 

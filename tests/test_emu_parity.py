@@ -463,3 +463,34 @@ def test_emulated_breakable_float_joints(R, oracle_cls):
             assert (act[i] == oact).all()
             assert np.abs(f[i] - of).max() / max(1.0, np.abs(of).max()) < 1e-9
     assert events >= 2 and all(sum(l) == 2 for l in last)          # the third brick's joint broke DURING the run, the first brick's held
+
+
+@pytest.mark.parametrize("cfg,B,nsteps", [("config2", 3, 2), ("config3", 3, 2), ("config4", 3, 2), ("config1b", 2, 2), ("arm_press", 3, 3)])
+def test_emulated_two_instances_per_wavefront(R, oracle_cls, cfg, B, nsteps):
+    """RKFD_W = 2 (rkfd_devmodel.h): two instances share a wavefront, 32 lanes each, four sweep lane groups and the list
+    schedule.  Results must be those of one instance per wavefront to the last bit (same operations per instance, the cross-lane
+    sums in the same association), an odd batch leaves the last wavefront half empty, and the oracle agrees as before."""
+    sc = R.scenarios.arm_press(batch=B) if cfg == "arm_press" else R.scenarios.CONFIGS[cfg](batch=B)
+    if cfg in ("config3", "config4"):
+        # the two halves of a wavefront must be free to take different branches: different contact counts per instance
+        sc["dis"] = sc["dis"].copy(); sc["dis"][1::2, 2] += 0.004
+    out = []
+    for ipw in (1, 2):
+        eb = EmuBatch(sc["world"], B, max_rigid=sc["max_rigid"], ipw=ipw)
+        eb.set_state(sc["dis"], sc["vel"])
+        if "motor_in" in sc:
+            eb.set_motor_input(sc["motor_in"])
+        eb.update_init(); eb.update(nsteps)
+        assert eb.status() == 0
+        out.append(eb.get_state() + eb.get_contact())
+    for x, y in zip(*out):
+        assert np.array_equal(x, y)
+    dis, vel, acc = out[1][:3]
+    for i in range(B):
+        o = oracle_cls(sc["world"].model)
+        o.set_state(sc["dis"][i], sc["vel"][i])
+        if "motor_in" in sc:
+            o.set_motor_input(sc["motor_in"][i])
+        o.update_init(); o.update_n(nsteps)
+        for x, y in zip((dis[i], vel[i], acc[i]), o.get_state()):
+            assert np.abs(x - y).max() / max(1.0, np.abs(y).max()) < 1e-9

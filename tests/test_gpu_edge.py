@@ -749,3 +749,72 @@ def test_c_arm_wall_driver(R, oracle_cls, tmp_path, plugin):
     assert o.get_broken()[w.link_offset(wl):w.link_offset(wl) + 4].tolist() == [0, 0, 1, 1]      # base, brick 1 (holds), bricks 2 and 3
     assert np.abs(od[ow + 6:ow + 18]).max() > (1e-3 if plugin == "mlcp" else 1e-5)                # the loose bricks have moved
     assert np.abs(arm - od[:4]).max() < 1e-6 and np.abs(wall - od[ow:ow + 18]).max() < 1e-6
+
+
+@pytest.mark.parametrize("cfg", ["config2", "config3", "config4", "config1b", "arm_press"])
+def test_two_instances_per_wavefront_are_bit_identical(R, cfg):
+    """RKFD_W = 2 (rkfd_devmodel.h): the world-specific kernel built with two instances per wavefront - 32 lanes each, per-lane LDS
+    base and instance index, ballots and broadcasts within the half, four links of a level per sweep iteration - gives bit for bit
+    the states, accelerations, contact sets and contact forces of one instance per wavefront.  Odd batch: the last wavefront's
+    second half is a stand-in that stores nothing."""
+    B, nsteps = 37, 12
+    sc = R.scenarios.arm_press(batch=B) if cfg == "arm_press" else R.scenarios.CONFIGS[cfg](batch=B)
+    out = []
+    for ipw in (1, 2):
+        b = R.Batch(sc["world"], B, max_rigid=sc["max_rigid"])
+        b.set_instances_per_wave(ipw); b.specialize()
+        assert b.instances_per_wave() == ipw
+        b.set_state(sc["dis"], sc["vel"])
+        if "motor_in" in sc:
+            b.set_motor_input(sc["motor_in"])
+        b.set_split(3 if ipw == 2 else 1)
+        b.update_init(); b.update(nsteps)
+        assert b.status() == 0
+        out.append((b.get_state(), b.get_contact(), b.get_pivot()))
+    for x, y in zip(out[0][0] + out[0][1] + out[0][2], out[1][0] + out[1][1] + out[1][2]):
+        assert np.array_equal(x, y)
+
+
+def test_two_instances_per_wavefront_need_a_small_world(R):
+    sc = R.scenarios.config5(batch=2)
+    b = R.Batch(sc["world"], 2, max_rigid=sc["max_rigid"])
+    with pytest.raises(R.RkfdError, match="two instances per wavefront need"):
+        b.set_instances_per_wave(2)
+    assert b.instances_per_wave() == 1
+
+
+@pytest.mark.gpu
+def test_tuning_the_instances_per_wavefront_keeps_state_and_snapshot(R):
+    """rkfdBatchTuneInstancesPerWave: measures both mappings from the batch's state and keeps the faster; the state, the pivots and
+    an earlier snapshot are as before, and the steps taken afterwards are those of an untuned batch to the last bit.  A world that
+    is not eligible for two comes back with 1 and no second time."""
+    B, nsteps = 300, 10
+    sc = R.scenarios.config3(batch=B)
+    ref = R.Batch(sc["world"], B, max_rigid=sc["max_rigid"])
+    ref.set_state(sc["dis"], sc["vel"]); ref.update_init(); ref.update(3)
+    at3 = ref.get_state()
+    ref.update(nsteps)
+    want = ref.get_state() + ref.get_contact()
+
+    b = R.Batch(sc["world"], B, max_rigid=sc["max_rigid"])
+    b.set_state(sc["dis"], sc["vel"]); b.update_init()
+    b.snapshot()                              # the caller's snapshot: after rkFDUpdateInit
+    b.update(3)
+    chosen, ms = b.tune_instances_per_wave(5)
+    assert chosen in (1, 2) and ms[0] > 0 and ms[1] > 0
+    assert b.instances_per_wave() == chosen
+    for x, y in zip(b.get_state(), at3):
+        assert np.array_equal(x, y)
+    b.update(nsteps)
+    assert b.status() == 0
+    for x, y in zip(b.get_state() + b.get_contact(), want):
+        assert np.array_equal(x, y)
+    b.restore(); b.update(3)                  # the caller's snapshot survived the measurement
+    for x, y in zip(b.get_state(), at3):
+        assert np.array_equal(x, y)
+
+    sc = R.scenarios.config5(batch=4)
+    b = R.Batch(sc["world"], 4, max_rigid=sc["max_rigid"])
+    b.set_state(sc["dis"], sc["vel"]); b.update_init()
+    chosen, ms = b.tune_instances_per_wave(2)
+    assert chosen == 1 and ms[0] > 0 and ms[1] < 0 and b.instances_per_wave() == 1

@@ -20,3 +20,8 @@ for nm in names:
     if n <= 0:
         print("%-16s FAILED: %s" % (nm, L.rkfdHipLastError().decode())); sys.exit(1)
     print("%-16s %6d bytes  %s  (%.1f s)" % (nm, n, "already in the store" if L.rkfdSpecializeLastFromStore() else "compiled", time.time() - t0), flush=True)
+    # the kernel with two instances per wavefront, for the worlds eligible for it (rkfdBatchTuneInstancesPerWave picks by measurement)
+    t0 = time.time()
+    n = L.rkfdSpecializeCompileW(sc["world"].model, sc["max_rigid"], 2)
+    if n > 0:
+        print("%-16s %6d bytes  %s  (%.1f s)  [two instances per wavefront]" % (nm, n, "already in the store" if L.rkfdSpecializeLastFromStore() else "compiled", time.time() - t0), flush=True)

@@ -19,13 +19,13 @@ def world(name):
     return getattr(S, name)(batch=1)
 
 
-def resources(sc):
-    """dict(vgpr, sgpr, scratch, vgpr_spill, sgpr_spill, lds) of the specialised kernel of scenario sc"""
+def resources(sc, ipw=1):
+    """dict(vgpr, sgpr, scratch, vgpr_spill, sgpr_spill, lds) of the specialised kernel of scenario sc (ipw instances per wavefront)"""
     with tempfile.TemporaryDirectory() as d:
         co = os.path.join(d, "k.co")
         os.environ["RKFD_SPEC_DUMP_CODE"] = co
         try:
-            n = R.lib().rkfdSpecializeCompile(sc["world"].model, sc["max_rigid"])
+            n = R.lib().rkfdSpecializeCompileW(sc["world"].model, sc["max_rigid"], ipw)
         finally:
             del os.environ["RKFD_SPEC_DUMP_CODE"]
         if n <= 0:
@@ -37,5 +37,6 @@ def resources(sc):
 
 
 if __name__ == "__main__":
-    for nm in sys.argv[1:] or ["config2", "config3", "config4", "config4v", "config5", "arm_press", "arm_press_rev", "arm_fold"]:
-        print("%-14s %s" % (nm, resources(world(nm))), flush=True)
+    for nm in sys.argv[1:] or ["config2", "config3", "config4", "config4v", "config5", "arm_press", "arm_press_rev", "arm_fold", "config2:2", "config3:2", "config4:2"]:
+        w_, _, ipw = nm.partition(":")
+        print("%-14s %s" % (nm, resources(world(w_), int(ipw or 1))), flush=True)
