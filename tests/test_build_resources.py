@@ -44,7 +44,9 @@ def test_kernel_fits_three_waves_per_simd_without_scratch(name):
     # whole kernel, none inside a sweep - the notes and the disassembly of the code object RKFD_SPEC_DUMP_CODE writes); config 4's
     # has none (154 VGPRs)
     pk = name.endswith("_pk")
-    assert k["VGPRs Spill"] <= (8 if pk else 0), k
+    # (the DIAGNOSTIC instantiation - phase-cycle counters, rkfdBatchProfile only - carries their stamps on top: two registers
+    # spilled since the live flag of two instances per wavefront joined the launch arguments; it is never a timed kernel)
+    assert k["VGPRs Spill"] <= (8 if pk else 2 if name == "rkfd_step_kernel_prof" else 0), k
     # otherwise no vector register is spilled; a few bytes of private segment may still be reserved for a stack object whose
     # accesses were optimised away (seen: 20 bytes in one variant, no scratch instruction in its code)
     assert k["ScratchSize"] <= (40 if pk else 32), k
