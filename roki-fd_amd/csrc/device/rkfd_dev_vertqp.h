@@ -21,6 +21,9 @@ template<bool pk> RKFD_DEV void rkfd_w_chol(double *Mx, int ld, int n)
     double s = 0;
     if( lane >= k && lane < n ){
       s = Mx[RKFD_WI( lane, k )];
+      /* (unrolled: the loads of several terms go out together - the loop is bound by the latency of LDS, not by its arithmetic;
+       *  the order of the subtractions stays) */
+#pragma unroll 8
       for( int j=0; j<k; j++ ) s -= Mx[RKFD_WI( lane, j )]*Mx[RKFD_WI( k, j )];
     }
     const double rinv = RKFD_RCP( sqrt( BCAST( s, k ) ) );
@@ -56,38 +59,94 @@ template<bool pk> RKFD_DEV double rkfd_w_back(const double *Mx, int ld, int n, d
 #undef RKFD_WI
 /* entry (r, c <= r) of the packed factor of Q */
 #define RKFD_QI(r,c) ( ( ( (r)*( (r)+1 ) ) >> 1 ) + (c) )
-/* minimum / sum over the wave through a 64-entry LDS scratch (log-depth tree) */
-RKFD_DEV double rkfd_w_min(double v, double *scr)
+
+/* ---- the factor of Q in REGISTERS -----------------------------------------------------------------------------------------
+ * One step under the Vert plugin is a dependent chain, not a throughput problem: at ONE instance per CU it takes as long as at
+ * seven (profiles/r03_vert_qp.txt), and most of that chain were the triangular solves with the factor of Q read from LDS term by
+ * term - the forward substitution for W = L^-1 C' with lane = column walked all n(n+1)/2 entries one after the other whatever the
+ * number of columns (15 k cycles per KKT solve for typically 0 .. 2 columns).  With at most RKFD_QP_NQ = 24 unknowns (8 contact
+ * vertices) lane i keeps row i of L (for L^-1) and column i (for L^-T) in registers for the whole QP; a substitution is then
+ * n steps of { multiply, v_readlane, fma } with nothing to wait for, and a column of W costs one such pass - two columns share
+ * a pass (independent chains in the same instructions).  The arithmetic per entry - operands and order - is that of the routines
+ * above, so the results are the same bits.  Worlds with a larger capacity, and the kernels not compiled for one world, keep the
+ * LDS routines. */
+#ifndef RKFD_QP_NQ
+#  if defined(RKFD_EMU)
+#    define RKFD_QP_NQ 24
+#  elif defined(RKFD_SPEC)
+#    define RKFD_QP_NQ ( ( RKFD_SPEC_VERT_RIGID && 3*RKFD_SPEC_MAXRG <= 24 ) ? 3*RKFD_SPEC_MAXRG : 0 )
+#  else
+#    define RKFD_QP_NQ 0
+#  endif
+#endif
+#define RKFD_QP_NQA ( RKFD_QP_NQ > 0 ? RKFD_QP_NQ : 1 )
+typedef struct {
+  double Lr[RKFD_QP_NQA];      /* L[lane][j], j < lane (else 0) */
+  double Lt[RKFD_QP_NQA];      /* L[j][lane], j > lane (else 0) */
+  double rd;                   /* 1 / L[lane][lane] */
+} rkfdQpFactor;
+RKFD_DEV void rkfd_qreg_load(rkfdQpFactor &F, const double *Q, int n)
 {
   const int lane = LANE();
-  scr[lane] = v;
-  SYNC();
-  for( int h=RKFD_WAVE/2; h>0; h>>=1 ){
-    double a = 0, b = 0;
-    if( lane < h ){ a = scr[lane]; b = scr[lane+h]; }
-    SYNC();
-    if( lane < h ) scr[lane] = a < b ? a : b;
-    SYNC();
+  const int base = ( lane*( lane+1 ) ) >> 1;
+#pragma unroll
+  for( int j=0; j<RKFD_QP_NQ; j++ ){
+    F.Lr[j] = ( j < lane && lane < n ) ? Q[base + j] : 0.0;
+    F.Lt[j] = ( j > lane && j < n ) ? Q[RKFD_QI( j, lane )] : 0.0;
   }
-  const double r = scr[0];
-  SYNC();
-  return r;
+  F.rd = lane < n ? Q[base + lane] : 0.0;
 }
-RKFD_DEV double rkfd_w_sum(double v, double *scr)
+/* y = L^-1 b for two right-hand sides at once (lane i passes b_i, receives y_i); rows above j0 are known to be zero in both */
+RKFD_DEV void rkfd_qreg_fwd2(const rkfdQpFactor &F, int n, int j0, double &a, double &b)
 {
   const int lane = LANE();
-  scr[lane] = v;
-  SYNC();
-  for( int h=RKFD_WAVE/2; h>0; h>>=1 ){
-    double a = 0, b = 0;
-    if( lane < h ){ a = scr[lane]; b = scr[lane+h]; }
-    SYNC();
-    if( lane < h ) scr[lane] = a + b;
-    SYNC();
+  double sa = a, sb = b, ya = 0, yb = 0;
+#pragma unroll
+  for( int j=0; j<RKFD_QP_NQ; j++ ){
+    if( j >= j0 && j < n ){
+      const double pa = BCAST( sa*F.rd, j ), pb = BCAST( sb*F.rd, j );
+      if( lane == j ){ ya = pa; yb = pb; }
+      sa = fma( -F.Lr[j], pa, sa ); sb = fma( -F.Lr[j], pb, sb );
+    }
   }
-  const double r = scr[0];
-  SYNC();
-  return r;
+  a = ya; b = yb;
+}
+RKFD_DEV double rkfd_qreg_fwd(const rkfdQpFactor &F, int n, double bi)
+{
+  const int lane = LANE();
+  double s = bi, yi = 0;
+#pragma unroll
+  for( int j=0; j<RKFD_QP_NQ; j++ ){
+    if( j < n ){
+      const double yj = BCAST( s*F.rd, j );
+      if( lane == j ) yi = yj;
+      s = fma( -F.Lr[j], yj, s );
+    }
+  }
+  return yi;
+}
+/* x = L^-T y */
+RKFD_DEV double rkfd_qreg_back(const rkfdQpFactor &F, int n, double yi)
+{
+  const int lane = LANE();
+  double s = yi, xi = 0;
+#pragma unroll
+  for( int j=RKFD_QP_NQ-1; j>=0; j-- ){
+    if( j < n ){
+      const double xj = BCAST( s*F.rd, j );
+      if( lane == j ) xi = xj;
+      s = fma( -F.Lt[j], xj, s );
+    }
+  }
+  return xi;
+}
+/* ( L' v )_lane: v_lane / rd + sum over j > lane of L[j][lane] v_j, the terms in ascending j */
+RKFD_DEV double rkfd_qreg_ltv(const rkfdQpFactor &F, int n, double vi)
+{
+  double u = vi/F.rd;
+#pragma unroll
+  for( int j=0; j<RKFD_QP_NQ; j++ ) if( j < n ) u = fma( F.Lt[j], BCAST( vi, j ), u );
+  return u;
 }
 
 #ifndef RKFD_EMU
@@ -153,7 +212,6 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
   double *Q = L.QL, *W = L.QW;
   double *cv = L.QV, *zv = L.QV + n, *ans = L.QV + 2*n, *lam = L.QV + 3*n, *dv = L.QV + 4*n;
   double *xv = L.MB;                          /* the bias vector is dead once c = A'b is formed */
-  double *scr = m.qscr_alias ? L.AC : L.QV + 5*n;   /* reduction scratch: the link accelerations are dead until the delta sweep */
   const bool onc = lane < mc;                 /* this lane is a constraint */
   const int cc = onc ? lane/P : 0;            /* its contact */
 
@@ -190,6 +248,7 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
     const int t = t0 + lane, i = t/n, k = t - i*n;
     if( t < n*n && k <= i ){
       double s = 0;
+#pragma unroll 8
       for( int r=0; r<n; r++ ) s = fma( L.MA[r*ld+i], L.MA[r*ld+k], s );
       if( i == k ) s += m.ci_l[RKFD_CI_CI( L.CIp[L.lrg[i/3]] )];
       Q[RKFD_QI( i, k )] = s;
@@ -197,15 +256,22 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
   }
   if( lane < n ){
     double s = 0;
+#pragma unroll 8
     for( int r=0; r<n; r++ ) s = fma( L.MA[r*ld+lane], L.MB[r], s );
     cv[lane] = s;
     ans[lane] = ( lane%3 == 0 ) ? 1.0 : 0.0;           /* _rkFDSolverQPASMInit */
   }
   SYNC();
   rkfd_w_chol<true>( Q, 0, n );
+  /* the factor into registers where it fits (see rkfdQpFactor) */
+  const bool reg = RKFD_QP_NQ > 0 && 3*m.maxrg <= RKFD_QP_NQ;
+  rkfdQpFactor F;
+  F.rd = 0.0;
+  if( reg ){ SYNC(); rkfd_qreg_load( F, Q, n ); }
   /* z = L^-1 c */
   {
-    const double zi = rkfd_w_fwd<true>( Q, 0, n, lane < n ? cv[lane] : 0.0 );
+    const double ci = lane < n ? cv[lane] : 0.0;
+    const double zi = reg ? rkfd_qreg_fwd( F, n, ci ) : rkfd_w_fwd<true>( Q, 0, n, ci );
     if( lane < n ) zv[lane] = zi;
   }
   SYNC();
@@ -242,18 +308,32 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
       }
     }
     SYNC();
-    VST(25);
     /* W = L^-1 C' by forward substitution (lane = reduced row), S = W'W, rhs = W'z */
-    if( lane < r ){
+    if( reg ){
+      /* lane = row, two columns per pass */
+      for( int a0=0; a0<r; a0+=2 ){
+        const int a1 = a0+1 < r ? a0+1 : a0;
+        const int c30 = 3*L.CRC[a0], c31 = 3*L.CRC[a1];
+        double y0 = lane == c30 ? L.CR[3*a0] : ( lane == c30+1 ? L.CR[3*a0+1] : ( lane == c30+2 ? L.CR[3*a0+2] : 0.0 ) );
+        double y1 = lane == c31 ? L.CR[3*a1] : ( lane == c31+1 ? L.CR[3*a1+1] : ( lane == c31+2 ? L.CR[3*a1+2] : 0.0 ) );
+        rkfd_qreg_fwd2( F, n, c30 < c31 ? c30 : c31, y0, y1 );
+        if( lane < n ){
+          W[lane*ldq+a0] = lane < c30 ? 0.0 : y0;
+          if( a1 != a0 ) W[lane*ldq+a1] = lane < c31 ? 0.0 : y1;
+        }
+      }
+    } else if( lane < r ){
       const int c3 = 3*L.CRC[lane];
       const double h0 = L.CR[3*lane], h1 = L.CR[3*lane+1], h2 = L.CR[3*lane+2];
       for( int i=0; i<n; i++ ){
         double sacc = i == c3 ? h0 : ( i == c3+1 ? h1 : ( i == c3+2 ? h2 : 0.0 ) );
+#pragma unroll 8
         for( int j=c3; j<i; j++ ) sacc -= Q[RKFD_QI( i, j )]*W[j*ldq+lane];
         W[i*ldq+lane] = i < c3 ? 0.0 : sacc*Q[RKFD_QI( i, i )];
       }
     }
     SYNC();
+    VST(25);
     double *S = L.MA;
     /* (on the matrix cores this product gained nothing: 262 k -> 271 k cycles per step, profiles/r02_vert_mfma_ab.txt - with 2 .. 16
      * of 24 rows active it is a few passes of latency either way; the switch was removed in round 3) */
@@ -269,12 +349,16 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
          * the skipped terms are exact zeros, the sum is bit for bit the same */
         const int ca = L.CRC[a], cb = L.CRC[b];
         double sacc = 0;
+#pragma unroll 8
         for( int i=3*( ca > cb ? ca : cb ); i<n; i++ ) sacc = fma( W[i*ldq+a], W[i*ldq+b], sacc );
         S[a*ld+b] = sacc; S[b*ld+a] = sacc;
       }
     }
     double rl = 0;
-    if( lane < r ) for( int i=3*L.CRC[lane]; i<n; i++ ) rl = fma( W[i*ldq+lane], zv[i], rl );
+    if( lane < r ){
+#pragma unroll 8
+      for( int i=3*L.CRC[lane]; i<n; i++ ) rl = fma( W[i*ldq+lane], zv[i], rl );
+    }
     SYNC();
     VST(26);
     rkfd_w_chol<false>( S, ld, r );
@@ -289,10 +373,11 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
     {
       double ti = 0;
       if( lane < n ){
+#pragma unroll 8
         for( int a=0; a<r; a++ ) ti = fma( W[lane*ldq+a], lam[a], ti );
         ti -= zv[lane];
       }
-      const double xi = rkfd_w_back<true>( Q, 0, n, ti );
+      const double xi = reg ? rkfd_qreg_back( F, n, ti ) : rkfd_w_back<true>( Q, 0, n, ti );
       if( lane < n ) xv[lane] = xi;
     }
     SYNC();
@@ -328,7 +413,7 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
       }
       SYNC();
       if( BALLOT( onc && act && y < 0 ) == 0ull ) break;                 /* found the optimal solution */
-      const double ymin = rkfd_w_min( ( onc && act ) ? y : HUGE_VAL, scr );
+      const double ymin = WMIN( ( onc && act ) ? y : HUGE_VAL );
       if( onc && act && fabs( y - ymin ) < RKFD_QP_ASM_TOL ) act = 0;
       VST(29);
       continue;
@@ -341,7 +426,7 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
       const double gd = g0*dv[3*cc] + g1*dv[3*cc+1] + g2*dv[3*cc+2];
       if( gd < 0 ) tq = ( 0.0 - ( g0*ans[3*cc] + g1*ans[3*cc+1] + g2*ans[3*cc+2] ) )/gd;
     }
-    double tmin = rkfd_w_min( tq, scr );
+    double tmin = WMIN( tq );
     if( !( tmin < 1.0 ) ) tmin = 1.0;
 #if defined(RKFD_EMU) && defined(RKFD_QP_TRACE)
     if( lane == 0 ) printf( "dev    step t %.12e\n", tmin );
@@ -352,12 +437,18 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
     /* circulation check (degeneracy): same basis seen before with the same objective value.
      * f'Qf/2 = |L'f|^2/2 with the stored factor (diagonal kept as 1/L_ii) */
     double part = 0;
-    if( lane < n ){
+    if( reg ){
+      const double ai = lane < n ? ans[lane] : 0.0;
+      const double u = rkfd_qreg_ltv( F, n, ai );
+      if( lane < n ) part = 0.5*u*u + cv[lane]*ai;
+    } else if( lane < n ){
       double u = ans[lane]/Q[RKFD_QI( lane, lane )];
+#pragma unroll 8
       for( int j=lane+1; j<n; j++ ) u = fma( Q[RKFD_QI( j, lane )], ans[j], u );
       part = 0.5*u*u + cv[lane]*ans[lane];
     }
-    const double objv = rkfd_w_sum( part, scr );
+    /* (the sum only feeds the circulation check's comparison to 1e-8: its association is free) */
+    const double objv = WSUM( part );
     const unsigned long long nmask = BALLOT( act );
     const bool seen = lane < nhist && hmask == nmask && !( fabs( hobj/objv - 1.0 ) > RKFD_QP_ASM_TOL );
     if( BALLOT( seen ) != 0ull ){ mask = nmask; break; }

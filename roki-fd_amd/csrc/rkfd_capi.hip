@@ -486,7 +486,7 @@ static std::string spec_source(const rkfdDevModel &d, int ipw = 1)
     ipw, d.nlink, d.ndof, d.ncand, d.nlink_model, d.nlevel, d.nround, d.nsched, d.maxrg, d.npool, d.nfloat, d.maxact, d.nside,
     d.npurow, d.pu_d0, d.pu_alias, d.vert_rigid, d.qscr_alias, d.has_slide, d.ma_size, d.ma_packed, d.max_iter, d.solver, d.pyramid, d.anchor, d.mlcp_mfma,
     d.has_brf, d.lds_instance, d.vol_npair, d.vol_np, d.vol_ncp, d.vol_pv, d.vol_nf,
-    ( d.vol_np > 0 || ipw == 2 ) ? 2 : 3, d.vol_np > 0 ? "2" : ( d.vert_rigid ? "1" : "0" ), d.ma_packed ? "true" : "false" );
+    ( d.vol_np > 0 || ipw == 2 || ( d.vert_rigid && 3*d.maxrg <= 24 ) ) ? 2 : 3, d.vol_np > 0 ? "2" : ( d.vert_rigid ? "1" : "0" ), d.ma_packed ? "true" : "false" );
   std::string src;
   if( const char *pre = getenv( "RKFD_SPEC_DEFINE" ) ){      /* diagnostic: NAME[,NAME...] defined as 1 in front of the source */
     std::string names( pre ); size_t p0 = 0;
