@@ -439,7 +439,7 @@ RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int
   /* probe scratch: lives while the contact problem is set up and solved, when C and PA are dead */
   if( pu_alias ) L->PU = L->C; else { L->PU = d; d += nside*npurow*M; }
   L->QL = d; L->QW = d; L->QV = d; L->CR = d;
-  if( vert_rigid ){ L->QL = d; d += M*( M+1 )/2; L->QW = d; d += M*M; L->QV = d; d += 5*M + ( vert_rigid == 2 ? 0 : RKFD_WAVE ); L->CR = d; d += 3*M; }
+  if( vert_rigid ){ L->QL = d; d += M*( M+1 )/2; L->QW = d; if( vert_rigid != 2 ) d += M*M; L->QV = d; d += 5*M; L->CR = d; d += 3*M; }
   L->VD = d; L->VPL = d; L->VPOLY = d; L->VRED = d; L->VQL = d; L->VQW = d; L->VS = d; L->VEV = d; L->VQV = d; L->VLP = d;
   if( vol_np ){
     const int n = 6*vol_np, mc = vol_np*( 1+vol_ncp );

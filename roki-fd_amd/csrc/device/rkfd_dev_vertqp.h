@@ -71,12 +71,10 @@ template<bool pk> RKFD_DEV double rkfd_w_back(const double *Mx, int ld, int n, d
  * above, so the results are the same bits.  Worlds with a larger capacity, and the kernels not compiled for one world, keep the
  * LDS routines. */
 #ifndef RKFD_QP_NQ
-#  if defined(RKFD_EMU)
-#    define RKFD_QP_NQ 24
-#  elif defined(RKFD_SPEC)
-#    define RKFD_QP_NQ ( ( RKFD_SPEC_VERT_RIGID && 3*RKFD_SPEC_MAXRG <= 24 ) ? 3*RKFD_SPEC_MAXRG : 0 )
+#  if defined(RKFD_SPEC)
+#    define RKFD_QP_NQ ( RKFD_SPEC_VERT_RIGID == 2 ? 3*RKFD_SPEC_MAXRG : 0 )      /* (the world's own bound) */
 #  else
-#    define RKFD_QP_NQ 0
+#    define RKFD_QP_NQ RKFD_QP_NQ_MAX
 #  endif
 #endif
 #define RKFD_QP_NQA ( RKFD_QP_NQ > 0 ? RKFD_QP_NQ : 1 )
@@ -95,6 +93,30 @@ RKFD_DEV void rkfd_qreg_load(rkfdQpFactor &F, const double *Q, int n)
     F.Lt[j] = ( j > lane && j < n ) ? Q[RKFD_QI( j, lane )] : 0.0;
   }
   F.rd = lane < n ? Q[base + lane] : 0.0;
+}
+/* The Cholesky factorisation itself with lane = row in registers, right-looking: after the pivot of column k every later entry
+ * ( i, c ) of the lower triangle takes its term - l_ik l_ck, so an entry receives its terms in ascending k exactly as the
+ * left-looking rkfd_w_chol subtracts them (same operands, same order: same bits); the values a step needs from another lane come
+ * by v_readlane, nothing goes through LDS until the factor is stored at the end (packed, for the transposed read of
+ * rkfd_qreg_load).  24 k cycles of LDS round trips per QP became 6 k. */
+RKFD_DEV void rkfd_qreg_chol(double *Q, int n)
+{
+  const int lane = LANE();
+  const int base = ( lane*( lane+1 ) ) >> 1;
+  double R[RKFD_QP_NQA];
+#pragma unroll
+  for( int j=0; j<RKFD_QP_NQ; j++ ) R[j] = ( j <= lane && lane < n ) ? Q[base + j] : 0.0;
+#pragma unroll
+  for( int k=0; k<RKFD_QP_NQ; k++ ){
+    if( k < n ){
+      const double rinv = RKFD_RCP( sqrt( BCAST( R[k], k ) ) );
+      R[k] = lane == k ? rinv : R[k]*rinv;
+#pragma unroll
+      for( int c=k+1; c<RKFD_QP_NQ; c++ ) R[c] = fma( -R[k], BCAST( R[k], c ), R[c] );
+    }
+  }
+#pragma unroll
+  for( int j=0; j<RKFD_QP_NQ; j++ ) if( j <= lane && lane < n ) Q[base + j] = R[j];
 }
 /* y = L^-1 b for two right-hand sides at once (lane i passes b_i, receives y_i); rows above j0 are known to be zero in both */
 RKFD_DEV void rkfd_qreg_fwd2(const rkfdQpFactor &F, int n, int j0, double &a, double &b)
@@ -209,7 +231,11 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
   const int lane = LANE();
   const int n = 3*nc, ld = n+1, ldq = n;      /* ld: the matrix that held A (now S); ldq: Q's factor and W */
   const int P = m.pyramid, mc = P*nc;
-  double *Q = L.QL, *W = L.QW;
+  /* the factor in registers where it fits (see rkfdQpFactor; the host decides: m.vert_rigid == 2 <=> 3 maxrg <= RKFD_QP_NQ_MAX).
+   * The LDS of such a world has no W block: W takes the storage of A once Q and c are formed, and the Schur complement S (packed)
+   * that of the factor once the registers hold it. */
+  const bool reg = RKFD_QP_NQ > 0 && m.vert_rigid == 2;
+  double *Q = L.QL, *W = reg ? L.MA : L.QW;
   double *cv = L.QV, *zv = L.QV + n, *ans = L.QV + 2*n, *lam = L.QV + 3*n, *dv = L.QV + 4*n;
   double *xv = L.MB;                          /* the bias vector is dead once c = A'b is formed */
   const bool onc = lane < mc;                 /* this lane is a constraint */
@@ -229,7 +255,16 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
     d_sincos( 0.0 + ( -PI/P ), &s0, &c0 );
     if( onc ){ g0 = mu*c0; g1 = s1; g2 = c1; }
   }
-  /* q = A'A + L (lower triangle, packed by rows), c = A'c */
+  /* c = A'c first: with the factor in registers the Gram product below lands on A's own storage */
+  if( lane < n ){
+    double s = 0;
+#pragma unroll 8
+    for( int r=0; r<n; r++ ) s = fma( L.MA[r*ld+lane], L.MB[r], s );
+    cv[lane] = s;
+    ans[lane] = ( lane%3 == 0 ) ? 1.0 : 0.0;           /* _rkFDSolverQPASMInit */
+  }
+  SYNC();
+  /* q = A'A + L (lower triangle, packed by rows) */
 #ifndef RKFD_EMU
   if( ( m.mlcp_mfma & 4 ) && n <= 32 ){
     /* the Gram product on the matrix cores (v_mfma_f64_16x16x4_f64) into W's storage, free until the first iteration, then packed:
@@ -254,17 +289,8 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
       Q[RKFD_QI( i, k )] = s;
     }
   }
-  if( lane < n ){
-    double s = 0;
-#pragma unroll 8
-    for( int r=0; r<n; r++ ) s = fma( L.MA[r*ld+lane], L.MB[r], s );
-    cv[lane] = s;
-    ans[lane] = ( lane%3 == 0 ) ? 1.0 : 0.0;           /* _rkFDSolverQPASMInit */
-  }
   SYNC();
-  rkfd_w_chol<true>( Q, 0, n );
-  /* the factor into registers where it fits (see rkfdQpFactor) */
-  const bool reg = RKFD_QP_NQ > 0 && 3*m.maxrg <= RKFD_QP_NQ;
+  if( reg ) rkfd_qreg_chol( Q, n ); else rkfd_w_chol<true>( Q, 0, n );
   rkfdQpFactor F;
   F.rd = 0.0;
   if( reg ){ SYNC(); rkfd_qreg_load( F, Q, n ); }
@@ -334,7 +360,7 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
     }
     SYNC();
     VST(25);
-    double *S = L.MA;
+    double *S = reg ? Q : L.MA;      /* (reg: packed lower triangle) */
     /* (on the matrix cores this product gained nothing: 262 k -> 271 k cycles per step, profiles/r02_vert_mfma_ab.txt - with 2 .. 16
      * of 24 rows active it is a few passes of latency either way; the switch was removed in round 3) */
     for( int t0=0; t0<( r*( r+1 ) >> 1 ); t0+=RKFD_WAVE ){
@@ -351,7 +377,7 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
         double sacc = 0;
 #pragma unroll 8
         for( int i=3*( ca > cb ? ca : cb ); i<n; i++ ) sacc = fma( W[i*ldq+a], W[i*ldq+b], sacc );
-        S[a*ld+b] = sacc; S[b*ld+a] = sacc;
+        if( reg ) S[RKFD_QI( a, b )] = sacc; else { S[a*ld+b] = sacc; S[b*ld+a] = sacc; }
       }
     }
     double rl = 0;
@@ -361,8 +387,13 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
     }
     SYNC();
     VST(26);
-    rkfd_w_chol<false>( S, ld, r );
-    {
+    if( reg ){
+      rkfd_w_chol<true>( S, 0, r );
+      const double y = rkfd_w_fwd<true>( S, 0, r, rl );
+      const double l = rkfd_w_back<true>( S, 0, r, y );
+      if( lane < r ) lam[lane] = l;
+    } else {
+      rkfd_w_chol<false>( S, ld, r );
       const double y = rkfd_w_fwd<false>( S, ld, r, rl );
       const double l = rkfd_w_back<false>( S, ld, r, y );
       if( lane < r ) lam[lane] = l;

@@ -29,8 +29,8 @@ static thread_local char g_err[512] = "";
  * three waves per SIMD, i.e. up to twelve instances per CU where the LDS allows (10 for the humanoid worlds).
  * With machine LICM on, the backend hoists ~35 registers of literals (sincos polynomial coefficients, fp64
  * constants) and addresses out of the step loop and the kernels need 184-193. */
-#define RKFD_KERNEL(name, prof, vqp, pk) \
-extern "C" __global__ void __launch_bounds__(RKFD_WAVE, 3) \
+#define RKFD_KERNEL(name, prof, vqp, pk, waves) \
+extern "C" __global__ void __launch_bounds__(RKFD_WAVE, waves) \
 name(rkfdDevModel m, rkfdDevState st, int first, int mode, int nsteps, int *errflag) \
 { \
   extern __shared__ __attribute__((aligned(16))) char lds[]; \
@@ -38,16 +38,18 @@ name(rkfdDevModel m, rkfdDevState st, int first, int mode, int nsteps, int *errf
   if( b >= st.batch ) return; \
   rkfd_instance<prof, vqp, pk>( m, st, b, lds, mode, nsteps, errflag ); \
 }
-RKFD_KERNEL( rkfd_step_kernel, false, 0, false )
+RKFD_KERNEL( rkfd_step_kernel, false, 0, false, 3 )
 /* the contact matrix as a packed lower triangle (worlds where that lets one more instance share a CU) */
-RKFD_KERNEL( rkfd_step_kernel_pk, false, 0, true )
+RKFD_KERNEL( rkfd_step_kernel_pk, false, 0, true, 3 )
 /* the variant that also carries the Vert plugin's QP (worlds with rigid pairs under the Vert plugin);
  * kept apart so that its code and registers do not weigh on the MLCP / penalty kernel */
-RKFD_KERNEL( rkfd_step_kernel_vqp, false, 1, false )
+/* (two waves per SIMD: up to 24 unknowns the QP keeps the factor of its Q in registers - 96 of them - and the QP's LDS allows at
+ *  most eight instances per CU anyway) */
+RKFD_KERNEL( rkfd_step_kernel_vqp, false, 1, false, 2 )
 /* diagnostic instantiations with in-kernel phase stamps (rkfdBatchProfile) */
-RKFD_KERNEL( rkfd_step_kernel_prof, true, 0, false )
-RKFD_KERNEL( rkfd_step_kernel_prof_pk, true, 0, true )
-RKFD_KERNEL( rkfd_step_kernel_prof_vqp, true, 1, false )
+RKFD_KERNEL( rkfd_step_kernel_prof, true, 0, false, 3 )
+RKFD_KERNEL( rkfd_step_kernel_prof_pk, true, 0, true, 3 )
+RKFD_KERNEL( rkfd_step_kernel_prof_vqp, true, 1, false, 2 )
 /* the variant that carries the Volume plugin (worlds with rigid pairs under it).  Built for two waves per SIMD: the phase is
  * latency-bound (a dozen lanes at work, dependent LDS / readlane chains), so a second wave per SIMD is worth more than the
  * ~90 vector registers it spills (measured, box on the floor / humanoid on two soles, M steps/s: one wave 2.33 / 1.49, two
@@ -486,7 +488,7 @@ static std::string spec_source(const rkfdDevModel &d, int ipw = 1)
     ipw, d.nlink, d.ndof, d.ncand, d.nlink_model, d.nlevel, d.nround, d.nsched, d.maxrg, d.npool, d.nfloat, d.maxact, d.nside,
     d.npurow, d.pu_d0, d.pu_alias, d.vert_rigid, d.qscr_alias, d.has_slide, d.ma_size, d.ma_packed, d.max_iter, d.solver, d.pyramid, d.anchor, d.mlcp_mfma,
     d.has_brf, d.lds_instance, d.vol_npair, d.vol_np, d.vol_ncp, d.vol_pv, d.vol_nf,
-    ( d.vol_np > 0 || ipw == 2 || ( d.vert_rigid && 3*d.maxrg <= 24 ) ) ? 2 : 3, d.vol_np > 0 ? "2" : ( d.vert_rigid ? "1" : "0" ), d.ma_packed ? "true" : "false" );
+    ( d.vol_np > 0 || ipw == 2 || d.vert_rigid == 2 ) ? 2 : 3, d.vol_np > 0 ? "2" : ( d.vert_rigid ? "1" : "0" ), d.ma_packed ? "true" : "false" );
   std::string src;
   if( const char *pre = getenv( "RKFD_SPEC_DEFINE" ) ){      /* diagnostic: NAME[,NAME...] defined as 1 in front of the source */
     std::string names( pre ); size_t p0 = 0;

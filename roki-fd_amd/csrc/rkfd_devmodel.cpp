@@ -589,8 +589,10 @@ extern "C" int rkfd_devmodel_build_w(const rkfdModel *m, int max_rigid, const in
   }
   dm.pyramid = m->pyramid > 0 ? m->pyramid : 8;
   dm.vert_rigid = ( m->solver == RKFD_SOLVER_VERT && has_rigid && max_rigid > 0 ) ? 1 : 0;
-  dm.qscr_alias = ( dm.vert_rigid && 6*NL >= RKFD_WAVE ) ? 1 : 0;
-  if( dm.qscr_alias ) dm.vert_rigid = 2;
+  /* 2: at most 24 unknowns - the factor of the QP's Q lives in registers (rkfd_dev_vertqp.h: rkfdQpFactor), W = L^-1 C' in the
+   * storage of the contact matrix and the Schur complement in that of the factor: no separate W in LDS */
+  if( dm.vert_rigid && 3*max_rigid <= RKFD_QP_NQ_MAX ) dm.vert_rigid = 2;
+  dm.qscr_alias = 0;      /* (the QP's reductions go through registers since round 3: no scratch) */
   dm.ma_packed = 0;
   dm.ma_size = dm.vert_rigid ? 3*max_rigid*( 3*max_rigid+1 ) : 9*max_rigid*max_rigid;   /* full rows (odd stride while a slot is free / for the Vert QP); see ma_packed below */
   if( dm.vert_rigid && (size_t)dm.pyramid*max_rigid > RKFD_WAVE )
@@ -697,7 +699,7 @@ extern "C" int rkfd_devmodel_build_w(const rkfdModel *m, int max_rigid, const in
     if( (size_t)dm.ma_size > stage ) stage = (size_t)dm.ma_size;   /* ... shared with the contact matrix */
     const size_t dbl = (size_t)NL*( 5*6 + 3 ) + stage + (size_t)33*nfloat
                      + (size_t)maxact*( 21 + ( NC > RKFD_WAVE/2 ? 3 : 0 ) + ( dm.has_slide ? 6 : 0 ) ) + ( ( dm.vert_rigid || vol_np > 0 ) ? 2 : 1 )*M + ( dm.pu_alias ? 0 : (size_t)nside*npurow*M )
-                     + ( dm.vert_rigid ? M*M + M*( M+1 )/2 + 5*M + ( dm.qscr_alias ? 0 : RKFD_WAVE ) + 3*M : 0 )   /* Vert QP: QL, QW, QV, CR */
+                     + ( dm.vert_rigid ? ( dm.vert_rigid == 2 ? 0 : M*M ) + M*( M+1 )/2 + 5*M + 3*M : 0 )   /* Vert QP: QL, QW, QV, CR */
                      + ( vol_np > 0 ? (size_t)RKFD_VOL_LDS_DOUBLES( vol_np, vol_ncp, vol_pv, vol_nf, dm.pyramid ) : 0 );
     const size_t ints = (size_t)NC + (size_t)nside*maxact + ( vol_np > 0 ? 12 + 2*vol_np : ( NC > 0 ? 8 : 4 ) ) + (size_t)NL     /* CIp, tgt, cnt (VI), LI */
                       + ( RKFD_GC_NEEDED( (int)M ) ? RKFD_GC_INTS : 0 );                                                            /* GC */

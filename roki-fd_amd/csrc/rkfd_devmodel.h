@@ -20,6 +20,7 @@
 #define RKFD_WL ( RKFD_WAVE/RKFD_W )      /* lanes of one instance */
 #define RKFD_MAX_LINK    64
 #define RKFD_MAX_DOF     64
+#define RKFD_QP_NQ_MAX   24   /* Vert QP: up to this many unknowns (8 contact vertices) the factor of Q is kept in registers (rkfd_dev_vertqp.h) */
 #define RKFD_MAX_CAND    4096 /* candidate contact vertices per instance (swept 64 at a time; 9 bytes of LDS each) */
 #define RKFD_MAX_ROWS    128  /* 3 * (rigid contact vertices): two MLCP rows per lane at most */
 
@@ -35,8 +36,8 @@ typedef struct {
   int anchor;            /* link whose position is the origin of the spatial (Pluecker) coordinates in every evaluation:
                             the first link that can move (-1: none, the world origin is used)           */
   int vert_rigid;        /* > 0: Vert plugin and rigid pairs exist -> the QP path and its LDS are set up;
-                            2: the QP's reduction scratch overlays the link accelerations (qscr_alias)      */
-  int qscr_alias;
+                            2: at most RKFD_QP_NQ_MAX unknowns - the QP keeps the factor of Q in registers and needs no W block */
+  int qscr_alias;        /* (unused since round 3, kept for the layout of the structure) */
   int ma_packed;         /* 1: the contact matrix is kept as a packed lower triangle (PGS kernels only), chosen where it lets one more instance share a CU */
   int ma_size;           /* doubles the contact matrix may take: full rows with an odd stride for the Vert QP, else the packed lower triangle */
   int pyramid;           /* faces of the Vert plugin's friction pyramid                                  */

@@ -35,7 +35,17 @@ def test_every_kernel_variant_is_reported():
                       "rkfd_step_kernel_vol", "rkfd_step_kernel_prof_vol", "rkfd_restore_kernel"}
 
 
-@pytest.mark.parametrize("name", ["rkfd_step_kernel", "rkfd_step_kernel_pk", "rkfd_step_kernel_vqp", "rkfd_step_kernel_prof", "rkfd_step_kernel_prof_pk", "rkfd_step_kernel_prof_vqp"])
+def test_vert_qp_kernel_resources():
+    """the variant carrying the Vert plugin's QP is built for two waves per SIMD since round 3: up to 24 unknowns lane i keeps row
+    and column i of the factor of Q in registers (rkfd_dev_vertqp.h: rkfdQpFactor, 96 registers) - the step is a dependent chain,
+    and the QP's LDS allows eight instances per CU at most.  No register may be spilled."""
+    for name in ("rkfd_step_kernel_vqp", "rkfd_step_kernel_prof_vqp"):
+        k = _kernels()[name]
+        assert k["Occupancy"] >= 2 and k["VGPRs"] <= 256, k
+        assert k["VGPRs Spill"] == 0 and k["ScratchSize"] <= 32, k
+
+
+@pytest.mark.parametrize("name", ["rkfd_step_kernel", "rkfd_step_kernel_pk", "rkfd_step_kernel_prof", "rkfd_step_kernel_prof_pk"])
 def test_kernel_fits_three_waves_per_simd_without_scratch(name):
     k = _kernels()[name]
     # the packed-matrix variants sit exactly at the 168-register limit of three waves per SIMD since they carry the grouped
