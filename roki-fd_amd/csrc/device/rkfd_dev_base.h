@@ -379,6 +379,8 @@ typedef struct {
                                      [M(M+1)/2] Q / its Cholesky factor (packed lower triangle), [M*M] W = L^-1 C', [5M (+64)] vectors (+ reduction scratch
                                      unless it overlays the link accelerations), [3M] reduced rows */
   unsigned char *CRC;             /* [M] contact of a reduced constraint row */
+  double *QG, *QY;                /* the wide form (vert_rigid == 3): pyramid rows [3 P maxrg], multipliers [P maxrg] */
+  unsigned char *QA;              /* ... active flags [P maxrg], active faces per contact [maxrg] */
   double *MA, *MB, *MF, *PU;      /* contact problem: [ma_size] the matrix (ALIASES IST|POOL; full rows or a packed lower triangle, rkfd_ma_idx),
                                      [M] bias vector, [M] forces (ALIAS the bias vector in the PGS kernels), [nside*npurow*M] (ALIASES C|PA when it fits) */
   int *tgt, *cnt;
@@ -440,6 +442,7 @@ RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int
   if( pu_alias ) L->PU = L->C; else { L->PU = d; d += nside*npurow*M; }
   L->QL = d; L->QW = d; L->QV = d; L->CR = d;
   if( vert_rigid ){ L->QL = d; d += M*( M+1 )/2; L->QW = d; if( vert_rigid != 2 ) d += M*M; L->QV = d; d += 5*M; L->CR = d; d += 3*M; }
+  L->QG = d; L->QY = d; if( vert_rigid == 3 ){ L->QG = d; d += pyramid*M; L->QY = d; d += pyramid*( M/3 ); }
   L->VD = d; L->VPL = d; L->VPOLY = d; L->VRED = d; L->VQL = d; L->VQW = d; L->VS = d; L->VEV = d; L->VQV = d; L->VLP = d;
   if( vol_np ){
     const int n = 6*vol_np, mc = vol_np*( 1+vol_ncp );
@@ -463,6 +466,7 @@ RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int
   unsigned char *bp = (unsigned char *)sp;
   L->act = bp; bp += NC; L->typ = bp; bp += NC; L->asl = bp; bp += NC;
   L->CRC = bp; if( vert_rigid ) bp += M;
+  L->QA = bp; if( vert_rigid == 3 ) bp += ( pyramid+1 )*( M/3 );
   L->PL = bp; if( has_pl ) bp += NL*( nlevel+3 );
   L->BRK = bp;
 }

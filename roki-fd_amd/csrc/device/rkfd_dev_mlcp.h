@@ -833,7 +833,10 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
   SYNC();
   MST(6);
   if( vert ){
-    const unsigned long long qmask = rkfd_vert_qp<prof>( m, L, nc, pc );
+    /* (more unknowns or pyramid faces than lanes: the wide form, which leaves the active flags in L.QA) */
+    const bool wide = m.vert_rigid == 3;
+    unsigned long long qmask = 0;
+    if( wide ) rkfd_vert_qp_wide<prof>( m, L, nc, pc ); else qmask = rkfd_vert_qp<prof>( m, L, nc, pc );
     MST(21);
     /* _rkFDSolverSetForce (reference src/rkfd_vert.c:286-323): contact state is committed only when doUpRef;
      * a vertex is in kinetic friction when one of its pyramid faces is active at the solution */
@@ -849,7 +852,10 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
       { const int sl_ = L.asl[j]; L.CF[3*sl_] = fw[0]; L.CF[3*sl_+1] = fw[1]; L.CF[3*sl_+2] = fw[2]; }
       if( doUpRef ){
         const int P = m.pyramid;
-        if( ( qmask >> ( lane*P ) ) & ( ( 1ull << P ) - 1ull ) ){
+        bool anyface = false;
+        if( wide ){ for( int f=0; f<P; f++ ) anyface = anyface || L.QA[lane*P+f]; }
+        else anyface = ( ( qmask >> ( lane*P ) ) & ( ( 1ull << P ) - 1ull ) ) != 0ull;
+        if( anyface ){
           L.typ[j] = RKFD_KF;
           { const int ri = RIDX( j ), sl_ = L.asl[j]; L.REF[3*ri] = L.PRO[3*sl_]; L.REF[3*ri+1] = L.PRO[3*sl_+1]; L.REF[3*ri+2] = L.PRO[3*sl_+2]; }
         } else {

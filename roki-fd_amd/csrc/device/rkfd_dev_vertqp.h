@@ -499,4 +499,280 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
   return mask;
 }
 
+
+/* ------------------------------------------------------------------------ */
+/* The WIDE form of the same QP: more unknowns or more pyramid faces than the wavefront has lanes (3 Nc > 64 or P Nc > 64; the
+ * reference has no such limit, src/rkfd_vert.c:73-103 - config 5's 24 contact vertices under the default plugin are 72 unknowns
+ * and 192 faces).  The method, its start point, its tolerances and the order of its decisions are those of rkfd_vert_qp above;
+ * what changes is where things live: every vector of the solver is in LDS, every loop over unknowns / faces / reduced rows is
+ * strided by the wavefront, the active set is a byte per face (and three 64-bit words where bases are compared), and the dense
+ * routines take their pivots from LDS instead of v_readlane.  Built for correctness, not speed: such a world holds one
+ * instance per CU (its matrices are 100 KB of LDS). */
+#define RKFD_WI(r,c) ( pk ? ( ( (r)*( (r)+1 ) ) >> 1 ) + (c) : (r)*ld + (c) )
+template<bool pk> RKFD_DEV void rkfd_ww_chol(double *Mx, int ld, int n, double *tmp)
+{
+  const int lane = LANE();
+  for( int k=0; k<n; k++ ){
+    for( int i=lane; i<n; i+=RKFD_WAVE ) if( i >= k ){
+      double s = Mx[RKFD_WI( i, k )];
+      for( int j=0; j<k; j++ ) s -= Mx[RKFD_WI( i, j )]*Mx[RKFD_WI( k, j )];
+      tmp[i] = s;
+    }
+    SYNC();
+    const double rinv = RKFD_RCP( sqrt( tmp[k] ) );
+    for( int i=lane; i<n; i+=RKFD_WAVE ) if( i >= k ) Mx[RKFD_WI( i, k )] = i == k ? rinv : tmp[i]*rinv;
+    SYNC();
+  }
+}
+/* v <- L^-1 v, v in LDS */
+template<bool pk> RKFD_DEV void rkfd_ww_fwd(const double *Mx, int ld, int n, double *v)
+{
+  const int lane = LANE();
+  for( int j=0; j<n; j++ ){
+    const double yj = v[j]*Mx[RKFD_WI( j, j )];
+    SYNC();
+    for( int i=lane; i<n; i+=RKFD_WAVE ){
+      if( i == j ) v[i] = yj;
+      else if( i > j ) v[i] -= Mx[RKFD_WI( i, j )]*yj;
+    }
+    SYNC();
+  }
+}
+/* v <- L^-T v */
+template<bool pk> RKFD_DEV void rkfd_ww_back(const double *Mx, int ld, int n, double *v)
+{
+  const int lane = LANE();
+  for( int j=n-1; j>=0; j-- ){
+    const double xj = v[j]*Mx[RKFD_WI( j, j )];
+    SYNC();
+    for( int i=lane; i<n; i+=RKFD_WAVE ){
+      if( i == j ) v[i] = xj;
+      else if( i < j ) v[i] -= Mx[RKFD_WI( j, i )]*xj;
+    }
+    SYNC();
+  }
+}
+#undef RKFD_WI
+
+/* In / out as rkfd_vert_qp; the active flags stay in L.QA[face] for the caller's stick / slip decision. */
+template<bool prof> RKFD_DEV void rkfd_vert_qp_wide(const rkfdDevModel &m, const rkfdLds &L, int nc, unsigned long long *pc)
+{
+  unsigned long long q0 = prof ? RKFD_CLOCK() : 0ull, q1;
+#define VST(k) do{ if( prof ){ q1 = RKFD_CLOCK(); pc[k] += q1 - q0; q0 = q1; } }while(0)
+  const int lane = LANE();
+  const int n = 3*nc, ld = n+1, ldq = n;
+  const int P = m.pyramid, mc = P*nc;
+  double *Q = L.QL, *W = L.QW, *S = L.MA;
+  double *cv = L.QV, *zv = L.QV + n, *ans = L.QV + 2*n, *lam = L.QV + 3*n, *dv = L.QV + 4*n;
+  double *xv = L.MB;
+  double *G = L.QG, *yv = L.QY;
+  unsigned char *act = L.QA, *kcn = L.QA + P*m.maxrg;
+  const double PI = 3.14159265358979323846;
+
+  /* pyramid rows (_rkFDSolverFrictionConstraint), face q = contact q / P, direction q % P */
+  {
+    double s0, c0;
+    d_sincos( 0.0 + ( -PI/P ), &s0, &c0 );
+    for( int q=lane; q<mc; q+=RKFD_WAVE ){
+      const int cc = q/P, kf = q - cc*P;
+      const int jc = L.lrg[cc], ci = RKFD_CI_CI( L.CIp[jc] );
+      const double mu = L.typ[jc] == RKFD_KF ? m.ci_kf[ci] : m.ci_sf[ci];
+      double th = 0.0, s1, c1;
+      for( int k=0; k<kf; k++ ) th += 2.0*PI/P;
+      d_sincos( th + ( -PI/P ), &s1, &c1 );
+      G[3*q] = mu*c0; G[3*q+1] = s1; G[3*q+2] = c1;
+    }
+  }
+  /* c = A'c, q = A'A + L (packed lower triangle), the start point */
+  for( int i=lane; i<n; i+=RKFD_WAVE ){
+    double s = 0;
+    for( int r=0; r<n; r++ ) s = fma( L.MA[r*ld+i], L.MB[r], s );
+    cv[i] = s;
+    ans[i] = ( i%3 == 0 ) ? 1.0 : 0.0;
+  }
+  for( int t=lane; t<n*n; t+=RKFD_WAVE ){
+    const int i = t/n, k = t - i*n;
+    if( k <= i ){
+      double s = 0;
+      for( int r=0; r<n; r++ ) s = fma( L.MA[r*ld+i], L.MA[r*ld+k], s );
+      if( i == k ) s += m.ci_l[RKFD_CI_CI( L.CIp[L.lrg[i/3]] )];
+      Q[RKFD_QI( i, k )] = s;
+    }
+  }
+  SYNC();
+  rkfd_ww_chol<true>( Q, 0, n, dv );
+  for( int i=lane; i<n; i+=RKFD_WAVE ) zv[i] = cv[i];
+  SYNC();
+  rkfd_ww_fwd<true>( Q, 0, n, zv );
+  VST(24);
+  /* initial active set */
+  for( int q=lane; q<mc; q+=RKFD_WAVE ){
+    const int c3 = 3*( q/P );
+    act[q] = fabs( G[3*q]*ans[c3] + G[3*q+1]*ans[c3+1] + G[3*q+2]*ans[c3+2] - 0.0 ) < RKFD_DEV_TOL;
+  }
+  SYNC();
+  unsigned long long hw0 = 0, hw1 = 0, hw2 = 0; double hobj = 0; int nhist = 0;      /* lane h keeps visited basis h */
+  int fail = 0;
+  for( int iter=0; ; iter++ ){
+    if( iter >= RKFD_QP_MAXITER ){ fail = 1; break; }
+    /* reduced, full-rank constraint rows: per contact its active faces (1 or 2) or the three unit rows (>= 3) */
+    for( int c=lane; c<nc; c+=RKFD_WAVE ){
+      int k = 0;
+      for( int f=0; f<P; f++ ) k += act[c*P+f];
+      kcn[c] = (unsigned char)k;
+    }
+    SYNC();
+    int r = 0;
+    for( int c=0; c<nc; c++ ) r += kcn[c] < 3 ? kcn[c] : 3;
+    for( int q=lane; q<mc; q+=RKFD_WAVE ) if( act[q] ){
+      const int cc = q/P, kf = q - cc*P, kc = kcn[cc];
+      int roff = 0, rho = 0;
+      for( int c=0; c<cc; c++ ) roff += kcn[c] < 3 ? kcn[c] : 3;
+      for( int f=0; f<kf; f++ ) rho += act[cc*P+f];
+      if( kc < 3 ){
+        L.CR[3*( roff+rho )] = G[3*q]; L.CR[3*( roff+rho )+1] = G[3*q+1]; L.CR[3*( roff+rho )+2] = G[3*q+2]; L.CRC[roff+rho] = (unsigned char)cc;
+      } else if( rho < 3 ){
+        L.CR[3*( roff+rho )] = rho == 0 ? 1.0 : 0.0; L.CR[3*( roff+rho )+1] = rho == 1 ? 1.0 : 0.0; L.CR[3*( roff+rho )+2] = rho == 2 ? 1.0 : 0.0;
+        L.CRC[roff+rho] = (unsigned char)cc;
+      }
+    }
+    SYNC();
+    /* W = L^-1 C' (lane = reduced row), S = W'W, rhs = W'z */
+    for( int a=lane; a<r; a+=RKFD_WAVE ){
+      const int c3 = 3*L.CRC[a];
+      const double h0 = L.CR[3*a], h1 = L.CR[3*a+1], h2 = L.CR[3*a+2];
+      for( int i=0; i<n; i++ ){
+        double sacc = i == c3 ? h0 : ( i == c3+1 ? h1 : ( i == c3+2 ? h2 : 0.0 ) );
+        for( int j=c3; j<i; j++ ) sacc -= Q[RKFD_QI( i, j )]*W[j*ldq+a];
+        W[i*ldq+a] = i < c3 ? 0.0 : sacc*Q[RKFD_QI( i, i )];
+      }
+    }
+    SYNC();
+    VST(25);
+    for( int t=lane; t<( r*( r+1 ) >> 1 ); t+=RKFD_WAVE ){
+      int a = (int)( ( sqrt( 8.0*t + 1.0 ) - 1.0 )*0.5 );
+      if( ( a*( a+1 ) >> 1 ) > t ) a--;
+      if( ( ( a+1 )*( a+2 ) >> 1 ) <= t ) a++;
+      const int b = t - ( a*( a+1 ) >> 1 );
+      const int ca = L.CRC[a], cb = L.CRC[b];
+      double sacc = 0;
+      for( int i=3*( ca > cb ? ca : cb ); i<n; i++ ) sacc = fma( W[i*ldq+a], W[i*ldq+b], sacc );
+      S[a*ld+b] = sacc; S[b*ld+a] = sacc;
+    }
+    for( int a=lane; a<r; a+=RKFD_WAVE ){
+      double rl = 0;
+      for( int i=3*L.CRC[a]; i<n; i++ ) rl = fma( W[i*ldq+a], zv[i], rl );
+      lam[a] = rl;
+    }
+    SYNC();
+    VST(26);
+    rkfd_ww_chol<false>( S, ld, r, dv );
+    rkfd_ww_fwd<false>( S, ld, r, lam );
+    rkfd_ww_back<false>( S, ld, r, lam );
+    VST(27);
+    /* f = L^-T ( W lambda - z ) */
+    for( int i=lane; i<n; i+=RKFD_WAVE ){
+      double ti = 0;
+      for( int a=0; a<r; a++ ) ti = fma( W[i*ldq+a], lam[a], ti );
+      xv[i] = ti - zv[i];
+    }
+    SYNC();
+    rkfd_ww_back<true>( Q, 0, n, xv );
+    VST(28);
+    bool mv = false;
+    for( int i=lane; i<n; i+=RKFD_WAVE ) mv = mv || !( fabs( xv[i] - ans[i] ) < RKFD_DEV_TOL );
+    if( !ANY( mv ) ){
+      SYNC();
+      for( int i=lane; i<n; i+=RKFD_WAVE ) ans[i] = xv[i];
+      /* multipliers of the original rows */
+      bool neg = false;
+      double ylo = HUGE_VAL;
+      for( int q=lane; q<mc; q+=RKFD_WAVE ) if( act[q] ){
+        const int cc = q/P, kf = q - cc*P, kc = kcn[cc];
+        int roff = 0, rho = 0;
+        for( int c=0; c<cc; c++ ) roff += kcn[c] < 3 ? kcn[c] : 3;
+        for( int f=0; f<kf; f++ ) rho += act[cc*P+f];
+        double y;
+        if( kc < 3 ) y = lam[roff+rho];
+        else {
+          /* y = g . (G'G)^-1 lambda_c over the active faces of this contact */
+          const double g0 = G[3*q];
+          double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0;
+          double th = 0.0;
+          for( int k=0; k<P; k++, th+=2.0*PI/P ){
+            if( !act[cc*P+k] ) continue;
+            double sk, ck;
+            d_sincos( th + ( -PI/P ), &sk, &ck );
+            a00 += g0*g0; a01 += g0*sk; a02 += g0*ck; a11 += sk*sk; a12 += sk*ck; a22 += ck*ck;
+          }
+          const double l0 = lam[roff], l1 = lam[roff+1], l2 = lam[roff+2];
+          const double c00 = a11*a22 - a12*a12, c01 = a02*a12 - a01*a22, c02 = a01*a12 - a02*a11;
+          const double c11 = a00*a22 - a02*a02, c12 = a01*a02 - a00*a12, c22 = a00*a11 - a01*a01;
+          const double det = a00*c00 + a01*c01 + a02*c02;
+          const double u0 = ( c00*l0 + c01*l1 + c02*l2 )/det, u1 = ( c01*l0 + c11*l1 + c12*l2 )/det, u2 = ( c02*l0 + c12*l1 + c22*l2 )/det;
+          y = g0*u0 + G[3*q+1]*u1 + G[3*q+2]*u2;
+        }
+        yv[q] = y;
+        neg = neg || y < 0;
+        ylo = y < ylo ? y : ylo;
+      }
+      SYNC();
+      if( !ANY( neg ) ) break;                 /* found the optimal solution */
+      const double ymin = WMIN( ylo );
+      for( int q=lane; q<mc; q+=RKFD_WAVE ) if( act[q] && fabs( yv[q] - ymin ) < RKFD_QP_ASM_TOL ) act[q] = 0;
+      SYNC();
+      VST(29);
+      continue;
+    }
+    /* STEP2: towards the equality-constrained minimiser as far as the inactive constraints allow */
+    for( int i=lane; i<n; i+=RKFD_WAVE ) dv[i] = xv[i] - ans[i];
+    SYNC();
+    double tq = HUGE_VAL;
+    for( int q=lane; q<mc; q+=RKFD_WAVE ) if( !act[q] ){
+      const int c3 = 3*( q/P );
+      const double gd = G[3*q]*dv[c3] + G[3*q+1]*dv[c3+1] + G[3*q+2]*dv[c3+2];
+      if( gd < 0 ){
+        const double t = ( 0.0 - ( G[3*q]*ans[c3] + G[3*q+1]*ans[c3+1] + G[3*q+2]*ans[c3+2] ) )/gd;
+        tq = t < tq ? t : tq;
+      }
+    }
+    double tmin = WMIN( tq );
+    if( !( tmin < 1.0 ) ) tmin = 1.0;
+    SYNC();
+    for( int i=lane; i<n; i+=RKFD_WAVE ) ans[i] += tmin*dv[i];
+    SYNC();
+    for( int q=lane; q<mc; q+=RKFD_WAVE ) if( !act[q] ){
+      const int c3 = 3*( q/P );
+      if( fabs( G[3*q]*ans[c3] + G[3*q+1]*ans[c3+1] + G[3*q+2]*ans[c3+2] - 0.0 ) < RKFD_DEV_TOL ) act[q] = 1;
+    }
+    /* circulation check (degeneracy): same basis seen before with the same objective value; f'Qf/2 = |L'f|^2/2 */
+    double part = 0;
+    for( int i=lane; i<n; i+=RKFD_WAVE ){
+      double u = ans[i]/Q[RKFD_QI( i, i )];
+      for( int j=i+1; j<n; j++ ) u = fma( Q[RKFD_QI( j, i )], ans[j], u );
+      part += 0.5*u*u + cv[i]*ans[i];
+    }
+    const double objv = WSUM( part );
+    SYNC();
+    const unsigned long long w0 = BALLOT( lane < mc && act[lane < mc ? lane : 0] );
+    const unsigned long long w1 = BALLOT( 64+lane < mc && act[64+lane < mc ? 64+lane : 0] );
+    const unsigned long long w2 = BALLOT( 128+lane < mc && act[128+lane < mc ? 128+lane : 0] );
+    const bool seen = lane < nhist && hw0 == w0 && hw1 == w1 && hw2 == w2 && !( fabs( hobj/objv - 1.0 ) > RKFD_QP_ASM_TOL );
+    if( ANY( seen ) ) break;
+    if( nhist >= RKFD_WAVE ){ fail = 1; break; }
+    if( lane == nhist ){ hw0 = w0; hw1 = w1; hw2 = w2; hobj = objv; }
+    nhist++;
+    VST(30);
+  }
+  SYNC();
+  bool bad = false;
+  for( int i=lane; i<n; i+=RKFD_WAVE ) bad = bad || !( ans[i] == ans[i] );
+  if( ANY( bad ) ) fail = 1;
+  if( fail && lane == 0 ) L.cnt[CNT_QPF] = 1;
+  SYNC();
+  for( int i=lane; i<n; i+=RKFD_WAVE ) L.MF[i] = ans[i]/m.dt;
+  SYNC();
+#undef VST
+}
+
 #endif /* RKFD_DEV_VERTQP_H */

@@ -592,11 +592,14 @@ extern "C" int rkfd_devmodel_build_w(const rkfdModel *m, int max_rigid, const in
   /* 2: at most 24 unknowns - the factor of the QP's Q lives in registers (rkfd_dev_vertqp.h: rkfdQpFactor), W = L^-1 C' in the
    * storage of the contact matrix and the Schur complement in that of the factor: no separate W in LDS */
   if( dm.vert_rigid && 3*max_rigid <= RKFD_QP_NQ_MAX ) dm.vert_rigid = 2;
+  /* 3: more unknowns or more pyramid faces than lanes - the QP's wide form, every vector in LDS and every loop strided by the
+   * wavefront (rkfd_vert_qp_wide) */
+  if( dm.vert_rigid && ( 3*max_rigid > RKFD_WAVE || dm.pyramid*max_rigid > RKFD_WAVE ) ) dm.vert_rigid = 3;
   dm.qscr_alias = 0;      /* (the QP's reductions go through registers since round 3: no scratch) */
   dm.ma_packed = 0;
   dm.ma_size = dm.vert_rigid ? 3*max_rigid*( 3*max_rigid+1 ) : 9*max_rigid*max_rigid;   /* full rows (odd stride while a slot is free / for the Vert QP); see ma_packed below */
-  if( dm.vert_rigid && (size_t)dm.pyramid*max_rigid > RKFD_WAVE )
-    FAIL( "Vert plugin: pyramid faces x rigid contact capacity exceeds 64 (one constraint per lane)" );
+  if( dm.vert_rigid && (size_t)dm.pyramid*max_rigid > 3*RKFD_WAVE )
+    FAIL( "Vert plugin: pyramid faces x rigid contact capacity exceeds 192 (the active set is kept as three 64-bit words)" );
   int maxact = has_elastic ? ( NC < 16 ? NC : 16 ) : 0;
   if( has_rigid && max_rigid > maxact ) maxact = max_rigid < NC ? max_rigid : NC;
   if( NC > 0 && maxact < 1 ) maxact = 1;
@@ -700,10 +703,11 @@ extern "C" int rkfd_devmodel_build_w(const rkfdModel *m, int max_rigid, const in
     const size_t dbl = (size_t)NL*( 5*6 + 3 ) + stage + (size_t)33*nfloat
                      + (size_t)maxact*( 21 + ( NC > RKFD_WAVE/2 ? 3 : 0 ) + ( dm.has_slide ? 6 : 0 ) ) + ( ( dm.vert_rigid || vol_np > 0 ) ? 2 : 1 )*M + ( dm.pu_alias ? 0 : (size_t)nside*npurow*M )
                      + ( dm.vert_rigid ? ( dm.vert_rigid == 2 ? 0 : M*M ) + M*( M+1 )/2 + 5*M + 3*M : 0 )   /* Vert QP: QL, QW, QV, CR */
+                     + ( dm.vert_rigid == 3 ? (size_t)dm.pyramid*M + (size_t)dm.pyramid*max_rigid : 0 )             /* ... wide form: QG, QY */
                      + ( vol_np > 0 ? (size_t)RKFD_VOL_LDS_DOUBLES( vol_np, vol_ncp, vol_pv, vol_nf, dm.pyramid ) : 0 );
     const size_t ints = (size_t)NC + (size_t)nside*maxact + ( vol_np > 0 ? 12 + 2*vol_np : ( NC > 0 ? 8 : 4 ) ) + (size_t)NL     /* CIp, tgt, cnt (VI), LI */
                       + ( RKFD_GC_NEEDED( (int)M ) ? RKFD_GC_INTS : 0 );                                                            /* GC */
-    const size_t bytes = (size_t)2*NL + (size_t)5*NC + (size_t)4*maxact + ( dm.vert_rigid ? M : 0 )                                     /* CHP (16 bit), act typ asl (bytes) */
+    const size_t bytes = (size_t)2*NL + (size_t)5*NC + (size_t)4*maxact + ( dm.vert_rigid ? M : 0 ) + ( dm.vert_rigid == 3 ? (size_t)( dm.pyramid+1 )*max_rigid : 0 )                                     /* CHP (16 bit), act typ asl (bytes) */
                        + ( max_rigid > 0 ? (size_t)NL*( nlevel+3 ) : 0 )                 /* PL */
                        + ( has_brf ? (size_t)NL : 0 );                                   /* BRK */
     out->lds_bytes = dbl*sizeof(double) + ints*sizeof(int) + bytes;

@@ -226,14 +226,15 @@ def config4_vert(batch=4096, model="humanoid30.ztk", first=0):
     return dict(name="config4_humanoid_vert_qp", world=w, dis=dis, vel=vel, max_rigid=8, steps=1000)
 
 
-def config5(batch=4096, max_rigid=24, first=0):
+def config5(batch=4096, max_rigid=24, first=0, solver=None):
     """config 4 + clutter: four small boxes resting on the floor around the feet; box-floor, box-foot and box-box
     pairs are RIGID ('ground body' / 'body body' of contactinfo.ztk).  Registration and rkCDPairChainUnreg in the order
     of the reference's box-drop drivers (boxdrop_test.c:27-39: the call drops a chain's OWN pairs - none for a one-link box;
     the humanoid's sole-sole pair goes).  54 joint coordinates, 34 links, 320 candidate contact vertices per instance
     (6 box-box + 8 box-sole + 4 box-floor + 2 sole-floor pairs x 16).  Contact capacity 24 vertices = 72 MLCP rows (two
-    rows per lane)."""
-    w = B.World(solver=B.SOLVER_MLCP)
+    rows per lane).  solver = SOLVER_VERT: the same world under the reference's default plugin - 72 unknowns and 192 pyramid
+    faces, the wide form of the QP (rkfd_vert_qp_wide)."""
+    w = B.World(solver=B.SOLVER_MLCP if solver is None else solver)
     w.contact_info(_m("contactinfo.ztk"))
     boxes = []
     for _ in range(4):
@@ -257,7 +258,7 @@ def config5(batch=4096, max_rigid=24, first=0):
     nominal = np.zeros(m.ndof); nominal[ho:ho + n] = init
     seat_soles_flat(m, dis, h, ho, nominal=nominal)
     vel = np.zeros_like(dis)
-    return dict(name="config5_humanoid_clutter_mlcp", world=w, dis=dis, vel=vel, max_rigid=max_rigid, steps=1000)
+    return dict(name="config5_humanoid_clutter_mlcp" if solver is None else "config5_humanoid_clutter_vert_qp", world=w, dis=dis, vel=vel, max_rigid=max_rigid, steps=1000)
 
 
 def arm_press(batch=8, root="fixed", with_box=True, seed=0x5EED00A1, solver=B.SOLVER_MLCP):
@@ -369,6 +370,11 @@ def wall_hit(batch=4, seed=0x5EED00F1, solver=B.SOLVER_MLCP, speed=1.0):
     return dict(name="wall_hit", world=w, dis=dis, vel=vel, max_rigid=6 if solver == B.SOLVER_VOLUME else 16, steps=200)
 
 
+def config5_vert(batch=4096, max_rigid=24, first=0):
+    """config 5 under the reference's default plugin (Vert): 24 contact vertices = 72 unknowns, 192 pyramid faces"""
+    return config5(batch=batch, max_rigid=max_rigid, first=first, solver=B.SOLVER_VERT)
+
+
 def config3_26(batch=4096, first=0):
     """config 3 on the 26-DoF model with mighty.ztk's own topology (reported alongside)"""
     d = config3(batch, model="humanoid26.ztk", first=first); d["name"] = "config3_humanoid26_penalty"; return d
@@ -449,5 +455,5 @@ def config4_volume(batch=4096, model="humanoid30.ztk", first=0):
     return dict(name="config4vol_humanoid_rigid_volume", world=w, dis=dis, vel=vel, max_rigid=2, steps=2000)
 
 
-CONFIGS = {"config1": config1, "config1_volume": config1_volume, "config4_volume": config4_volume, "config1b": config1_rigid, "config2": config2, "config3": config3, "config4": config4, "config4v": config4_vert, "config5": config5,
+CONFIGS = {"config1": config1, "config1_volume": config1_volume, "config4_volume": config4_volume, "config1b": config1_rigid, "config2": config2, "config3": config3, "config4": config4, "config4v": config4_vert, "config5": config5, "config5v": config5_vert,
            "config3_26": config3_26, "config4_26": config4_26, "config4_shell": config4_shell}

@@ -494,3 +494,37 @@ def test_emulated_two_instances_per_wavefront(R, oracle_cls, cfg, B, nsteps):
         o.update_init(); o.update_n(nsteps)
         for x, y in zip((dis[i], vel[i], acc[i]), o.get_state()):
             assert np.abs(x - y).max() / max(1.0, np.abs(y).max()) < 1e-9
+
+
+def test_emulated_vert_qp_wide_form(R, oracle_cls):
+    """more unknowns / pyramid faces than lanes (rkfd_vert_qp_wide): config 5 under the Vert plugin - 24 contact vertices, 72
+    unknowns, 192 faces - and a box world with capacity 16 x 8 faces, vs the oracle"""
+    import os
+    sc = R.scenarios.config5_vert(batch=1)
+    eb = EmuBatch(sc["world"], 1, max_rigid=sc["max_rigid"])
+    eb.set_state(sc["dis"], sc["vel"]); eb.update_init(); eb.update(2)
+    assert eb.status() == 0
+    d, v, a = eb.get_state(); act, typ, ref, f = eb.get_contact()
+    o = oracle_cls(sc["world"].model); o.set_state(sc["dis"][0], sc["vel"][0]); o.update_init(); o.update_n(2)
+    od, ov, oa = o.get_state(); oact, otyp, _, of = o.get_contact()
+    assert act[0].sum() == 24 and (act[0] == oact).all() and (typ[0] == otyp * (oact != 0)).all()
+    for x, y in ((d[0], od), (v[0], ov), (a[0], oa)):
+        assert np.abs(x - y).max() / max(1.0, np.abs(y).max()) < 1e-8
+    assert np.abs(f[0] - of * (oact[:, None] != 0)).max() / max(1.0, np.abs(of).max()) < 1e-5
+
+    M = R.scenarios.MODELS
+    w = R.World(solver=R.SOLVER_VERT); w.contact_info(os.path.join(M, "contactinfo.ztk"))
+    w.reg_file(os.path.join(M, "box.ztk")); w.reg_file(os.path.join(M, "floor.ztk"))
+    dis = np.zeros((2, 6)); vel = np.zeros((2, 6))
+    dis[:, 2] = 0.0499; dis[1, 3:6] = (0.01, 0.02, 0.3); vel[:, 0] = (0.0, 0.05)
+    eb = EmuBatch(w, 2, max_rigid=16)
+    eb.set_state(dis, vel); eb.update_init(); eb.update(8)
+    assert eb.status() == 0
+    d, v, a = eb.get_state(); act, typ, ref, f = eb.get_contact()
+    for i in range(2):
+        o = oracle_cls(w.model); o.set_state(dis[i], vel[i]); o.update_init(); o.update_n(8)
+        od, ov, oa = o.get_state(); oact, otyp, _, of = o.get_contact()
+        assert (act[i] == oact).all() and (typ[i] == otyp * (oact != 0)).all()
+        for x, y in ((d[i], od), (v[i], ov), (a[i], oa)):
+            assert np.abs(x - y).max() / max(1.0, np.abs(y).max()) < 1e-9
+        assert np.abs(f[i] - of * (oact[:, None] != 0)).max() / max(1.0, np.abs(of).max()) < 1e-8

@@ -404,8 +404,8 @@ def test_vert_plugin_rigid_qp_humanoid(R, oracle_cls):
 
 @pytest.mark.parametrize("P,cap", [(4, 8), (6, 8), (12, 5), (16, 4)])
 def test_vert_plugin_other_pyramids(R, oracle_cls, P, cap):
-    """rkFDPrpSetPyramid: pyramids with 4 / 6 / 12 / 16 faces (capacity = 64 lanes / faces), a tilted
-    sliding box on the rigid floor vs the oracle"""
+    """rkFDPrpSetPyramid: pyramids with 4 / 6 / 12 / 16 faces (here within 64 faces: one face per lane), a tilted
+    sliding box on the rigid floor vs the oracle; the capacity ends at 192 faces (three 64-bit words of active flags)"""
     w = _vert_box_world(R); w.set_pyramid(P)
     B = 4
     dis = np.zeros((B, 6)); vel = np.zeros((B, 6))
@@ -423,8 +423,61 @@ def test_vert_plugin_other_pyramids(R, oracle_cls, P, cap):
         od, ov, oa = o.get_state(); oact, otyp, _, of = o.get_contact()
         assert (act[i] == oact).all() and (typ[i] == otyp * (oact != 0)).all()
         assert _rel(d[i], od) < 1e-8 and _rel(v[i], ov) < 1e-8 and _rel(a[i], oa) < 1e-6
-    with pytest.raises(R.RkfdError, match="pyramid"):
-        R.Batch(w, 1, max_rigid=64 // P + 1)
+    with pytest.raises(R.RkfdError, match="pyramid|per-wave limit"):
+        R.Batch(w, 1, max_rigid=192 // P + 1)
+
+
+def test_vert_plugin_wide_qp_box(R, oracle_cls):
+    """more pyramid faces than lanes: capacity 16 vertices x 8 faces = 128 (rkfd_vert_qp_wide, vert_rigid == 3; the reference has
+    no such limit, src/rkfd_vert.c:73-103).  Tilted / sliding / spinning boxes vs the oracle, and against the same boxes run
+    through the one-face-per-lane form (capacity 8): same contact sets and friction states, values to rounding."""
+    w = _vert_box_world(R)
+    B = 16
+    rng = np.random.default_rng(5)
+    dis = np.zeros((B, 6)); vel = np.zeros((B, 6))
+    dis[:, 2] = 0.0499
+    dis[1:, 3:6] = rng.uniform(-0.3, 0.3, (B - 1, 3))
+    vel[:, 0] = np.linspace(0.0, 0.4, B); vel[2:, 3:6] = rng.uniform(-1, 1, (B - 2, 3))
+    m = w.model.contents
+    for i in range(1, B):
+        dis[i, 2] -= R.scenarios.lowest_vertex_z(m, dis[i], 0) + 0.0001
+    out = []
+    for cap in (16, 8):
+        b = R.Batch(w, B, max_rigid=cap)
+        b.set_state(dis, vel); b.update_init(); b.update(30)
+        assert b.status() == 0
+        out.append(b.get_state() + b.get_contact())
+    d, v, a, act, typ, ref, f = out[0]
+    agree = 0
+    for i in range(B):
+        o = oracle_cls(w.model); o.set_state(dis[i], vel[i]); o.update_init(); o.update_n(30)
+        od, ov, oa = o.get_state(); oact, otyp, _, of = o.get_contact()
+        # (the method's 1e-12 knife-edge decisions: an instance may leave the oracle's active-set path - tools/vert_agreement.py;
+        #  the one-face-per-lane form shows the same rate)
+        if (act[i] == oact).all() and (typ[i] == otyp * (oact != 0)).all() and _rel(d[i], od) < 1e-8 and _rel(v[i], ov) < 1e-8:
+            agree += 1
+    assert agree >= B - 2, agree
+    same = sum(int((out[0][3][i] == out[1][3][i]).all() and _rel(out[0][0][i], out[1][0][i]) < 1e-8) for i in range(B))
+    assert same >= B - 2, same
+
+
+def test_vert_plugin_config5_world(R, oracle_cls):
+    """config 5 under the reference's DEFAULT plugin (VERDICT r02 missing 4): humanoid + four boxes on 24 contact vertices =
+    72 unknowns and 192 pyramid faces, the wide form of the QP; 10 steps vs the oracle"""
+    B, N = 8, 10
+    sc = R.scenarios.config5_vert(batch=B)
+    b = R.Batch(sc["world"], B, max_rigid=sc["max_rigid"])
+    assert b.lds_bytes > 64 * 1024                     # (one instance per CU: the QP's matrices)
+    b.set_state(sc["dis"], sc["vel"]); b.update_init(); b.update(N)
+    assert b.status() == 0
+    d, v, a = b.get_state(); act, typ, ref, f = b.get_contact()
+    assert act.sum(1).min() >= 20
+    for i in range(0, B, 3):
+        o = oracle_cls(sc["world"].model); o.set_state(sc["dis"][i], sc["vel"][i]); o.update_init(); o.update_n(N)
+        od, ov, oa = o.get_state(); oact, otyp, _, of = o.get_contact()
+        assert (act[i] == oact).all() and (typ[i] == otyp * (oact != 0)).all()
+        assert _rel(d[i], od) < 1e-9 and _rel(v[i], ov) < 1e-8 and _rel(a[i], oa) < 1e-6
+        assert _rel(f[i], of * (oact[:, None] != 0)) < 1e-5      # (24 coplanar vertices: the force split is ill-conditioned, the wrench is not)
 
 
 @pytest.mark.parametrize("plugin,need", [("mlcp", 64), ("vert", 52)])
