@@ -31,8 +31,9 @@ const char *rkfdHipLastError(void);
  * Replaces, for the whole batch: rkFDCreate + rkFDChainReg* + rkFDUpdateInit's allocations
  * (reference src/rkfd_sim.c:32-54,188-235,552-558; rkFDCDUpdateInit src/rkfd_cd.c:22-31;
  * plugin _init src/rkfd_mlcp.c:312-325, src/rkfd_vert.c:350-368).  max_rigid = capacity of rigid
- * contact vertices solved per instance (MLCP plugin: 3*max_rigid <= 128; Vert plugin: one pyramid
- * face per lane, pyramid*max_rigid <= 64; Volume plugin: rigid PAIRS in collision at once, at most 10 -
+ * contact vertices solved per instance (MLCP plugin: 3*max_rigid <= 128; Vert plugin: pyramid*max_rigid
+ * <= 192 - up to 8 vertices the QP keeps its factor in registers, up to 64 faces and unknowns one per lane, beyond that the
+ * wide form with everything in LDS, one instance per CU; Volume plugin: rigid PAIRS in collision at once, at most 10 -
  * the shapes of a rigid pair must be convex polyhedra with at most 64 faces together, else create fails
  * with a message); exceeding it at run time is reported as an error by
  * rkfdBatchStatus. */
