@@ -34,8 +34,8 @@ const char *rkfdHipLastError(void);
  * contact vertices solved per instance (MLCP plugin: 3*max_rigid <= 128; Vert plugin: pyramid*max_rigid
  * <= 192 - up to 8 vertices the QP keeps its factor in registers, up to 64 faces and unknowns one per lane, beyond that the
  * wide form with everything in LDS, one instance per CU; Volume plugin: rigid PAIRS in collision at once, at most 10 -
- * the shapes of a rigid pair must be convex polyhedra with at most 64 faces together, else create fails
- * with a message); exceeding it at run time is reported as an error by
+ * rigid pairs of convex polyhedra with at most 64 faces together are solved, the others are guarded:
+ * status 4 when one comes into contact); exceeding it at run time is reported as an error by
  * rkfdBatchStatus. */
 rkfdBatch *rkfdBatchCreate(const rkfdModel *m, int batch, int device, int max_rigid);
 void rkfdBatchDestroy(rkfdBatch *b);
@@ -125,7 +125,10 @@ int rkfdBatchLaunchTiming(rkfdBatch *b, int *launches, double *total_ms);
  * conditions of a pair: 8) than max_rigid, or more rigid + elastic contact
  * vertices than the active-contact slots (max_rigid when the world has no elastic pairs, else max(max_rigid, 16)
  * capped by the candidate count); the vertices beyond the capacity were dropped -, 3 the Vert plugin's QP ran
- * out of iterations (256) or of basis history (64); negative: HIP error.  rkfdHipLastError() describes a
+ * out of iterations (256) or of basis history (64), 4 Volume plugin: a GUARDED pair came into contact - a rigid pair with a
+ * shape that is not convex, or with more than 64 faces together, cannot be clipped on the device; such a world is accepted
+ * (the reference's humanoid mighty.ztk, whose body meshes are not convex, stands and walks on its convex soles) and the
+ * plugin's own collision test watches those pairs -; negative: HIP error.  rkfdHipLastError() describes a
  * non-zero status.  A condition is reported ONCE: the call clears the device-side flag, so the next status tells
  * what happened after this one (when several conditions occurred since the last call, the last one written wins). */
 int rkfdBatchStatus(rkfdBatch *b, void *stream);

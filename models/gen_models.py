@@ -331,6 +331,66 @@ def humanoid_shell():
     w("humanoid30_shell.ztk", text)
 
 
+def lfoot():
+    """lfoot.ztk (SYNTHETIC): one free body with a CONVEX foot plate (box, below) and a NON-CONVEX bracket above it (an L-shaped
+    prism as a polyhedron: 12 vertices, 20 triangles, one reflex edge) - what the reference's mighty.ztk is to the Volume plugin
+    in the small: it stands on a convex shape the plugin can clip, while the pairs of the shape that is not convex are guarded
+    (status 4 when the bracket itself touches something)."""
+    # L cross-section in the x-z plane (counter-clockwise), extruded along y
+    prof = [(-0.05, 0.01), (0.05, 0.01), (0.05, 0.04), (-0.02, 0.04), (-0.02, 0.12), (-0.05, 0.12)]
+    ys = (-0.03, 0.03)
+    verts = [(x, y, z) for y in ys for (x, z) in prof]
+    n = len(prof)
+    faces = []
+    for i in range(n):                                   # side walls (outward for a counter-clockwise profile seen from -y)
+        j = (i + 1) % n
+        faces += [(i, j, n + j), (i, n + j, n + i)]
+    tri = [(0, 1, 2), (0, 2, 3), (0, 3, 4), (0, 4, 5)]     # the L as a fan from its inner corner's opposite vertex
+    faces += [(a, c, b) for a, b, c in tri]              # cap at y = -0.03 (normal -y)
+    faces += [(n + a, n + b, n + c) for a, b, c in tri]  # cap at y = +0.03 (normal +y)
+    # orientation check: every face normal points away from a point inside the thick leg
+    import numpy as np
+    V = np.array(verts); inside = np.array([-0.035, 0.0, 0.025])
+    out = []
+    for a, b, c in faces:
+        nrm = np.cross(V[b] - V[a], V[c] - V[a])
+        if np.dot(nrm, V[a] - inside) < 0:
+            a, b, c = a, c, b
+        out.append((a, b, c))
+    vtxt = "".join("vert: %d { %.5f, %.5f, %.5f }\n" % (i, *v) for i, v in enumerate(verts))
+    ftxt = "".join("face: %d %d %d\n" % f for f in out)
+    return f"""% lfoot (SYNTHETIC, models/gen_models.py: lfoot): a convex foot plate under a non-convex L bracket
+[roki::chain]
+name : lfoot
+
+[zeo::shape]
+type : box
+name : plate
+center : 0, 0, 0.005
+depth : 0.12
+width : 0.08
+height : 0.01
+
+[zeo::shape]
+name: bracket
+type: polyhedron
+{vtxt}{ftxt}
+[roki::link]
+name : link#00
+jointtype : float
+mass : 0.4
+stuff : body
+COM : 0, 0, 0.03
+inertia : {{
+ 6e-4, 0, 0
+ 0, 6e-4, 0
+ 0, 0, 6e-4
+}}
+shape : plate
+shape : bracket
+"""
+
+
 def main():
     w("box.ztk", box("box", 0.1, 0.1, 0.1, 0.5, "8.33e-4"))
     w("box_small.ztk", box("box_small", 0.05, 0.10, 0.05, 0.125, "5.208333333e-05"))
@@ -345,6 +405,7 @@ def main():
     w("arm_fold.ztk", arm_fold())
     w("wall.ztk", wall("wall", 3, [(200.0, 200.0), (10.0, 10.0), (10.0, 10.0)]))          # the reference's wall.ztk: same structure and thresholds
     w("wall_cantilever.ztk", wall("wall_cantilever", 2, [(100.0, 0.4), (100.0, 100.0)], upright=False))
+    w("lfoot.ztk", lfoot())
     ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
     if os.path.isdir(ref):
         humanoid(ref)

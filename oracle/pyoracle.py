@@ -35,6 +35,7 @@ def _bind(path):
     L.rkfdOracleUpdateN.argtypes = [vp, C.c_int]
     L.rkfdOracleLastQPIter.argtypes = [vp]
     L.rkfdOracleQPCycleStops.argtypes = [vp]
+    L.rkfdOracleVolumeGuardHits.argtypes = [vp]
     L.rkfdOracleEval.argtypes = [vp, C.c_int]
     L.rkfdOracleGetLinkFrames.argtypes = [vp, vp, vp]
     L.rkfdOracleGetLinkVelAcc.argtypes = [vp, vp, vp]
@@ -153,6 +154,9 @@ class Oracle:
 
     def qp_cycle_stops(self):
         return self._L.rkfdOracleQPCycleStops(self._o)
+
+    def volume_guard_hits(self):
+        return self._L.rkfdOracleVolumeGuardHits(self._o)
 
     def update(self):
         return self._L.rkfdOracleUpdate(self._o)

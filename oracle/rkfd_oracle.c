@@ -151,6 +151,8 @@ struct rkfdOracle {
   int last_nc;
   int last_qp_iter;      /* KKT solves of the last Vert QP (diagnostic) */
   int qp_cycle_stops;    /* how many Vert QPs so far were ended by the circulation check (diagnostic) */
+  unsigned char *vol_raw;  /* Volume plugin: [nshape] 1 = the shape is not convex - its rigid pairs are GUARDED (see rkfdOracleCreate) */
+  int vol_guard_hits;    /* ... evaluations x pairs in which a guarded pair was found in collision (and left without a force) */
   int qp_n, qp_mc;       /* the last Vert QP, kept for the tests: sizes, then q (n*n), c (n), nf (mc*n), ans (n), idx (mc) */
   double *qp_q, *qp_c, *qp_nf, *qp_ans; int *qp_idx;
   /* RKG workspace */
@@ -169,17 +171,19 @@ rkfdOracle *rkfdOracleCreate(const rkfdModel *m)
   rkfdOracle *o;
   int i, j, nl = m->nlink, n = m->ndof, nc = m->ncand, k;
 
-  if( m->solver == RKFD_SOLVER_VOLUME )      /* the Volume plugin's intersection volumes are formed by clipping CONVEX shapes */
-    for( i=0; i<m->npair; i++ ){
-      if( m->ci_type[m->pair_ci[i]] != RKFD_CONTACT_RIGID ) continue;
-      for( k=0; k<2; k++ ){
-        int sh = m->pair_shape[2*i+k], f, v;
-        for( f=m->shape_foff[sh]; f<m->shape_foff[sh+1]; f++ )
-          for( v=m->shape_voff[sh]; v<m->shape_voff[sh+1]; v++ )
-            if( v3_dot( &m->planes[4*f], &m->verts[3*v] ) - m->planes[4*f+3] > 1e-9 ) return NULL;
-      }
-    }
   o = (rkfdOracle *)zalloc( sizeof(rkfdOracle) );
+  /* The Volume plugin's intersection volumes are formed by clipping CONVEX shapes [UNVERIFIED-DEP, rkfd_oracle_volume.h].  A rigid
+   * pair with a shape that is not convex (the body meshes of the reference's mighty.ztk) is GUARDED: the plugin's own collision
+   * test - a vertex of one shape behind every face plane of the other - runs for it, a hit is counted (rkfdOracleVolumeGuardHits)
+   * and the pair is left without a contact force; the device reports the same condition as status 4. */
+  o->vol_raw = (unsigned char *)zalloc( m->nshape > 0 ? m->nshape : 1 );
+  if( m->solver == RKFD_SOLVER_VOLUME ){
+    int sh, f, v;
+    for( sh=0; sh<m->nshape; sh++ )
+      for( f=m->shape_foff[sh]; f<m->shape_foff[sh+1] && !o->vol_raw[sh]; f++ )
+        for( v=m->shape_voff[sh]; v<m->shape_voff[sh+1]; v++ )
+          if( v3_dot( &m->planes[4*f], &m->verts[3*v] ) - m->planes[4*f+3] > 1e-9 ){ o->vol_raw[sh] = 1; break; }
+  }
 
   o->m = m; o->nl = nl; o->n = n; o->ncand = nc;
   o->dis = zalloc( sizeof(double)*n ); o->vel = zalloc( sizeof(double)*n ); o->acc = zalloc( sizeof(double)*n );
@@ -230,7 +234,7 @@ void rkfdOracleDestroy(rkfdOracle *o)
   int k;
   if( !o ) return;
   free( o->qp_q ); free( o->qp_c ); free( o->qp_nf ); free( o->qp_ans ); free( o->qp_idx );
-  free( o->dis ); free( o->vel ); free( o->acc ); free( o->motor_in ); free( o->piv_type ); free( o->piv_prev ); free( o->broken );
+  free( o->dis ); free( o->vel ); free( o->acc ); free( o->motor_in ); free( o->vol_raw ); free( o->piv_type ); free( o->piv_prev ); free( o->broken );
   free( o->cv_active ); free( o->cv_type ); free( o->cv_ref ); free( o->cv_f ); free( o->lk );
   free( o->beta0 ); free( o->ext ); free( o->pA ); free( o->u ); free( o->contrib ); free( o->csum );
   free( o->s_beta0 ); free( o->s_pA ); free( o->s_u ); free( o->s_contrib ); free( o->s_csum );
@@ -1591,6 +1595,7 @@ int rkfdOracleGetVolumePair(const rkfdOracle *o, int k, double *out, int cap)
 int rkfdOracleVolumePairs(const rkfdOracle *o){ return o->vol_ready ? o->nvp : 0; }
 int rkfdOracleVolumeLP(int mr, int n, const double *A, const double *b, const double *c, double *x){ return vol_lp( mr, n, A, b, c, x ); }
 int rkfdOracleQPCycleStops(const rkfdOracle *o){ return o->qp_cycle_stops; }
+int rkfdOracleVolumeGuardHits(const rkfdOracle *o){ return o->vol_guard_hits; }
 
 /* test access to the two numerical building blocks of the Vert rigid branch */
 void rkfdOraclePinvSolve(int n, const double *K, const double *rhs, double *x)

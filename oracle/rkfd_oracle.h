@@ -59,6 +59,8 @@ int  rkfdOracleLastQPIter(const rkfdOracle *o);
 void rkfdOracleGetLastQP(const rkfdOracle *o, int *n, int *mc, double *q, double *c, double *nf, double *ans, int *idx);
 /* how many Vert QPs so far were ended by the circulation check instead of at the optimum (diagnostic) */
 int  rkfdOracleQPCycleStops(const rkfdOracle *o);
+/* Volume plugin: how often a GUARDED pair (a shape that is not convex: cannot be clipped) was found in collision so far */
+int  rkfdOracleVolumeGuardHits(const rkfdOracle *o);
 /* Volume plugin: number of colliding rigid pairs of the last evaluation; the data of one of them (see the .c); the
  * simplex LP min c'x s.t. Ax = b, x >= 0 (c NULL: feasibility only) */
 int  rkfdOracleVolumePairs(const rkfdOracle *o);

@@ -165,6 +165,7 @@ static void vol_collision(rkfdOracle *o)
     double asA[3], asB[3], ref[3], v6 = 0, cen[3] = {0,0,0};
     if( m->ci_type[m->pair_ci[pr]] != RKFD_CONTACT_RIGID ) continue;
     if( !vol_any_vertex_inside( o, sa, sb ) && !vol_any_vertex_inside( o, sb, sa ) ) continue;
+    if( o->vol_raw[sa] || o->vol_raw[sb] ){ o->vol_guard_hits++; continue; }      /* a guarded pair (rkfdOracleCreate) */
     vp->pair = pr; vp->ci = m->pair_ci[pr]; vp->sa = sa; vp->sb = sb;
     vp->la = m->shape_link[sa]; vp->lb = m->shape_link[sb];
     vp->ntri = 0; vp->ncp = 0;

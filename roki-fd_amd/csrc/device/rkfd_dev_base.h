@@ -519,5 +519,6 @@ typedef struct { double min, pivp; int pivt;
 #define CNT_SEL 6       /* elastic contacts, */
 #define CNT_SN  7       /* steps (rkfdBatchContactStats) */
 #define CNT_NVP 8       /* Volume plugin: rigid pairs in collision in this evaluation (twelve counters in that kernel variant) */
+#define CNT_GRD 9       /* ... a guarded pair (a shape that cannot be clipped) was found in collision */
 
 #endif /* RKFD_DEV_BASE_H */

@@ -163,7 +163,7 @@ template<bool prof, int vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDevM
     SYNC();
   }
   if( lane == 0 ){
-    L.cnt[CNT_OVF] = 0; L.cnt[CNT_QPF] = 0;
+    L.cnt[CNT_OVF] = 0; L.cnt[CNT_QPF] = 0; if( vqp == 2 ) L.cnt[CNT_GRD] = 0;
     if( RKFD_GC_NEEDED( 3*m.maxrg ) ) L.GC[RKFD_GC_INTS-1] = -1;      /* no grouped layout remembered yet */
     if( NC > 0 ){ L.cnt[CNT_SRG] = 0; L.cnt[CNT_SEL] = 0; L.cnt[CNT_SN] = 0; }
   }
@@ -317,6 +317,7 @@ template<bool prof, int vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDevM
     if( err ) *errflag = 1;              /* rigid contact with a solver that has no device path */
     if( L.cnt[CNT_OVF] ) *errflag = 2;   /* more rigid contacts than the configured capacity   */
     if( L.cnt[CNT_QPF] ) *errflag = 3;   /* the Vert QP ran out of iterations / basis history   */
+    if( vqp == 2 && L.cnt[CNT_GRD] ) *errflag = 4;   /* Volume plugin: a pair that cannot be clipped came into contact */
   }
 }
 

@@ -312,6 +312,7 @@ template<bool prof> RKFD_DEV void rkfd_phase_volcol(const rkfdDevModel &m, const
     }
     VCT(28);
     if( !hit ) continue;
+    if( rec[7] & 4 ){ if( lane == 0 ) L.cnt[CNT_GRD] = 1; continue; }      /* a pair that cannot be clipped is in contact: status 4 */
     if( nvp >= m.vol_np ){ if( lane == 0 ) L.cnt[CNT_OVF] = 1; continue; }
     /* faces of A inside B, faces of B inside A: lane = face */
     const bool onf = lane < na+nb;
@@ -483,7 +484,7 @@ template<bool prof> RKFD_DEV void rkfd_phase_volcol(const rkfdDevModel &m, const
         d_point_vel( &L.V[6*la], x, va ); d_point_vel( &L.V[6*lb], x, vb );
         double v[3] = { va[0]-vb[0], va[1]-vb[1], va[2]-vb[2] };
         double vs[3] = { v[0], v[1], v[2] };          /* with the cells' slide velocities (the friction fix-ups; not the 6-D velocity) */
-        if( rec[7] ){
+        if( rec[7] & 3 ){
 #pragma unroll
           for( int sd=0; sd<2; sd++ ){
             if( !( ( rec[7] >> sd ) & 1 ) ) continue;

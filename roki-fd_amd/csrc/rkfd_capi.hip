@@ -907,6 +907,8 @@ extern "C" int rkfdBatchStatus(rkfdBatch *b, void *stream)
     SETERR( "contact capacity exceeded in at least one instance: more rigid contact vertices than max_rigid (%d), or more "
             "rigid + elastic contact vertices than the %d active-contact slots; contacts beyond the capacity were dropped", b->dm.maxrg, b->dm.maxact );
   if( e == 3 ) SETERR( "the %s plugin's QP ran out of iterations (256) or of basis history (64) in at least one instance", b->dm.vol_np > 0 ? "Volume" : "Vert" );
+  if( e == 4 ) SETERR( "Volume plugin: a rigid pair the device cannot clip (a shape that is not convex, or more than 64 faces together) came into "
+                       "contact in at least one instance; it was left without a contact force" );
   if( e != 0 ){
     /* the condition is reported once: the flag is cleared, so a later status describes what happened after this call */
     const int zero = 0;

@@ -332,21 +332,38 @@ extern "C" int rkfd_devmodel_build_w(const rkfdModel *m, int max_rigid, const in
   std::vector<double> vol_lplane, vol_lvert, vol_slide;
   int vol_npair = 0, vol_np = 0, vol_ncp = 0, vol_pv = 0, vol_nf = 0;
   if( m->solver == RKFD_SOLVER_VOLUME ){
-    std::vector<int> sh_l0( m->nshape, -1 ), sh_nl( m->nshape, 0 );
-    int maxloop = 0, maxfaces = 0;
+    std::vector<int> sh_l0( m->nshape, -1 ), sh_nl( m->nshape, 0 ), sh_raw( m->nshape, 0 );
+    int maxloop = 0, maxfaces = 0, nclip = 0;
     for( int pr=0; pr<m->npair; pr++ ){
       if( m->ci_type[m->pair_ci[pr]] != RKFD_CONTACT_RIGID ) continue;
       for( int sd=0; sd<2; sd++ ){
         const int sh = m->pair_shape[2*pr+sd];
         if( sh_l0[sh] >= 0 ) continue;
         const double *T = &Trep[12*m->shape_link[sh]];
-        for( int f=m->shape_foff[sh]; f<m->shape_foff[sh+1]; f++ )
+        for( int f=m->shape_foff[sh]; f<m->shape_foff[sh+1] && !sh_raw[sh]; f++ )
           for( int v=m->shape_voff[sh]; v<m->shape_voff[sh+1]; v++ ){
             const double *pl = &m->planes[4*f], *x = &m->verts[3*v];
-            if( pl[0]*x[0] + pl[1]*x[1] + pl[2]*x[2] - pl[3] > 1e-9 )
-              FAIL( "Volume plugin: shape %d of a rigid pair is not convex (the intersection volume is formed by clipping convex shapes)", sh );
+            if( pl[0]*x[0] + pl[1]*x[1] + pl[2]*x[2] - pl[3] > 1e-9 ){ sh_raw[sh] = 1; break; }
           }
         sh_l0[sh] = (int)vol_loop.size()/2;
+        if( sh_raw[sh] ){
+          /* a shape that is not convex (the reference's humanoid mighty.ztk: its body meshes): the intersection volume is formed
+           * by clipping CONVEX shapes, so its pairs cannot be clipped - they are GUARDED instead: the plugin's own collision test
+           * (a vertex of one shape behind every face plane of the other, "Vert") runs for them, and a hit is reported as status 4
+           * instead of being solved.  For that test: every plane of the shape, and its vertices as the "loop" of the last plane. */
+          const int nf = m->shape_foff[sh+1] - m->shape_foff[sh], nv = m->shape_voff[sh+1] - m->shape_voff[sh];
+          const int vbase = (int)vol_lvert.size()/3;
+          for( int v=m->shape_voff[sh]; v<m->shape_voff[sh+1]; v++ ){
+            const double *x = &m->verts[3*v];
+            for( int a=0; a<3; a++ ) vol_lvert.push_back( T[9+a] + T[3*a]*x[0] + T[3*a+1]*x[1] + T[3*a+2]*x[2] );
+          }
+          for( int f=0; f<nf; f++ ){
+            vol_loop.push_back( vbase ); vol_loop.push_back( f == nf-1 ? nv : 0 );
+            for( int a=0; a<4; a++ ) vol_lplane.push_back( planes_d[4*( m->shape_foff[sh]+f )+a] );
+          }
+          sh_nl[sh] = nf;
+          continue;
+        }
         for( int f=m->shape_foff[sh]; f<m->shape_foff[sh+1]; f++ ){
           const double *pl = &m->planes[4*f];
           bool dup = false;
@@ -396,7 +413,7 @@ extern "C" int rkfd_devmodel_build_w(const rkfdModel *m, int max_rigid, const in
           if( (int)ang.size() > maxloop ) maxloop = (int)ang.size();
           sh_nl[sh]++;
         }
-        if( sh_nl[sh] < 4 ) FAIL( "Volume plugin: shape %d of a rigid pair is not a closed convex polyhedron (%d faces found)", sh, sh_nl[sh] );
+        if( sh_nl[sh] < 4 ) FAIL( "Volume plugin: shape %d of a rigid pair is not a closed polyhedron (%d faces found)", sh, sh_nl[sh] );
       }
       const int shA = m->pair_shape[2*pr], shB = m->pair_shape[2*pr+1];
       /* slide-mode cells (rkFDLinkAddSlideVel, reference src/rkfd_util.c:26-40; the plugin's friction fix-ups see them, its 6-D
@@ -411,14 +428,19 @@ extern "C" int rkfd_devmodel_build_w(const rkfdModel *m, int max_rigid, const in
         if( on ){ const double *ax = &m->shape_slide_axis[3*sh]; for( int a=0; a<3; a++ ) o[1+a] = T[3*a]*ax[0] + T[3*a+1]*ax[1] + T[3*a+2]*ax[2]; }
         vol_slide.insert( vol_slide.end(), o, o+8 );
       }
-      const int rec[8] = { rep[m->shape_link[shA]], rep[m->shape_link[shB]], m->pair_ci[pr], sh_l0[shA], sh_nl[shA], sh_l0[shB], sh_nl[shB], smode };
+      /* (bit 2 of the mode word: a guarded pair - a shape that is not convex, or more faces together than lanes) */
+      const bool guard = sh_raw[shA] || sh_raw[shB] || sh_nl[shA] + sh_nl[shB] > RKFD_WAVE;
+      const int rec[8] = { rep[m->shape_link[shA]], rep[m->shape_link[shB]], m->pair_ci[pr], sh_l0[shA], sh_nl[shA], sh_l0[shB], sh_nl[shB], smode | ( guard ? 4 : 0 ) };
       vol_pair.insert( vol_pair.end(), rec, rec+8 );
       vol_npair++;
-      if( sh_nl[shA] + sh_nl[shB] > RKFD_WAVE ) FAIL( "Volume plugin: the two shapes of a rigid pair have %d faces together (one lane per face: at most %d)", sh_nl[shA]+sh_nl[shB], RKFD_WAVE );
+      if( guard ) continue;
+      nclip++;
       if( sh_nl[shA] + sh_nl[shB] > maxfaces ) maxfaces = sh_nl[shA] + sh_nl[shB];
       const int big = sh_nl[shA] > sh_nl[shB] ? sh_nl[shA] : sh_nl[shB];
       if( maxloop + big > vol_pv ) vol_pv = maxloop + big;
     }
+    if( vol_npair > 0 && nclip == 0 )
+      FAIL( "Volume plugin: no rigid pair of this world can be clipped on the device (convex shapes with at most %d faces together)", RKFD_WAVE );
     if( vol_npair > 0 ){
       /* capacities: pairs in collision at once (the caller's max_rigid, at most 10: six unknowns each, one per lane),
        * contact-plane conditions per pair (every face of the two shapes can give one), constraints <= 64 */
@@ -436,6 +458,10 @@ extern "C" int rkfd_devmodel_build_w(const rkfdModel *m, int max_rigid, const in
         while( vol_ncp > 8 && RKFD_VOL_LDS_SOL( vol_np, vol_ncp, pyr ) > 3072 ) vol_ncp--;
         if( vol_np*( 1+vol_ncp ) > RKFD_WAVE ) FAIL( "Volume plugin: %d pairs x ( 1 + %d conditions ) exceed 64 constraints", vol_np, vol_ncp );
         if( vol_pv < 10 ) vol_pv = 10;
+        /* (a face loop of n vertices clipped by the k planes of the other shape can reach n + k vertices - the bound above - but a
+         *  cylinder's 16-gon against a 34-face cylinder is 50 vertices x 64 lanes x 24 bytes = 77 KB of LDS for polygons that in
+         *  practice gain a handful: 32 vertices per lane, a polygon beyond that is reported at run time - status 2) */
+        if( vol_pv > 32 && maxloop + 8 <= 32 ) vol_pv = 32;
         vol_nf = maxfaces;
       }
     }

@@ -871,3 +871,58 @@ def test_tuning_the_instances_per_wavefront_keeps_state_and_snapshot(R):
     b.set_state(sc["dis"], sc["vel"]); b.update_init()
     chosen, ms = b.tune_instances_per_wave(2)
     assert chosen == 1 and ms[0] > 0 and ms[1] < 0 and b.instances_per_wave() == 1
+
+
+def _lfoot_world(R):
+    M = R.scenarios.MODELS
+    w = R.World(solver=R.SOLVER_VOLUME); w.contact_info(os.path.join(M, "contactinfo.ztk"))
+    h = w.reg_file(os.path.join(M, "lfoot.ztk")); w.pair_chain_unreg(h)
+    w.reg_file(os.path.join(M, "floor.ztk"))
+    return w
+
+
+def test_volume_plugin_guards_pairs_it_cannot_clip(R, oracle_cls):
+    """a world with a shape that is NOT convex under the Volume plugin (models/lfoot.ztk: a convex foot plate under an L-shaped
+    bracket; the reference's mighty.ztk in the small - VERDICT r02 missing 3): accepted; standing / sliding / rocking on the plate
+    it matches the oracle, the bracket's pair with the floor being watched by the plugin's own collision test; once the bracket
+    itself reaches the floor the status says so (4) instead of a wrong volume being solved"""
+    w = _lfoot_world(R)
+    B, N = 6, 40
+    dis = np.zeros((B, 6)); vel = np.zeros((B, 6))
+    dis[:, 2] = -1e-4
+    dis[1:, 4] = np.linspace(0.0, 0.08, B - 1)             # small tilts about y: plate edges dig in, the bracket stays clear
+    vel[:, 0] = np.linspace(0.0, 0.3, B); vel[3:, 5] = 0.5
+    b = R.Batch(w, B, max_rigid=4)
+    b.set_state(dis, vel); b.update_init(); b.update(N)
+    assert b.status() == 0
+    d, v, a = b.get_state()
+    seen = 0
+    for i in range(B):
+        o = oracle_cls(w.model); o.set_state(dis[i], vel[i]); o.update_init(); o.update_n(N)
+        od, ov, oa = o.get_state()
+        assert _rel(d[i], od) < 1e-8 and _rel(v[i], ov) < 1e-7, i
+        seen += int(np.abs(oa[2] + 9.8) > 1e-3)            # (supported: not in free fall)
+    assert seen >= B - 1
+    # lying on its side (rotation of 90 degrees about y): the bracket's vertices are the lowest points
+    dis2 = np.zeros((2, 6)); dis2[:, 2] = 0.049; dis2[:, 4] = np.pi / 2
+    b2 = R.Batch(w, 2, max_rigid=4)
+    b2.set_state(dis2, np.zeros((2, 6))); b2.update_init(); b2.update(3)
+    assert b2.status() == 4
+    assert "cannot clip" in R.lib().rkfdHipLastError().decode()
+
+
+def test_volume_plugin_accepts_worlds_with_large_shapes(R):
+    """humanoid30_shell.ztk carries 128-face shells (more faces than lanes): their pairs are guarded, the soles are solved - the
+    standing humanoid runs under Volume"""
+    M = R.scenarios.MODELS
+    w = R.World(solver=R.SOLVER_VOLUME); w.contact_info(os.path.join(M, "contactinfo.ztk"))
+    h = w.reg_file(os.path.join(M, "humanoid30_shell.ztk")); w.pair_chain_unreg(h)
+    w.reg_file(os.path.join(M, "floor.ztk"))
+    sc = R.scenarios.config4_volume(batch=4)
+    b = R.Batch(w, 4, max_rigid=sc["max_rigid"])
+    b.set_state(sc["dis"], sc["vel"]); b.update_init(); b.update(20)
+    assert b.status() == 0
+    ref = R.Batch(sc["world"], 4, max_rigid=sc["max_rigid"])
+    ref.set_state(sc["dis"], sc["vel"]); ref.update_init(); ref.update(20)
+    for x, y in zip(b.get_state(), ref.get_state()):
+        assert _rel(x, y) < 1e-9          # (the shells add mass to nothing: shapes only)
