@@ -528,3 +528,33 @@ def test_emulated_vert_qp_wide_form(R, oracle_cls):
         for x, y in ((d[i], od), (v[i], ov), (a[i], oa)):
             assert np.abs(x - y).max() / max(1.0, np.abs(y).max()) < 1e-9
         assert np.abs(f[i] - of * (oact[:, None] != 0)).max() / max(1.0, np.abs(of).max()) < 1e-8
+
+
+def test_emulated_volume_plugin_guards_a_shape_that_is_not_convex(R, oracle_cls):
+    """models/lfoot.ztk under the Volume plugin (a convex foot plate under an L-shaped bracket): on its plate the device code
+    matches the oracle and the bracket's pair with the floor is only watched; lying on its side the bracket reaches the floor:
+    status 4 on the device, a counted guard hit in the oracle, no force from that pair in either"""
+    import os
+    M = R.scenarios.MODELS
+    w = R.World(solver=R.SOLVER_VOLUME); w.contact_info(os.path.join(M, "contactinfo.ztk"))
+    h = w.reg_file(os.path.join(M, "lfoot.ztk")); w.pair_chain_unreg(h)
+    w.reg_file(os.path.join(M, "floor.ztk"))
+    dis = np.zeros((2, 6)); vel = np.zeros((2, 6))
+    dis[:, 2] = -1e-4; dis[1, 4] = 0.05; vel[:, 0] = (0.0, 0.1)
+    eb = EmuBatch(w, 2, max_rigid=4)
+    eb.set_state(dis, vel); eb.update_init(); eb.update(6)
+    assert eb.status() == 0
+    d, v, a = eb.get_state()
+    for i in range(2):
+        o = oracle_cls(w.model); o.set_state(dis[i], vel[i]); o.update_init(); o.update_n(6)
+        assert o.volume_guard_hits() == 0
+        for x, y in zip((d[i], v[i], a[i]), o.get_state()):
+            assert np.abs(x - y).max() / max(1.0, np.abs(y).max()) < 1e-9
+    side = np.zeros((1, 6)); side[0, 2] = 0.049; side[0, 4] = np.pi / 2
+    eb = EmuBatch(w, 1, max_rigid=4)
+    eb.set_state(side, np.zeros((1, 6))); eb.update_init(); eb.update(2)
+    assert eb.status() == 4
+    o = oracle_cls(w.model); o.set_state(side[0], np.zeros(6)); o.update_init(); o.update_n(2)
+    assert o.volume_guard_hits() > 0
+    for x, y in zip(eb.get_state(), o.get_state()):
+        assert np.abs(x[0] - y).max() / max(1.0, np.abs(y).max()) < 1e-9
