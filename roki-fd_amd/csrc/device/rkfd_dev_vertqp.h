@@ -77,18 +77,18 @@ template<bool pk> RKFD_DEV double rkfd_w_back(const double *Mx, int ld, int n, d
 #    define RKFD_QP_NQ RKFD_QP_NQ_MAX
 #  endif
 #endif
-#define RKFD_QP_NQA ( RKFD_QP_NQ > 0 ? RKFD_QP_NQ : 1 )
-typedef struct {
-  double Lr[RKFD_QP_NQA];      /* L[lane][j], j < lane (else 0) */
-  double Lt[RKFD_QP_NQA];      /* L[j][lane], j > lane (else 0) */
-  double rd;                   /* 1 / L[lane][lane] */
-} rkfdQpFactor;
-RKFD_DEV void rkfd_qreg_load(rkfdQpFactor &F, const double *Q, int n)
+template<int NQ> struct rkfdQpFactorT {
+  double Lr[NQ > 0 ? NQ : 1];      /* L[lane][j], j < lane (else 0) */
+  double Lt[NQ > 0 ? NQ : 1];      /* L[j][lane], j > lane (else 0) */
+  double rd;                       /* 1 / L[lane][lane] */
+};
+typedef rkfdQpFactorT<RKFD_QP_NQ> rkfdQpFactor;
+template<int NQ> RKFD_DEV void rkfd_qreg_load(rkfdQpFactorT<NQ> &F, const double *Q, int n)
 {
   const int lane = LANE();
   const int base = ( lane*( lane+1 ) ) >> 1;
 #pragma unroll
-  for( int j=0; j<RKFD_QP_NQ; j++ ){
+  for( int j=0; j<NQ; j++ ){
     F.Lr[j] = ( j < lane && lane < n ) ? Q[base + j] : 0.0;
     F.Lt[j] = ( j > lane && j < n ) ? Q[RKFD_QI( j, lane )] : 0.0;
   }
@@ -99,32 +99,32 @@ RKFD_DEV void rkfd_qreg_load(rkfdQpFactor &F, const double *Q, int n)
  * left-looking rkfd_w_chol subtracts them (same operands, same order: same bits); the values a step needs from another lane come
  * by v_readlane, nothing goes through LDS until the factor is stored at the end (packed, for the transposed read of
  * rkfd_qreg_load).  24 k cycles of LDS round trips per QP became 6 k. */
-RKFD_DEV void rkfd_qreg_chol(double *Q, int n)
+template<int NQ> RKFD_DEV void rkfd_qreg_chol(double *Q, int n)
 {
   const int lane = LANE();
   const int base = ( lane*( lane+1 ) ) >> 1;
-  double R[RKFD_QP_NQA];
+  double R[NQ > 0 ? NQ : 1];
 #pragma unroll
-  for( int j=0; j<RKFD_QP_NQ; j++ ) R[j] = ( j <= lane && lane < n ) ? Q[base + j] : 0.0;
+  for( int j=0; j<NQ; j++ ) R[j] = ( j <= lane && lane < n ) ? Q[base + j] : 0.0;
 #pragma unroll
-  for( int k=0; k<RKFD_QP_NQ; k++ ){
+  for( int k=0; k<NQ; k++ ){
     if( k < n ){
       const double rinv = RKFD_RCP( sqrt( BCAST( R[k], k ) ) );
       R[k] = lane == k ? rinv : R[k]*rinv;
 #pragma unroll
-      for( int c=k+1; c<RKFD_QP_NQ; c++ ) R[c] = fma( -R[k], BCAST( R[k], c ), R[c] );
+      for( int c=k+1; c<NQ; c++ ) R[c] = fma( -R[k], BCAST( R[k], c ), R[c] );
     }
   }
 #pragma unroll
-  for( int j=0; j<RKFD_QP_NQ; j++ ) if( j <= lane && lane < n ) Q[base + j] = R[j];
+  for( int j=0; j<NQ; j++ ) if( j <= lane && lane < n ) Q[base + j] = R[j];
 }
 /* y = L^-1 b for two right-hand sides at once (lane i passes b_i, receives y_i); rows above j0 are known to be zero in both */
-RKFD_DEV void rkfd_qreg_fwd2(const rkfdQpFactor &F, int n, int j0, double &a, double &b)
+template<int NQ> RKFD_DEV void rkfd_qreg_fwd2(const rkfdQpFactorT<NQ> &F, int n, int j0, double &a, double &b)
 {
   const int lane = LANE();
   double sa = a, sb = b, ya = 0, yb = 0;
 #pragma unroll
-  for( int j=0; j<RKFD_QP_NQ; j++ ){
+  for( int j=0; j<NQ; j++ ){
     if( j >= j0 && j < n ){
       const double pa = BCAST( sa*F.rd, j ), pb = BCAST( sb*F.rd, j );
       if( lane == j ){ ya = pa; yb = pb; }
@@ -133,12 +133,12 @@ RKFD_DEV void rkfd_qreg_fwd2(const rkfdQpFactor &F, int n, int j0, double &a, do
   }
   a = ya; b = yb;
 }
-RKFD_DEV double rkfd_qreg_fwd(const rkfdQpFactor &F, int n, double bi)
+template<int NQ> RKFD_DEV double rkfd_qreg_fwd(const rkfdQpFactorT<NQ> &F, int n, double bi)
 {
   const int lane = LANE();
   double s = bi, yi = 0;
 #pragma unroll
-  for( int j=0; j<RKFD_QP_NQ; j++ ){
+  for( int j=0; j<NQ; j++ ){
     if( j < n ){
       const double yj = BCAST( s*F.rd, j );
       if( lane == j ) yi = yj;
@@ -148,12 +148,12 @@ RKFD_DEV double rkfd_qreg_fwd(const rkfdQpFactor &F, int n, double bi)
   return yi;
 }
 /* x = L^-T y */
-RKFD_DEV double rkfd_qreg_back(const rkfdQpFactor &F, int n, double yi)
+template<int NQ> RKFD_DEV double rkfd_qreg_back(const rkfdQpFactorT<NQ> &F, int n, double yi)
 {
   const int lane = LANE();
   double s = yi, xi = 0;
 #pragma unroll
-  for( int j=RKFD_QP_NQ-1; j>=0; j-- ){
+  for( int j=NQ-1; j>=0; j-- ){
     if( j < n ){
       const double xj = BCAST( s*F.rd, j );
       if( lane == j ) xi = xj;
@@ -163,11 +163,11 @@ RKFD_DEV double rkfd_qreg_back(const rkfdQpFactor &F, int n, double yi)
   return xi;
 }
 /* ( L' v )_lane: v_lane / rd + sum over j > lane of L[j][lane] v_j, the terms in ascending j */
-RKFD_DEV double rkfd_qreg_ltv(const rkfdQpFactor &F, int n, double vi)
+template<int NQ> RKFD_DEV double rkfd_qreg_ltv(const rkfdQpFactorT<NQ> &F, int n, double vi)
 {
   double u = vi/F.rd;
 #pragma unroll
-  for( int j=0; j<RKFD_QP_NQ; j++ ) if( j < n ) u = fma( F.Lt[j], BCAST( vi, j ), u );
+  for( int j=0; j<NQ; j++ ) if( j < n ) u = fma( F.Lt[j], BCAST( vi, j ), u );
   return u;
 }
 
@@ -290,7 +290,7 @@ template<bool prof> RKFD_DEV unsigned long long rkfd_vert_qp(const rkfdDevModel 
     }
   }
   SYNC();
-  if( reg ) rkfd_qreg_chol( Q, n ); else rkfd_w_chol<true>( Q, 0, n );
+  if( reg ) rkfd_qreg_chol<RKFD_QP_NQ>( Q, n ); else rkfd_w_chol<true>( Q, 0, n );
   rkfdQpFactor F;
   F.rd = 0.0;
   if( reg ){ SYNC(); rkfd_qreg_load( F, Q, n ); }

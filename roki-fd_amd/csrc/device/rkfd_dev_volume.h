@@ -613,9 +613,22 @@ RKFD_DEV double rkfd_vol_pinv(double *S, double *EV, double *vec, int ld, int r,
 /* rkFDQPSolveASM (reference src/rkfd_opt_qp.c:43-181) for the Volume plugin: min x'Qx/2 + c'x s.t. G x >= 0, G's row
  * lane touching the six unknowns of its pair; start point init (lane = unknown).  In: L.VQL = Q (packed lower triangle),
  * cv; out: ans (L.VQV + 2n).  lane = constraint as well (mc <= 64). */
-RKFD_DEV void rkfd_vol_qp(const rkfdLds &L, int n, int mc, const double *g, int gp, double init)
+/* With at most RKFD_VQ_NQ = 24 unknowns (four pairs in contact at once) the factor of Q lives in registers as in the Vert QP
+ * (rkfd_dev_vertqp.h: rkfdQpFactorT - same arithmetic per entry, same bits): the factorisation, z, the columns of W two per pass
+ * with lane = row, the back substitution and the objective without a trip through LDS per term. */
+#ifndef RKFD_VQ_NQ
+#  if defined(RKFD_SPEC)
+#    define RKFD_VQ_NQ ( ( RKFD_SPEC_VOL_NP > 0 && 6*RKFD_SPEC_VOL_NP <= 24 ) ? 6*RKFD_SPEC_VOL_NP : 0 )
+#  else
+#    define RKFD_VQ_NQ 24
+#  endif
+#endif
+RKFD_DEV void rkfd_vol_qp(const rkfdLds &L, int n, int mc, const double *g, int gp, double init, int nmax)
 {
   const int lane = LANE();
+  const bool reg = RKFD_VQ_NQ > 0 && nmax <= RKFD_VQ_NQ;
+  rkfdQpFactorT<RKFD_VQ_NQ> F;
+  F.rd = 0.0;
   const int ldw = mc > 0 ? mc : 1;
   double *Q = L.VQL, *W = L.VQW, *S = L.VS, *EV = L.VEV;
   double *cv = L.VQV, *zv = L.VQV + n, *ans = L.VQV + 2*n, *xv = L.VQV + 3*n, *dv = L.VQV + 4*n;
@@ -623,9 +636,11 @@ RKFD_DEV void rkfd_vol_qp(const rkfdLds &L, int n, int mc, const double *g, int 
   const bool onc = lane < mc;
   if( lane < n ) ans[lane] = init;
   SYNC();
-  rkfd_w_chol<true>( Q, 0, n );
+  if( reg ){ rkfd_qreg_chol<RKFD_VQ_NQ>( Q, n ); SYNC(); rkfd_qreg_load( F, Q, n ); }
+  else rkfd_w_chol<true>( Q, 0, n );
   {
-    const double zi = rkfd_w_fwd<true>( Q, 0, n, lane < n ? cv[lane] : 0.0 );
+    const double ci = lane < n ? cv[lane] : 0.0;
+    const double zi = reg ? rkfd_qreg_fwd( F, n, ci ) : rkfd_w_fwd<true>( Q, 0, n, ci );
     if( lane < n ) zv[lane] = zi;
   }
   SYNC();
@@ -640,7 +655,28 @@ RKFD_DEV void rkfd_vol_qp(const rkfdLds &L, int n, int mc, const double *g, int 
     const int r = __builtin_popcountll( mask );
     const int rho = __builtin_popcountll( mask & ( lane == 0 ? 0ull : ( ~0ull >> ( 64-lane ) ) ) );
     /* W = L^-1 G' (column rho = this lane's active row), S = W'W, rhs = W'z */
-    if( onc && act ){
+    if( reg ){
+      /* lane = row; the active rows in ascending lane order (their columns rho = 0, 1, ...), two per pass */
+      unsigned long long mk = mask;
+      for( int a0=0; a0<r; a0+=2 ){
+        const int l0 = __builtin_ctzll( mk ); mk &= mk - 1ull;
+        int l1 = l0;
+        if( a0+1 < r ){ l1 = __builtin_ctzll( mk ); mk &= mk - 1ull; }
+        const int p0 = 6*BCASTI( gp, l0 ), p1 = 6*BCASTI( gp, l1 );
+        double y0 = 0, y1 = 0;
+#pragma unroll
+        for( int k=0; k<6; k++ ){
+          const double g0k = BCAST( g[k], l0 ), g1k = BCAST( g[k], l1 );
+          if( lane == p0+k ) y0 = g0k;
+          if( lane == p1+k ) y1 = g1k;
+        }
+        rkfd_qreg_fwd2( F, n, p0 < p1 ? p0 : p1, y0, y1 );
+        if( lane < n ){
+          W[lane*ldw+a0] = lane < p0 ? 0.0 : y0;
+          if( l1 != l0 ) W[lane*ldw+a0+1] = lane < p1 ? 0.0 : y1;
+        }
+      }
+    } else if( onc && act ){
       for( int i=0; i<n; i++ ){
         const int k = i - 6*gp;
         double sacc = ( k >= 0 && k < 6 ) ? ( k == 0 ? g[0] : ( k == 1 ? g[1] : ( k == 2 ? g[2] : ( k == 3 ? g[3] : ( k == 4 ? g[4] : g[5] ) ) ) ) ) : 0.0;
@@ -671,7 +707,7 @@ RKFD_DEV void rkfd_vol_qp(const rkfdLds &L, int n, int mc, const double *g, int 
         for( int a=0; a<r; a++ ) ti = fma( W[lane*ldw+a], lam[a], ti );
         ti -= zv[lane];
       }
-      const double xi = rkfd_w_back<true>( Q, 0, n, ti );
+      const double xi = reg ? rkfd_qreg_back( F, n, ti ) : rkfd_w_back<true>( Q, 0, n, ti );
       if( lane < n ) xv[lane] = xi;
     }
     SYNC();
@@ -698,7 +734,11 @@ RKFD_DEV void rkfd_vol_qp(const rkfdLds &L, int n, int mc, const double *g, int 
     SYNC();
     if( onc && !act && fabs( RKFD_VOL_COND( ans ) - 0.0 ) < RKFD_DEV_TOL ) act = 1;
     double part = 0;
-    if( lane < n ){
+    if( reg ){
+      const double ai = lane < n ? ans[lane] : 0.0;
+      const double u = rkfd_qreg_ltv( F, n, ai );
+      if( lane < n ) part = 0.5*u*u + cv[lane]*ai;
+    } else if( lane < n ){
       double u = ans[lane]/Q[RKFD_QI( lane, lane )];
       for( int j=lane+1; j<n; j++ ) u = fma( Q[RKFD_QI( j, lane )], ans[j], u );
       part = 0.5*u*u + cv[lane]*ans[lane];
@@ -1148,7 +1188,7 @@ template<bool prof> RKFD_DEV void rkfd_phase_volume(const rkfdDevModel &m, const
   if( lane < n ){ const int c = lane/6, i = lane - 6*c; init = i < 3 ? L.VD[RKFD_VD*c + RKFD_VD_AX + i] : 0.0; }
   SYNC();
   VST(24);
-  rkfd_vol_qp( L, n, mc, g, gp, init );
+  rkfd_vol_qp( L, n, mc, g, gp, init, 6*m.vol_np );
   VST(25);
   /* _rkFDSolverQP (:547), _rkFDSolverSetForce (:552-568; the offset stays behind a pair without conditions, as in the reference) */
   {
