@@ -396,7 +396,7 @@ typedef struct {
   /* Volume plugin (kernel variant sv == 2 only; rkfd_dev_volume.h): per colliding pair VD [np*48] and its contact-plane
    * conditions VPL [np*ncp*8]; face polygons VPOLY [nf*pv*3] and reduction scratch VRED [16*nf+16] of the collision phase, sharing
    * their storage with the solve's:
-   * QP: VQL [n(n+1)/2] Q / its factor, VQW [n*mc], VS, VEV [mc*mc], VQV [5n + mc + 64]; simplex workspace VLP; VI [np*2]
+   * QP: VQL [n(n+1)/2] Q / its factor, VQW [n*mc], VS, VEV [mc*mc], VQV [5n + mc]; simplex workspace VLP (over the QP arrays); VI [np*2]
    * conditions of a pair, its model pair.  n = 6 np, mc = np ( 1 + ncp ). */
   double *VD, *VPL, *VPOLY, *VRED, *VQL, *VQW, *VS, *VEV, *VQV, *VLP;
   int *VI;
@@ -437,7 +437,7 @@ RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int
   L->CF = d; d += maxact*3;
   L->SV = d; L->SD = d; if( has_slide ){ L->SV = d; d += maxact*3; L->SD = d; d += maxact*3; }
   /* PGS: a lane reads its three entries of b before it writes its three forces, so they share storage */
-  L->MB = d; d += M; L->MF = L->MB; if( vert_rigid || vol_np ){ L->MF = d; d += M; }
+  L->MB = d; d += M; L->MF = L->MB; if( vert_rigid ){ L->MF = d; d += M; }      /* (Volume plugin: the forces are written when the bias is long dead) */
   /* probe scratch: lives while the contact problem is set up and solved, when C and PA are dead */
   if( pu_alias ) L->PU = L->C; else { L->PU = d; d += nside*npurow*M; }
   L->QL = d; L->QW = d; L->QV = d; L->CR = d;
@@ -451,7 +451,7 @@ RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int
     L->VPOLY = d; L->VRED = d + vol_nf*vol_pv*3;
     double *e = d;
     L->VQL = e; e += n*( n+1 )/2; L->VQW = e; e += n*mc; L->VS = e; e += mc*mc; L->VEV = e; e += mc*mc;
-    L->VQV = e; e += 5*n + mc + 64; L->VLP = e; e += 8*pyramid*vol_ncp + 6;
+    L->VQV = e; e += 5*n + mc; L->VLP = d;      /* (the simplex's workspace overlays the QP's arrays, dead by then) */
     d += RKFD_VOL_LDS_COL( vol_nf, vol_pv ) > RKFD_VOL_LDS_SOL( vol_np, vol_ncp, pyramid ) ? RKFD_VOL_LDS_COL( vol_nf, vol_pv ) : RKFD_VOL_LDS_SOL( vol_np, vol_ncp, pyramid );
   }
   int *ip = (int *)d;

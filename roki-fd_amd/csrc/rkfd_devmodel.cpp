@@ -727,7 +727,7 @@ extern "C" int rkfd_devmodel_build_w(const rkfdModel *m, int max_rigid, const in
     size_t stage = (size_t)14*NL + pool;                         /* inertia staging + Ia pool ...   */
     if( (size_t)dm.ma_size > stage ) stage = (size_t)dm.ma_size;   /* ... shared with the contact matrix */
     const size_t dbl = (size_t)NL*( 5*6 + 3 ) + stage + (size_t)33*nfloat
-                     + (size_t)maxact*( 21 + ( NC > RKFD_WAVE/2 ? 3 : 0 ) + ( dm.has_slide ? 6 : 0 ) ) + ( ( dm.vert_rigid || vol_np > 0 ) ? 2 : 1 )*M + ( dm.pu_alias ? 0 : (size_t)nside*npurow*M )
+                     + (size_t)maxact*( 21 + ( NC > RKFD_WAVE/2 ? 3 : 0 ) + ( dm.has_slide ? 6 : 0 ) ) + ( dm.vert_rigid ? 2 : 1 )*M + ( dm.pu_alias ? 0 : (size_t)nside*npurow*M )
                      + ( dm.vert_rigid ? ( dm.vert_rigid == 2 ? 0 : M*M ) + M*( M+1 )/2 + 5*M + 3*M : 0 )   /* Vert QP: QL, QW, QV, CR */
                      + ( dm.vert_rigid == 3 ? (size_t)dm.pyramid*M + (size_t)dm.pyramid*max_rigid : 0 )             /* ... wide form: QG, QY */
                      + ( vol_np > 0 ? (size_t)RKFD_VOL_LDS_DOUBLES( vol_np, vol_ncp, vol_pv, vol_nf, dm.pyramid ) : 0 );

@@ -143,8 +143,13 @@ typedef struct {
  * (face polygons nf x pv x 3, reduction 16 nf + 16) and the solve's (Q n(n+1)/2, W n mc, S and EV mc^2 each, vectors 5n + mc + 64,
  * simplex 8 pyr ncp + 6), n = 6 np, mc = np ( 1 + ncp ) */
 #define RKFD_VOL_LDS_COL(nf, pv) ( (nf)*(pv)*3 + 16*(nf) + 16 )
+/* (the QP's arrays - VQL, VQW, VS, VEV, VQV - and the friction simplex's workspace VLP overlay each other: the wrenches have left
+ *  the QP for the pair records before the first LP is set up) */
+#define RKFD_VOL_LDS_QP(np, ncp) \
+  ( ( 6*(np) )*( 6*(np)+1 )/2 + 6*(np)*(np)*( 1+(ncp) ) + 2*(np)*( 1+(ncp) )*(np)*( 1+(ncp) ) + ( 30*(np) + (np)*( 1+(ncp) ) ) )
+#define RKFD_VOL_LDS_LP(ncp, pyr) ( 8*(pyr)*(ncp) + 6 )
 #define RKFD_VOL_LDS_SOL(np, ncp, pyr) \
-  ( ( 6*(np) )*( 6*(np)+1 )/2 + 6*(np)*(np)*( 1+(ncp) ) + 2*(np)*( 1+(ncp) )*(np)*( 1+(ncp) ) + ( 30*(np) + (np)*( 1+(ncp) ) + 64 ) + ( 8*(pyr)*(ncp) + 6 ) )
+  ( RKFD_VOL_LDS_QP( np, ncp ) > RKFD_VOL_LDS_LP( ncp, pyr ) ? RKFD_VOL_LDS_QP( np, ncp ) : RKFD_VOL_LDS_LP( ncp, pyr ) )
 #define RKFD_VOL_LDS_DOUBLES(np, ncp, pv, nf, pyr) \
   ( (np)*48 + (np)*(ncp)*8 + ( RKFD_VOL_LDS_COL( nf, pv ) > RKFD_VOL_LDS_SOL( np, ncp, pyr ) ? RKFD_VOL_LDS_COL( nf, pv ) : RKFD_VOL_LDS_SOL( np, ncp, pyr ) ) )
 

