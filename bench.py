@@ -418,8 +418,10 @@ def main():
             # what bounds the kernel: VALU instruction issue.  Instructions per instance-step from the rocprofv3
             # SQ_INSTS_VALU pass on file; one wave-wide VALU instruction occupies its SIMD for 4 cycles (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.02
             # quad-cycles measured); 256 CUs x 4 SIMDs.  The clock under this kernel is ~1.8-2.0 GHz, the nominal 2.4 GHz is used.
-            ips = vi * Bn / (step_ms * 1e-3)
-            res["valu_issue"] = {"valu_insts_per_instance_step": vi, "simd_busy_fraction_at_2.4GHz": ips * 4.0 / (256 * 4 * 2.4e9), "source": vi_note}
+            # (SQ_INSTS_VALU / SQ_WAVES is per WAVEFRONT: with two instances per wavefront it serves both)
+            ipw_now = max(1, b.instances_per_wave())
+            ips = vi * (Bn / ipw_now) / (step_ms * 1e-3)
+            res["valu_issue"] = {"valu_insts_per_instance_step": vi / ipw_now, "valu_insts_per_wavefront_step": vi, "simd_busy_fraction_at_2.4GHz": ips * 4.0 / (256 * 4 * 2.4e9), "source": vi_note}
         if world == 1 and not args.no_cpu_baseline:      # the CPU baseline is a single-GPU-run figure (rank 0, N = 1)
             res["cpu_baseline"] = cpu_baseline(R, args.workload, H)
             res["cpu_baseline_all_cores"] = cpu_baseline_all_cores(R, args.workload, H)

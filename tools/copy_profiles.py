@@ -52,3 +52,19 @@ open(f"profiles/{tag}_traffic_calibration.txt", "a").write("calibration (known b
 for f in ("ubench_pgs.txt",):
     if os.path.exists("gpurun_out/" + f):
         shutil.copy("gpurun_out/" + f, f"profiles/{tag}_" + f)
+# the other bench lines of the collection, the Volume plugin's phase cycles and the kernel traces of config 5 / the Volume humanoid
+for f in sorted(glob.glob("gpurun_out/bench_*.json")):
+    name = os.path.basename(f)
+    if name == "bench_driver_cmd.json" or not os.path.exists(f"profiles/{tag}_{name}"):
+        txt = open(f).read().strip().splitlines()
+        if txt:
+            open(f"profiles/{tag}_{name}", "w").write(txt[-1] + "\n")
+            d = json.loads(txt[-1]); print(name, "%.4g %s" % (d["value"], d["unit"]), d["config"].get("instances_per_wavefront"), d["roofline"].get("resident_instances_per_cu"))
+if os.path.exists("gpurun_out/phase_cycles_volume.txt"):
+    shutil.copy("gpurun_out/phase_cycles_volume.txt", f"profiles/{tag}_phase_cycles_volume.txt")
+for w in ("config5", "config4_volume"):
+    ks = sorted(glob.glob(f"gpurun_out/prof_{tag}_{w}/trace/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)
+    if ks:
+        shutil.copy(ks[-1], f"profiles/{tag}_{w}_kernel_stats.csv")
+        if os.path.exists(f"gpurun_out/prof_{tag}_{w}.bench.json"):
+            shutil.copy(f"gpurun_out/prof_{tag}_{w}.bench.json", f"profiles/{tag}_{w}_kernel_stats.bench.json")
