@@ -11,7 +11,9 @@ rm -rf $OUT && mkdir -p $OUT
 ARGS="bench.py --workload $W --steps 20 --warmup 5 --no-cpu-baseline --min-seconds 0"
 # kernel trace + stats of the SAME command whose JSON line is reported (default steps / warmup), so that
 # the average kernel duration can be compared with bench.py's own HIP-event figure
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --workload $W > $OUT.bench.json 2> $OUT.trace.log
+# (--no-continuous: the continuous-trajectory record of the default line launches the same kernel on a lighter contact regime,
+#  which would pull the trace's average below the rollouts' figure; the default line itself is bench_driver_cmd.json)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --workload $W --no-continuous > $OUT.bench.json 2> $OUT.trace.log
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ARGS > $OUT.fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ARGS > $OUT.write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $OUT/sq1 -- python3 $ARGS > $OUT.sq1.log 2>&1
