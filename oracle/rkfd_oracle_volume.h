@@ -760,6 +760,7 @@ static int volume_rigid(rkfdOracle *o, int doUpRef)
   /* _rkFDSolverCountContacts (:21-28), _rkFDSolverFrictionConstraint (:121-138) */
   for( c=0; c<np; c++ ) colnum += o->vp[c].ncp;
   cnum = np + colnum;
+  if( cnum < 1 ) cnum = 1;      /* (np >= 1 here; said for the compiler's range analysis) */
   nf = (double *)calloc( (size_t)cnum*n, sizeof(double) ); d = (double *)calloc( (size_t)cnum, sizeof(double) ); idx = (int *)malloc( sizeof(int)*(size_t)cnum );
   io = 0; jo = 0;
   for( c=0; c<np; c++ ){
