@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 LIB_PATH = os.environ.get("RKFD_EMU_LIB", os.path.join(HERE, "librkfd_emu.so"))      # (RKFD_EMU_LIB: a sanitizer build, tools/emu_asan.sh)
 _lib = None
 _lib_w2 = None
-LIB_PATH_W2 = os.path.join(HERE, "librkfd_emu_w2.so")
+LIB_PATH_W2 = os.environ.get("RKFD_EMU_LIB_W2", os.path.join(HERE, "librkfd_emu_w2.so"))      # (two instances per wavefront; RKFD_EMU_LIB_W2: its sanitizer build)
 
 
 class DevState(C.Structure):

@@ -12,7 +12,11 @@ OUT=/tmp/librkfd_emu_tsan.so
 g++ -std=c++20 -O1 -g -fsanitize=thread -fno-omit-frame-pointer -Wno-unknown-pragmas -fPIC -shared -pthread \
     -Iinclude -Iroki-fd_amd/csrc -Iroki-fd_amd/csrc/host -Iroki-fd_amd/build -o $OUT tests/emu/rkfd_emu.cpp roki-fd_amd/csrc/rkfd_devmodel.cpp
 rm -f /tmp/rkfd_tsan.*
+# the same harness with two instances per wavefront (RKFD_W = 2)
+g++ -std=c++20 -O1 -g -fsanitize=thread -fno-omit-frame-pointer -Wno-unknown-pragmas -fPIC -shared -pthread -DRKFD_W=2 \
+    -Iinclude -Iroki-fd_amd/csrc -Iroki-fd_amd/csrc/host -Iroki-fd_amd/build -o /tmp/librkfd_emu_tsan_w2.so tests/emu/rkfd_emu.cpp roki-fd_amd/csrc/rkfd_devmodel.cpp
 export RKFD_EMU_LIB=$OUT
+export RKFD_EMU_LIB_W2=/tmp/librkfd_emu_tsan_w2.so
 export TSAN_OPTIONS="halt_on_error=0:report_signal_unsafe=0:log_path=/tmp/rkfd_tsan"
 LD_PRELOAD="$(g++ -print-file-name=libtsan.so)" python3 -m pytest tests/test_emu_parity.py -x -q -k "${1:-emulated}" || true
 echo "ThreadSanitizer reports: $(cat /tmp/rkfd_tsan.* 2>/dev/null | grep -c 'WARNING: ThreadSanitizer')"
