@@ -114,14 +114,14 @@ RKFD_DEV void rkfd_brf_wrench_part(const rkfdDevModel &m, const rkfdLds &L)
 
 /* the wrench w ((ang, lin) about the origin of the spatial coordinates) the joint of link `lane` transmits against its thresholds:
  * the force's norm, and the norm of the torque about the link origin p (kept by the kinematics in the link's frame slot) */
-RKFD_DEV void rkfd_brf_decide(const rkfdDevModel &m, const rkfdLds &L, int lane, const double *XF, const double *w)
+RKFD_DEV bool rkfd_brf_decide(const rkfdDevModel &m, const rkfdLds &L, int lane, const double *XF, const double *w)
 {
   const double p[3] = { XF[9], XF[10], XF[11] };
   double pf[3];
   d_cross( p, w+3, pf );
   const double tq[3] = { w[0]-pf[0], w[1]-pf[1], w[2]-pf[2] };
   const double fn = sqrt( d_dot( w+3, w+3 ) ), tn = sqrt( d_dot( tq, tq ) );
-  if( fn > m.brk_f[lane] || tn > m.brk_t[lane] ) L.BRK[lane] = RKFD_BRF_BROKEN;
+  return fn > m.brk_f[lane] || tn > m.brk_t[lane];
 }
 /* float slot of a link (the table lives with the path tables, which only worlds with a rigid contact capacity keep; otherwise count) */
 RKFD_DEV int rkfd_brf_fslot(const rkfdDevModel &m, const rkfdLds &L, int lane)
@@ -138,6 +138,9 @@ RKFD_DEV void rkfd_brf_break_test(const rkfdDevModel &m, const rkfdLds &L, bool 
 {
   const int lane = LANE();
   const unsigned char *FSL = L.PL + m.nlink*m.nlevel + m.nlink;
+  /* every joint is tested against the states of THIS evaluation (which joints are attached decides which contact forces a
+   * joint carries): the verdicts are written only after every lane has read what it needs */
+  bool breaks = false;
   if( lane < m.nlink && L.BRK[lane] == RKFD_BRF_ATTACHED ){
     int fs = 0;
     if( m.maxrg > 0 ) fs = FSL[lane];
@@ -167,8 +170,10 @@ RKFD_DEV void rkfd_brf_break_test(const rkfdDevModel &m, const rkfdLds &L, bool 
         }
       }
     }
-    rkfd_brf_decide( m, L, lane, XF, w );
+    breaks = rkfd_brf_decide( m, L, lane, XF, w );
   }
+  SYNC();
+  if( breaks ) L.BRK[lane] = RKFD_BRF_BROKEN;
   SYNC();
 }
 

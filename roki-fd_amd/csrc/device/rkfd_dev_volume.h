@@ -1346,6 +1346,7 @@ template<bool prof> RKFD_DEV void rkfd_phase_volume(const rkfdDevModel &m, const
 RKFD_DEV void rkfd_brf_break_test_vol(const rkfdDevModel &m, const rkfdLds &L, bool solved)
 {
   const int lane = LANE();
+  bool breaks = false;      /* (verdicts are written after every lane has read the states of this evaluation, as in rkfd_brf_break_test) */
   if( lane < m.nlink && L.BRK[lane] == RKFD_BRF_ATTACHED ){
     const double *XF = &L.XF[12*rkfd_brf_fslot( m, L, lane )];
     double w[6];
@@ -1372,8 +1373,10 @@ RKFD_DEV void rkfd_brf_break_test_vol(const rkfdDevModel &m, const rkfdLds &L, b
         }
       }
     }
-    rkfd_brf_decide( m, L, lane, XF, w );
+    breaks = rkfd_brf_decide( m, L, lane, XF, w );
   }
+  SYNC();
+  if( breaks ) L.BRK[lane] = RKFD_BRF_BROKEN;
   SYNC();
 }
 

@@ -603,7 +603,9 @@ static int spec_from_store(unsigned long long key, std::vector<char> &code)
 static void spec_to_store(unsigned long long key, const std::vector<char> &code)
 {
   if( !spec_store_on() ) return;
-  const std::string dir = spec_dir(), path = spec_path( key ), tmp = path + ".tmp";
+  char uniq[48];
+  snprintf( uniq, sizeof(uniq), ".tmp.%ld.%p", (long)getpid(), (void *)&code );      /* (several ranks of a node may compile the same world at once) */
+  const std::string dir = spec_dir(), path = spec_path( key ), tmp = path + uniq;
   (void)mkdir( dir.c_str(), 0777 );
   FILE *f = fopen( tmp.c_str(), "wb" );
   if( !f ) return;                                  /* (a read-only installation: compile every time) */

@@ -113,7 +113,11 @@ extern "C" int rkfd_emu_run(const rkfdModel *m, int max_rigid, rkfdDevState *st,
      * shows here instead of depending on what the previous kernel on the box left behind */
     std::memset( lds.data(), 0xFF, lds.size() );
     std::vector<std::thread> th;
-    for( int l=0; l<64; l++ )
+    for( int l=0; l<64; l++ ){
+      /* the half of an odd batch's last wavefront that has no instance of its own: on the device its lanes run in lockstep with
+       * the other half on a copy of that half's instance and store nothing; here the halves are independent threads (per-instance
+       * barriers), so the stand-in is simply not run - it would read the state the live half is writing */
+      if( b + l/EMU_WL >= st->batch ) continue;
       th.emplace_back( [&, l](){ t_tid = l;
         /* the instance of this thread's half; a half beyond the batch stands in with the instance before it and stores nothing */
         int bi = b + l/EMU_WL;
@@ -125,6 +129,7 @@ extern "C" int rkfd_emu_run(const rkfdModel *m, int max_rigid, rkfdDevState *st,
         else if( h.dm.vert_rigid ) rkfd_instance<false, 1, false>( h.dm, *st, bi, base, mode, nsteps, &errflag, live );
         else if( h.dm.ma_packed ) rkfd_instance<false, 0, true>( h.dm, *st, bi, base, mode, nsteps, &errflag, live );
         else rkfd_instance<false, 0, false>( h.dm, *st, bi, base, mode, nsteps, &errflag, live ); } );
+    }
     for( auto &t : th ) t.join();
   }
   if( h.ncand > 0 ) rkfd_ref_to_model( &h, st->cv_ref, (size_t)st->batch*h.ncand );
