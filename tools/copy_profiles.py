@@ -55,8 +55,8 @@ for f in ("ubench_pgs.txt",):
 # the other bench lines of the collection, the Volume plugin's phase cycles and the kernel traces of config 5 / the Volume humanoid
 for f in sorted(glob.glob("gpurun_out/bench_*.json")):
     name = os.path.basename(f)
-    if name == "bench_driver_cmd.json" or not os.path.exists(f"profiles/{tag}_{name}"):
-        txt = open(f).read().strip().splitlines()
+    txt = open(f).read().strip().splitlines()
+    if True:
         if txt:
             open(f"profiles/{tag}_{name}", "w").write(txt[-1] + "\n")
             d = json.loads(txt[-1]); print(name, "%.4g %s" % (d["value"], d["unit"]), d["config"].get("instances_per_wavefront"), d["roofline"].get("resident_instances_per_cu"))
