@@ -211,6 +211,8 @@ def main():
     ap.add_argument("--ipw", type=int, default=0, choices=(0, 1, 2), help="instances per wavefront of the world-specific step kernel: 1 = one instance has the "
                     "64 lanes; 2 = two instances share a wavefront, 32 lanes each (worlds of at most 32 links / joint coordinates; same results "
                     "to the last bit); 0 (default) = measure both before the timed region and keep the faster (rkfdBatchTuneInstancesPerWave)")
+    ap.add_argument("--steps-per-launch", type=int, default=5, help="under split launches a call of n steps goes out as rounds of launches of at most "
+                    "this many steps (rkfdBatchSetStepsPerLaunch; results do not depend on it)")
     ap.add_argument("--split", type=int, default=3, help="launch each step as this many kernels over parts of the batch on internal HIP streams (1..8)")
     args = ap.parse_args()
 
@@ -252,6 +254,7 @@ def main():
             print("bench.py: %s" % e, file=sys.stderr)
     b.set_state(sc["dis"], sc["vel"])
     b.set_split(args.split)
+    b.set_steps_per_launch(args.steps_per_launch)
     stream = torch.cuda.current_stream().cuda_stream
     b.update_init(stream)
     assert b.status(stream) == 0
@@ -388,7 +391,7 @@ def main():
                        "instances_per_gpu": Bn, "instances_per_wavefront": b.instances_per_wave(), "instances_per_wavefront_tuning": ipw_tuning, "ndof": m.ndof, "nlink": m.nlink,
                        "rollout_horizon": H, "timed_steps": timed_steps, "blocks": reps,
                        "mean_rigid_contacts": mean_rg if has_contacts else 0.0, "mean_elastic_contacts": mean_el if has_contacts else 0.0,
-                       "parallelism": f"instances sharded over {world} GPU(s), no data-path collective; {args.split} launches per step on internal streams",
+                       "parallelism": f"instances sharded over {world} GPU(s), no data-path collective; {args.split} parts of the batch on internal streams, up to {args.steps_per_launch} steps per launch",
                        "step_kernel": ("compiled for this world ahead of time (make spec), loaded from roki-fd_amd/spec" if aot else "compiled for this world at run time (hipRTC)") if specialized else "generic"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
@@ -420,6 +423,8 @@ def main():
             # quad-cycles measured); 256 CUs x 4 SIMDs.  The clock under this kernel is ~1.8-2.0 GHz, the nominal 2.4 GHz is used.
             # (SQ_INSTS_VALU / SQ_WAVES is per WAVEFRONT: with two instances per wavefront it serves both)
             ipw_now = max(1, b.instances_per_wave())
+            # ... and per LAUNCH: a launch carries spl steps
+            vi = vi / spl
             ips = vi * (Bn / ipw_now) / (step_ms * 1e-3)
             res["valu_issue"] = {"valu_insts_per_instance_step": vi / ipw_now, "valu_insts_per_wavefront_step": vi, "simd_busy_fraction_at_2.4GHz": ips * 4.0 / (256 * 4 * 2.4e9), "source": vi_note}
         if world == 1 and not args.no_cpu_baseline:      # the CPU baseline is a single-GPU-run figure (rank 0, N = 1)

@@ -81,6 +81,12 @@ int rkfdBatchEval(rkfdBatch *b, int doUpRef, void *stream);
  * rkfdBatchJoin( b, stream ) or rkfdBatchStatus( b, stream ); the host-side accessors (Get / Set) wait.
  * nsplit = 1 (default): one launch on the caller's stream, plain stream order. */
 int rkfdBatchSetSplit(rkfdBatch *b, int nsplit);
+/* Under split launches a call of n steps goes out as rounds of launches of at most `steps` steps each (default 5; worlds under
+ * the Vert plugin keep one fused launch per part): one step per launch reloads the instance's state and the world's tables every
+ * step, all n in one launch hold the slots while the rest of the batch waits - measured on config 4, rollouts of 25 steps, 1 / 2 /
+ * 3 / 5 / 9 / 13 / 25 steps per launch: 11.51 / 11.63 / 11.65 / 11.82 / 11.79 / 11.82 / 11.76 M steps/s.  Results do not depend
+ * on it (tests/test_gpu_edge.py: fused vs single-step launches bit for bit). */
+int rkfdBatchSetStepsPerLaunch(rkfdBatch *b, int steps);
 /* Compile the step kernel for THIS world (hipRTC, a few seconds): the same device code with the world's dimensions
  * as literals, so that the LDS layout, loop bounds and table strides fold into immediates (+7 % steps/s on the
  * 30-DoF humanoid).  Results are bit-identical to the generic kernels, which stay in use for the profiling entry

@@ -94,6 +94,7 @@ def lib():
     L.rkfdBatchSetPivot.argtypes = [vp, vp, vp]
     L.rkfdBatchGetBroken.argtypes = [vp, vp]; L.rkfdBatchSetBroken.argtypes = [vp, vp]
     L.rkfdBatchSetInstancesPerWave.argtypes = [vp, C.c_int]; L.rkfdBatchInstancesPerWave.argtypes = [vp]
+    L.rkfdBatchSetStepsPerLaunch.argtypes = [vp, C.c_int]
     L.rkfdBatchTuneInstancesPerWave.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     L.rkfdSpecializeCompileW.argtypes = [C.POINTER(RkfdModel), C.c_int, C.c_int]
     L.rkfdBatchUpdateInit.argtypes = [vp, vp]
@@ -325,6 +326,10 @@ class Batch:
     @property
     def lds_bytes(self):
         return self._L.rkfdBatchLdsBytes(self._b)
+
+    def set_steps_per_launch(self, n):
+        """under split launches: steps one launch carries (default 5)"""
+        self._chk(self._L.rkfdBatchSetStepsPerLaunch(self._b, int(n)))
 
     def set_instances_per_wave(self, ipw):
         """1 (default) or 2 instances per wavefront in the world-specific kernel; call before specialize()"""

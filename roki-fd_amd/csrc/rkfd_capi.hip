@@ -111,6 +111,7 @@ struct rkfdBatch {
   hipFunction_t spec_fn;
   /* rkfdBatchSetInstancesPerWave( b, 2 ): a second device model (sweep schedule with four links per iteration) for the
    * world-specific kernel built with RKFD_W = 2 - two instances per wavefront, 32 lanes each */
+  int steps_per_launch;      /* under split launches: steps one launch carries (rkfdBatchSetStepsPerLaunch) */
   int ipw;                           /* instances per wavefront of the specialised kernel: 1 or 2 */
   const rkfdModel *model_for_w2;     /* the caller's model (must outlive the batch, as for rkfdBatchCreate's own use) */
   rkfdDevModelHost host2;
@@ -158,7 +159,7 @@ extern "C" rkfdBatch *rkfdBatchCreate(const rkfdModel *m, int batch, int device,
   HIPCHK( hipSetDevice( device ), NULL );
 
   rkfdBatch *b = (rkfdBatch *)calloc( 1, sizeof(rkfdBatch) );
-  if( b ){ b->nsplit = 1; b->tev = new std::vector<hipEvent_t>(); }
+  if( b ){ b->nsplit = 1; b->steps_per_launch = 5; b->tev = new std::vector<hipEvent_t>(); }
   if( !b ){ SETERR( "out of memory" ); return NULL; }
   char err[256];
   if( rkfd_devmodel_build( m, max_rigid, &b->host, err, sizeof(err) ) < 0 ){
@@ -445,14 +446,18 @@ static int launch(rkfdBatch *b, int mode, int nsteps, void *stream)
    * of the last round runs thin (4096 instances, 200 steps: 9.2 M steps/s fused, 12.7 M in rounds; tools/fused_vs_stepwise.py) */
   /* (not for worlds under the Vert plugin: the QP makes the step times of the instances vary widely, and there the
    * per-step barrier of a round costs more than the slots a fused launch holds: 2.1 M against 3.6 M steps/s) */
-  const int rounds = ( mode == 0 && nsteps > 1 && !b->dm.vert_rigid ) ? nsteps : 1, per = rounds > 1 ? 1 : nsteps;
+  /* (round 3: not one step per launch either - rounds of b->steps_per_launch steps, 5 by default: rollouts of 25 steps on config 4,
+   *  steps per launch 1 / 2 / 3 / 5 / 9 / 13 / 25: 11.51 / 11.63 / 11.65 / 11.82 / 11.79 / 11.82 / 11.76 M steps/s - a launch loads
+   *  an instance's state and the world's tables once, against slots held a little longer; profiles/r03_steps_per_launch.txt) */
+  int rounds = 1, per = nsteps;
+  if( mode == 0 && nsteps > 1 && !b->dm.vert_rigid ){ per = b->steps_per_launch < nsteps ? b->steps_per_launch : nsteps; rounds = ( nsteps + per - 1 )/per; }
   for( int r=0; r<rounds; r++ )
     for( int k=0; k<b->nsplit; k++ ){
       const int lo = (int)( (long long)b->batch*k/b->nsplit ), hi = (int)( (long long)b->batch*( k+1 )/b->nsplit );
       if( hi <= lo ) continue;
       hipEvent_t e0 = NULL, e1 = NULL;
       if( b->timing && timing_pair( b, &e0, &e1 ) ) HIPCHK( hipEventRecord( e0, b->sub[k] ), -1 );
-      if( launch_one( b, kern, hi-lo, lo, mode, per, b->sub[k] ) < 0 ) return -1;
+      if( launch_one( b, kern, hi-lo, lo, mode, ( r+1 )*per <= nsteps ? per : nsteps - r*per, b->sub[k] ) < 0 ) return -1;
       if( e0 && e1 ) HIPCHK( hipEventRecord( e1, b->sub[k] ), -1 );
     }
   for( int k=0; k<b->nsplit; k++ ) HIPCHK( hipEventRecord( b->done[k], b->sub[k] ), -1 );
@@ -816,6 +821,12 @@ extern "C" int rkfdBatchTuneInstancesPerWave(rkfdBatch *b, int nsteps, double *m
   return chosen;
 }
 
+extern "C" int rkfdBatchSetStepsPerLaunch(rkfdBatch *b, int n)
+{
+  if( !b || n < 1 ){ SETERR( "rkfdBatchSetStepsPerLaunch: n >= 1" ); return -1; }
+  b->steps_per_launch = n;
+  return 0;
+}
 extern "C" int rkfdBatchSetSplit(rkfdBatch *b, int nsplit)
 {
   if( !b || nsplit < 1 || nsplit > RKFD_MAX_SPLIT ){ SETERR( "rkfdBatchSetSplit: 1 <= nsplit <= %d", RKFD_MAX_SPLIT ); return -1; }
