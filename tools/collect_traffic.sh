@@ -14,6 +14,10 @@ ARGS="bench.py --workload $W --steps 20 --warmup 5 --no-cpu-baseline --min-secon
 # (--no-continuous: the continuous-trajectory record of the default line launches the same kernel on a lighter contact regime,
 #  which would pull the trace's average below the rollouts' figure; the default line itself is bench_driver_cmd.json)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --workload $W --no-continuous > $OUT.bench.json 2> $OUT.trace.log
+# the counter passes run the lane mapping the traced run chose, without measuring it again: the tuner's launches (both kernels)
+# would otherwise outnumber the timed ones in the per-launch medians
+IPW=$(python3 -c "import json; print(json.loads(open('$OUT.bench.json').read().strip().splitlines()[-1])['config']['instances_per_wavefront'])")
+ARGS="$ARGS --ipw $IPW"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ARGS > $OUT.fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ARGS > $OUT.write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $OUT/sq1 -- python3 $ARGS > $OUT.sq1.log 2>&1
