@@ -246,7 +246,10 @@ def main():
     if not args.no_specialize and b.lds_bytes <= 64 * 1024:
         try:
             if args.ipw == 2:
-                b.set_instances_per_wave(2)
+                try:
+                    b.set_instances_per_wave(2)
+                except R.RkfdError as e:      # the world does not fit 32 lanes per instance: one per wavefront it is
+                    print("bench.py: %s" % e, file=sys.stderr)
             b.specialize()
             specialized = True
             aot = bool(R.lib().rkfdSpecializeLastFromStore())
