@@ -8,6 +8,7 @@
 #  define RKFD_DEV static inline
    int    rkfd_emu_lane(void);
    void   rkfd_emu_sync(void);
+   void   rkfd_emu_sync_wave(void);
    double rkfd_emu_g8sum(double x);
    double rkfd_emu_bcast(double x, int src);
    unsigned long long rkfd_emu_ballot(int pred);
@@ -15,6 +16,7 @@
    int    rkfd_emu_half(void);
 #  define HALF()        rkfd_emu_half()
 #  define SYNC()        rkfd_emu_sync()
+#  define SYNCW()       rkfd_emu_sync_wave()      /* all live instances of the wavefront (two instances per wavefront: the shared tables) */
    double rkfd_emu_g8bcast(double x, int k);
 #  define G8SUM(x)      rkfd_emu_g8sum(x)
 #  define G8SUM2(x,y)   do{ (x) = rkfd_emu_g8sum(x); (y) = rkfd_emu_g8sum(y); }while(0)
@@ -50,6 +52,7 @@ static __device__ __forceinline__ int rkfd_lane(void){ int l = (int)threadIdx.x 
  * for the wave's own outstanding LDS operations.  __syncthreads() would also drain vmcnt (the
  * schedule-record prefetches), which is exactly the latency the prefetch is meant to hide. */
 #  define SYNC()        asm volatile( "s_waitcnt lgkmcnt(0)" ::: "memory" )
+#  define SYNCW()       SYNC()      /* (the instances of a wavefront run in lockstep: what one half wrote in program order the other reads) */
 RKFD_DEV double rkfd_dpp_xor1(double x)
 {
   int lo = __double2loint( x ), hi = __double2hiint( x );
@@ -379,6 +382,7 @@ typedef struct {
                                      [M(M+1)/2] Q / its Cholesky factor (packed lower triangle), [M*M] W = L^-1 C', [5M (+64)] vectors (+ reduction scratch
                                      unless it overlays the link accelerations), [3M] reduced rows */
   unsigned char *CRC;             /* [M] contact of a reduced constraint row */
+  unsigned char *FS;              /* [maxact] the slot's CF holds a force (it shares storage with RW) */
   double *QG, *QY;                /* the wide form (vert_rigid == 3): pyramid rows [3 P maxrg], multipliers [P maxrg] */
   unsigned char *QA;              /* ... active flags [P maxrg], active faces per contact [maxrg] */
   double *MA, *MB, *MF, *PU;      /* contact problem: [ma_size] the matrix (ALIASES IST|POOL; full rows or a packed lower triangle, rkfd_ma_idx),
@@ -405,8 +409,9 @@ typedef struct {
   int *GC;
 } rkfdLds;
 RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int M, int nlevel, int npool, int nfloat, int maxact, int nside, int pu_alias, int npurow, int vert_rigid, int has_slide, int ma_size,
-                             int vol_np, int vol_ncp, int vol_pv, int vol_nf, int pyramid, int has_pl)
-/* must match the byte count computed in rkfd_devmodel.cpp */
+                             int vol_np, int vol_ncp, int vol_pv, int vol_nf, int pyramid, int has_pl, void *shared = 0)
+/* must match the byte count computed in rkfd_devmodel.cpp.  shared != 0: the world's static tables live there (once per wavefront,
+ * rkfdDevModel.lds_shared) instead of in the instance's own block */
 {
   double *d = (double *)base;
   L->S = d; d += NL*6;
@@ -434,7 +439,10 @@ RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int
   L->CHOL = d; d += 21*nfloat; L->XF = d; d += 12*nfloat;
   L->CX = d; d += maxact*3; L->AX = d; d += maxact*6; L->RW = d; d += maxact*3; L->PRO = d; d += maxact*3;
   L->REF = d; d += maxact*3; L->RTMP = d; if( NC > RKFD_WAVE/2 ) d += maxact*3;      /* (more than one chunk of candidates at two instances per wavefront) */
-  L->CF = d; d += maxact*3;
+  /* the world force of a contact is written after the last look at its anchor in world coordinates (RW: the penalty force and the
+   * bias of the rigid system read it): they share storage, and FS says whether a slot holds a force yet (a contact nobody solved -
+   * beyond the capacity, or a rigid vertex under the Volume plugin - reports zero) */
+  L->CF = L->RW;
   L->SV = d; L->SD = d; if( has_slide ){ L->SV = d; d += maxact*3; L->SD = d; d += maxact*3; }
   /* PGS: a lane reads its three entries of b before it writes its three forces, so they share storage */
   L->MB = d; d += M; L->MF = L->MB; if( vert_rigid ){ L->MF = d; d += M; }      /* (Volume plugin: the forces are written when the bias is long dead) */
@@ -455,19 +463,22 @@ RKFD_DEV void rkfd_lds_carve(rkfdLds *L, void *base, int NL, int ND, int NC, int
     d += RKFD_VOL_LDS_COL( vol_nf, vol_pv ) > RKFD_VOL_LDS_SOL( vol_np, vol_ncp, pyramid ) ? RKFD_VOL_LDS_COL( vol_nf, vol_pv ) : RKFD_VOL_LDS_SOL( vol_np, vol_ncp, pyramid );
   }
   int *ip = (int *)d;
-  L->CIp = ip; ip += NC;
+  int *sip = (int *)shared;
+  if( shared ){ L->CIp = sip; sip += NC; } else { L->CIp = ip; ip += NC; }
   L->tgt = ip; ip += nside*maxact; L->cnt = ip; ip += vol_np ? 12 : ( NC > 0 ? 8 : 4 );
   L->VI = ip; if( vol_np ) ip += 2*vol_np;
   L->GC = ip; if( RKFD_GC_NEEDED( M ) ) ip += RKFD_GC_INTS;
-  L->LI = ip; ip += NL;
+  if( shared ){ L->LI = sip; sip += NL; } else { L->LI = ip; ip += NL; }
   unsigned short *sp = (unsigned short *)ip;
-  L->CHP = sp; sp += NL; L->CFO = sp; sp += NC;
+  unsigned short *ssp = (unsigned short *)sip;
+  if( shared ){ L->CHP = ssp; ssp += NL; L->CFO = ssp; ssp += NC; } else { L->CHP = sp; sp += NL; L->CFO = sp; sp += NC; }
   L->lrg = sp; sp += maxact; L->lel = sp; sp += maxact;
   unsigned char *bp = (unsigned char *)sp;
   L->act = bp; bp += NC; L->typ = bp; bp += NC; L->asl = bp; bp += NC;
+  L->FS = bp; bp += maxact;
   L->CRC = bp; if( vert_rigid ) bp += M;
   L->QA = bp; if( vert_rigid == 3 ) bp += ( pyramid+1 )*( M/3 );
-  L->PL = bp; if( has_pl ) bp += NL*( nlevel+3 );
+  if( shared ) L->PL = (unsigned char *)ssp; else { L->PL = bp; if( has_pl ) bp += NL*( nlevel+3 ); }
   L->BRK = bp;
 }
 

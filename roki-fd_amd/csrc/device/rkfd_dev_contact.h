@@ -96,7 +96,7 @@ RKFD_DEV void rkfd_phase_collision(const rkfdDevModel &m, const rkfdLds &L)
           ref[0] = pro[0]; ref[1] = pro[1]; ref[2] = pro[2];
         } else { ref[0] = oref[0]; ref[1] = oref[1]; ref[2] = oref[2]; }
         L.REF[3*slot] = ref[0]; L.REF[3*slot+1] = ref[1]; L.REF[3*slot+2] = ref[2];
-        L.CF[3*slot] = 0; L.CF[3*slot+1] = 0; L.CF[3*slot+2] = 0;
+        L.FS[slot] = 0;
         d_mulv( RB, ref, rw );
         L.RW[3*slot] = rw[0]+pB[0]; L.RW[3*slot+1] = rw[1]+pB[1]; L.RW[3*slot+2] = rw[2]+pB[2];
         d_ortho_space( nw, t1, t2 );
@@ -256,7 +256,7 @@ RKFD_DEV void rkfd_phase_penalty(const rkfdDevModel &m, const rkfdLds &L, bool d
     } else {
       d_modify_friction( m, L, j, vr, f, doUpRef );
     }
-    { const int sl_ = L.asl[j]; L.CF[3*sl_] = f[0]; L.CF[3*sl_+1] = f[1]; L.CF[3*sl_+2] = f[2]; }
+    { const int sl_ = L.asl[j]; L.CF[3*sl_] = f[0]; L.CF[3*sl_+1] = f[1]; L.CF[3*sl_+2] = f[2]; L.FS[sl_] = 1; }
   }
   SYNC();
   rkfd_push_wrenches( m, L, L.lel, nel );

@@ -849,7 +849,7 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
         const double fi = L.MF[3*lane+i];
         fw[0] += fi*axl[3*i]; fw[1] += fi*axl[3*i+1]; fw[2] += fi*axl[3*i+2];
       }
-      { const int sl_ = L.asl[j]; L.CF[3*sl_] = fw[0]; L.CF[3*sl_+1] = fw[1]; L.CF[3*sl_+2] = fw[2]; }
+      { const int sl_ = L.asl[j]; L.CF[3*sl_] = fw[0]; L.CF[3*sl_+1] = fw[1]; L.CF[3*sl_+2] = fw[2]; L.FS[sl_] = 1; }
       if( doUpRef ){
         const int P = m.pyramid;
         bool anyface = false;
@@ -898,7 +898,7 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
 #else
     if( nc <= RKFD_PGS_NC ) rkfd_pgs_registers<pk>( L.MA, r0, ld, nc, m.max_iter, on, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
     else if( nc == 8 ) rkfd_pgs_dpp8<pk>( L.MA, r0, ld, m.max_iter, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
-    else if( !pk && nc <= RKFD_PGS_DPP_MAX ) rkfd_pgs_dpp<pk>( L.MA, r0, ld, nc, m.maxrg, m.max_iter, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
+    else if( ( !pk || RKFD_W == 2 ) && nc <= RKFD_PGS_DPP_MAX ) rkfd_pgs_dpp<pk>( L.MA, r0, ld, nc, m.maxrg, m.max_iter, lane, mu, in_, i1, i2, rn, r1, r2, fn, f1, f2 );
     else if( gfills >= 0 ){
       /* (several independent bodies in contact: their Gauss-Seidel sequences run side by side, one DPP row each) */
       if( sw ) rkfd_pgs_grouped_sw( m, L, (const unsigned char *)L.AC, gmaxlen, dt );
@@ -921,7 +921,7 @@ template<bool prof, bool vqp, bool pk> RKFD_DEV void rkfd_phase_mlcp(const rkfdD
       const double fi = L.MF[3*lane+i];
       fw[0] += fi*axl[3*i]; fw[1] += fi*axl[3*i+1]; fw[2] += fi*axl[3*i+2];
     }
-    { const int sl_ = L.asl[j]; L.CF[3*sl_] = fw[0]; L.CF[3*sl_+1] = fw[1]; L.CF[3*sl_+2] = fw[2]; }
+    { const int sl_ = L.asl[j]; L.CF[3*sl_] = fw[0]; L.CF[3*sl_+1] = fw[1]; L.CF[3*sl_+2] = fw[2]; L.FS[sl_] = 1; }
     const double fn = fw[0], fs = sqrt( fw[1]*fw[1] + fw[2]*fw[2] );
     const double mu = L.typ[j] == RKFD_SF ? m.ci_sf[ci] : m.ci_kf[ci];
     if( fs > mu*fn - RKFD_DEV_TOL ){

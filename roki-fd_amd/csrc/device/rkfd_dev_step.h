@@ -134,7 +134,7 @@ RKFD_DEV void rkfd_cat_dis(const rkfdDevModel &m, const rkfdLds &L, int dofkind,
  * and owns the h-th block of lds_instance bytes of the workgroup's LDS.  A half beyond the end of the batch part (odd count) keeps
  * in step by simulating the instance before it once more - the halves share every branch and barrier - and stores nothing. */
 template<bool prof, int vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDevModel &m_, const rkfdDevState &st, int b, void *ldsbase,
-                            int mode, int nsteps, int *errflag, bool live = true)
+                            int mode, int nsteps, int *errflag, bool live = true, void *ldsshared = 0)
 {
 #ifdef RKFD_SPEC
   /* kernel compiled for ONE world (rkfdBatchSpecialize, hipRTC): its dimensions are literals, so the LDS layout,
@@ -148,7 +148,7 @@ template<bool prof, int vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDevM
   m.npurow = RKFD_SPEC_NPUROW; m.pu_d0 = RKFD_SPEC_PU_D0; m.pu_alias = RKFD_SPEC_PU_ALIAS; m.vert_rigid = RKFD_SPEC_VERT_RIGID; m.qscr_alias = RKFD_SPEC_QSCR_ALIAS;
   m.has_slide = RKFD_SPEC_HAS_SLIDE; m.ma_size = RKFD_SPEC_MA_SIZE; m.ma_packed = RKFD_SPEC_MA_PACKED;
   m.max_iter = RKFD_SPEC_MAX_ITER; m.solver = RKFD_SPEC_SOLVER; m.pyramid = RKFD_SPEC_PYRAMID; m.anchor = RKFD_SPEC_ANCHOR;
-  m.mlcp_mfma = RKFD_SPEC_MLCP_MFMA; m.has_brf = RKFD_SPEC_HAS_BRF;
+  m.mlcp_mfma = RKFD_SPEC_MLCP_MFMA; m.has_brf = RKFD_SPEC_HAS_BRF; m.lds_shared = RKFD_SPEC_LDS_SHARED;
   m.vol_npair = RKFD_SPEC_VOL_NPAIR; m.vol_np = RKFD_SPEC_VOL_NP; m.vol_ncp = RKFD_SPEC_VOL_NCP; m.vol_pv = RKFD_SPEC_VOL_PV; m.vol_nf = RKFD_SPEC_VOL_NF;
 #else
   const rkfdDevModel &m = m_;
@@ -157,7 +157,9 @@ template<bool prof, int vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDevM
   const int ND = m.ndof, NL = m.nlink, NC = m.ncand;
   rkfdLds L;
   rkfd_lds_carve( &L, ldsbase, NL, ND, NC, 3*m.maxrg, m.nlevel, m.npool, m.nfloat, m.maxact, m.nside, m.pu_alias, m.npurow, m.vert_rigid, m.has_slide, m.ma_size,
-                  vqp == 2 ? m.vol_np : 0, m.vol_ncp, m.vol_pv, m.vol_nf, m.pyramid, m.maxrg > 0 );
+                  vqp == 2 ? m.vol_np : 0, m.vol_ncp, m.vol_pv, m.vol_nf, m.pyramid, m.maxrg > 0, m.lds_shared > 0 ? ldsshared : 0 );
+  /* the world's static tables, once per wavefront where the instances share them: the first instance of the wavefront fills them */
+  const bool fills = !( m.lds_shared > 0 ) || HALF() == 0;
   if( m.lds_poison > 0 ){      /* (RKFD_DEBUG_POISON_LDS: see rkfd_devmodel.h) */
     for( int i=lane; i<m.lds_poison; i+=RKFD_WL ) ( (unsigned *)ldsbase )[i] = 0xffffffffu;
     SYNC();
@@ -183,14 +185,16 @@ template<bool prof, int vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDevM
     }
   }
   if( lane < NL ){
-    L.LI[lane]   = m.linfo[lane];
-    { const int ch = m.child_idx[lane]; L.CHP[lane] = (unsigned short)( ch | ( ( m.pslot[ch]+1 ) << 8 ) ); }
+    if( fills ){
+      L.LI[lane]   = m.linfo[lane];
+      const int ch = m.child_idx[lane]; L.CHP[lane] = (unsigned short)( ch | ( ( m.pslot[ch]+1 ) << 8 ) );
+    }
     const int lm = m.orig[lane];
     ll.min  = st.motor_in[(size_t)b*m.nlink_model+lm];
     ll.pivt = st.piv_type[(size_t)b*m.nlink_model+lm];
     ll.pivp = st.piv_prev[(size_t)b*m.nlink_model+lm];
   }
-  if( m.maxrg > 0 ){
+  if( m.maxrg > 0 && fills ){
     for( int k=lane; k<NL*( m.nlevel+3 ); k+=RKFD_WL ) L.PL[k] = (unsigned char)m.pathlink[k];
   }
   if( m.has_brf ) rkfd_brf_load( m, st, L, b );
@@ -199,8 +203,7 @@ template<bool prof, int vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDevM
     const bool onj = j < NC;
     int a = 0;
     if( onj ){
-      L.CIp[j] = m.cinfo[j];
-      L.CFO[j] = m.cand_foff[j];
+      if( fills ){ L.CIp[j] = m.cinfo[j]; L.CFO[j] = m.cand_foff[j]; }
       a = st.cv_active[(size_t)b*NC+j];
       L.typ[j] = a ? st.cv_type[(size_t)b*NC+j] : 0;
     }
@@ -219,6 +222,7 @@ template<bool prof, int vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDevM
     }
   }
   SYNC();
+  if( m.lds_shared > 0 ) SYNCW();
   int err = 0;
   /* phase-cycle counters exist only in the diagnostic instantiation (prof = true) */
   unsigned long long pc[prof ? RKFD_NPROF : 1];
@@ -300,7 +304,7 @@ template<bool prof, int vqp, bool pk> RKFD_DEV void rkfd_instance(const rkfdDevM
 #pragma unroll
       for( int k=0; k<3; k++ ){
         st.cv_ref[((size_t)b*NC+j)*3+k] = L.REF[3*RIDX( j )+k];
-        st.cv_f[((size_t)b*NC+j)*3+k] = L.CF[3*L.asl[j]+k];
+        st.cv_f[((size_t)b*NC+j)*3+k] = L.FS[L.asl[j]] ? L.CF[3*L.asl[j]+k] : 0.0;
       }
     }
   }

@@ -254,7 +254,7 @@ extern "C" int rkfdBatchResidency(const rkfdBatch *b)
   if( pieces > 0 && 128/pieces < n ) n = 128/pieces;
   if( b->ipw == 2 && b->spec_fn ){
     /* two instances per wavefront: workgroups of 2 x the LDS, at most two waves per SIMD (the kernel is built for that) */
-    const int p2 = (int)( ( 2*b->host2.lds_bytes + 1279 )/1280 );
+    const int p2 = (int)( ( 2*b->host2.lds_bytes + (size_t)b->host2.dm.lds_shared + 1279 )/1280 );
     int w = p2 > 0 ? 128/p2 : 0;
     if( w > 8 ) w = 8;
     n = 2*w;
@@ -412,7 +412,7 @@ static int launch_one(rkfdBatch *b, rkfdKernel kern, int count, int first, int m
       rkfdDevState st2 = b->st;
       st2.batch = first + count;
       void *args[] = { &b->dm2, &st2, &first, &mode, &nsteps, &b->d_err };
-      HIPCHK( hipModuleLaunchKernel( b->spec_fn, ( count+1 )/2, 1, 1, RKFD_WAVE, 1, 1, (unsigned)( 2*b->host2.lds_bytes ), stream, args, NULL ), -1 );
+      HIPCHK( hipModuleLaunchKernel( b->spec_fn, ( count+1 )/2, 1, 1, RKFD_WAVE, 1, 1, (unsigned)( 2*b->host2.lds_bytes + (size_t)b->host2.dm.lds_shared ), stream, args, NULL ), -1 );
       return 0;
     }
     void *args[] = { &b->dm, &b->st, &first, &mode, &nsteps, &b->d_err };
@@ -477,7 +477,7 @@ static std::string spec_source(const rkfdDevModel &d, int ipw = 1)
     "#define RKFD_SPEC_NPUROW %d\n#define RKFD_SPEC_PU_D0 %d\n#define RKFD_SPEC_PU_ALIAS %d\n#define RKFD_SPEC_VERT_RIGID %d\n#define RKFD_SPEC_QSCR_ALIAS %d\n"
     "#define RKFD_SPEC_HAS_SLIDE %d\n#define RKFD_SPEC_MA_SIZE %d\n#define RKFD_SPEC_MA_PACKED %d\n"
     "#define RKFD_SPEC_MAX_ITER %d\n#define RKFD_SPEC_SOLVER %d\n#define RKFD_SPEC_PYRAMID %d\n#define RKFD_SPEC_ANCHOR %d\n#define RKFD_SPEC_MLCP_MFMA %d\n"
-    "#define RKFD_SPEC_HAS_BRF %d\n#define RKFD_SPEC_LDS_INSTANCE %d\n"
+    "#define RKFD_SPEC_HAS_BRF %d\n#define RKFD_SPEC_LDS_INSTANCE %d\n#define RKFD_SPEC_LDS_SHARED %d\n"
     "#define RKFD_SPEC_VOL_NPAIR %d\n#define RKFD_SPEC_VOL_NP %d\n#define RKFD_SPEC_VOL_NCP %d\n#define RKFD_SPEC_VOL_PV %d\n#define RKFD_SPEC_VOL_NF %d\n"
     "#include \"rkfd_device.h\"\n"
     "extern \"C\" __global__ void __launch_bounds__(64, %d)\n"
@@ -488,11 +488,11 @@ static std::string spec_source(const rkfdDevModel &d, int ipw = 1)
     "  if( RKFD_W == 1 && b >= st.batch ) return;\n"
     "  const bool live = b < st.batch;\n"
     "  if( !live ) b -= 1;\n"
-    "  rkfd_instance<false, %s, %s>( m, st, b, lds + HALF()*RKFD_SPEC_LDS_INSTANCE, mode, nsteps, errflag, live );\n"
+    "  rkfd_instance<false, %s, %s>( m, st, b, lds + HALF()*RKFD_SPEC_LDS_INSTANCE, mode, nsteps, errflag, live, lds + RKFD_W*RKFD_SPEC_LDS_INSTANCE );\n"
     "}\n",
     ipw, d.nlink, d.ndof, d.ncand, d.nlink_model, d.nlevel, d.nround, d.nsched, d.maxrg, d.npool, d.nfloat, d.maxact, d.nside,
     d.npurow, d.pu_d0, d.pu_alias, d.vert_rigid, d.qscr_alias, d.has_slide, d.ma_size, d.ma_packed, d.max_iter, d.solver, d.pyramid, d.anchor, d.mlcp_mfma,
-    d.has_brf, d.lds_instance, d.vol_npair, d.vol_np, d.vol_ncp, d.vol_pv, d.vol_nf,
+    d.has_brf, d.lds_instance, ipw == 2 ? d.lds_shared : 0, d.vol_npair, d.vol_np, d.vol_ncp, d.vol_pv, d.vol_nf,
     ( d.vol_np > 0 || ipw == 2 || d.vert_rigid == 2 ) ? 2 : 3, d.vol_np > 0 ? "2" : ( d.vert_rigid ? "1" : "0" ), d.ma_packed ? "true" : "false" );
   std::string src;
   if( const char *pre = getenv( "RKFD_SPEC_DEFINE" ) ){      /* diagnostic: NAME[,NAME...] defined as 1 in front of the source */
@@ -737,7 +737,7 @@ extern "C" int rkfdBatchSetInstancesPerWave(rkfdBatch *b, int ipw)
   if( !b->dblob2 ){
     char err[256];
     if( rkfd_devmodel_build_w( b->model_for_w2, b->host.dm.maxrg, 4, &b->host2, err, sizeof(err) ) < 0 ){ SETERR( "rkfdBatchSetInstancesPerWave: %s", err ); return -1; }
-    if( b->host2.lds_bytes*2 > 160*1024 ){ SETERR( "rkfdBatchSetInstancesPerWave: two instances need %zu bytes of LDS (> 160 KiB)", 2*b->host2.lds_bytes ); rkfd_devmodel_free( &b->host2 ); return -1; }
+    if( b->host2.lds_bytes*2 + (size_t)b->host2.dm.lds_shared > 160*1024 ){ SETERR( "rkfdBatchSetInstancesPerWave: two instances need %zu bytes of LDS (> 160 KiB)", 2*b->host2.lds_bytes ); rkfd_devmodel_free( &b->host2 ); return -1; }
     HIPCHK( hipMalloc( &b->dblob2, b->host2.bytes ), -1 );
     HIPCHK( hipMemcpy( b->dblob2, b->host2.blob, b->host2.bytes, hipMemcpyHostToDevice ), -1 );
     b->dm2 = b->host2.dm;

@@ -719,7 +719,12 @@ extern "C" int rkfd_devmodel_build_w(const rkfdModel *m, int max_rigid, const in
   for( int pass=0; pass<2; pass++ ){
     if( pass == 1 ){
       const size_t Mr = 3*(size_t)max_rigid;
-      if( dm.vert_rigid || max_rigid <= 0 || vol_np > 0 || NG != 8 ) break;      /* (two instances per wavefront: full rows) */
+      if( dm.vert_rigid || max_rigid <= 0 || vol_np > 0 ) break;
+      /* (one instance per wavefront: the Gauss-Seidel form that broadcasts through the DPP operand exists for full rows only - its
+       *  index arithmetic on the packed triangle costs registers that kernel does not have - so up to 16 contacts a packed matrix
+       *  means the general loop whenever the count is not 4 or 8: the 26-DoF humanoid 10.2 M steps/s with full rows at ten per CU,
+       *  8.8 M packed at eleven.  The kernel with two instances per wavefront has the registers and takes the packed form.) */
+      if( NG == 8 && max_rigid <= 16 ) break;
       dm.ma_packed = 1; dm.ma_size = (int)( Mr*( Mr+1 )/2 );
     }
     const size_t M = 3*(size_t)max_rigid;
@@ -727,19 +732,28 @@ extern "C" int rkfd_devmodel_build_w(const rkfdModel *m, int max_rigid, const in
     size_t stage = (size_t)14*NL + pool;                         /* inertia staging + Ia pool ...   */
     if( (size_t)dm.ma_size > stage ) stage = (size_t)dm.ma_size;   /* ... shared with the contact matrix */
     const size_t dbl = (size_t)NL*( 5*6 + 3 ) + stage + (size_t)33*nfloat
-                     + (size_t)maxact*( 21 + ( NC > RKFD_WAVE/2 ? 3 : 0 ) + ( dm.has_slide ? 6 : 0 ) ) + ( dm.vert_rigid ? 2 : 1 )*M + ( dm.pu_alias ? 0 : (size_t)nside*npurow*M )
+                     + (size_t)maxact*( 18 + ( NC > RKFD_WAVE/2 ? 3 : 0 ) + ( dm.has_slide ? 6 : 0 ) ) + ( dm.vert_rigid ? 2 : 1 )*M + ( dm.pu_alias ? 0 : (size_t)nside*npurow*M )
                      + ( dm.vert_rigid ? ( dm.vert_rigid == 2 ? 0 : M*M ) + M*( M+1 )/2 + 5*M + 3*M : 0 )   /* Vert QP: QL, QW, QV, CR */
                      + ( dm.vert_rigid == 3 ? (size_t)dm.pyramid*M + (size_t)dm.pyramid*max_rigid : 0 )             /* ... wide form: QG, QY */
                      + ( vol_np > 0 ? (size_t)RKFD_VOL_LDS_DOUBLES( vol_np, vol_ncp, vol_pv, vol_nf, dm.pyramid ) : 0 );
+    /* two instances per wavefront: the world's static tables - CIp, LI (ints), CHP, CFO (16 bit), PL (bytes) - once per wavefront
+     * (rkfdDevModel.lds_shared); not with breakable joints, whose link info and path tops are per instance */
+    const bool shr = NG == 4 && !has_brf;
+    const size_t sh_ints = (size_t)NC + (size_t)NL, sh_bytes = (size_t)2*NL + (size_t)2*NC + ( max_rigid > 0 ? (size_t)NL*( nlevel+3 ) : 0 );
+    dm.lds_shared = shr ? (int)( ( sh_ints*sizeof(int) + sh_bytes + 15 ) & ~(size_t)15 ) : 0;
     const size_t ints = (size_t)NC + (size_t)nside*maxact + ( vol_np > 0 ? 12 + 2*vol_np : ( NC > 0 ? 8 : 4 ) ) + (size_t)NL     /* CIp, tgt, cnt (VI), LI */
-                      + ( RKFD_GC_NEEDED( (int)M ) ? RKFD_GC_INTS : 0 );                                                            /* GC */
-    const size_t bytes = (size_t)2*NL + (size_t)5*NC + (size_t)4*maxact + ( dm.vert_rigid ? M : 0 ) + ( dm.vert_rigid == 3 ? (size_t)( dm.pyramid+1 )*max_rigid : 0 )                                     /* CHP (16 bit), act typ asl (bytes) */
+                      + ( RKFD_GC_NEEDED( (int)M ) ? RKFD_GC_INTS : 0 )                                                             /* GC */
+                      - ( shr ? sh_ints : 0 );
+    const size_t bytes = (size_t)2*NL + (size_t)5*NC + (size_t)5*maxact - ( shr ? sh_bytes : 0 ) + ( dm.vert_rigid ? M : 0 ) + ( dm.vert_rigid == 3 ? (size_t)( dm.pyramid+1 )*max_rigid : 0 )                                     /* CHP (16 bit), act typ asl (bytes) */
                        + ( max_rigid > 0 ? (size_t)NL*( nlevel+3 ) : 0 )                 /* PL */
                        + ( has_brf ? (size_t)NL : 0 );                                   /* BRK */
     out->lds_bytes = dbl*sizeof(double) + ints*sizeof(int) + bytes;
     out->lds_bytes = ( out->lds_bytes + 15 ) & ~(size_t)15;
+    /* (what a workgroup asks for: one instance, or two and the shared tables) */
+    const size_t wg = NG == 4 ? 2*out->lds_bytes + (size_t)dm.lds_shared : out->lds_bytes;
+    const size_t wg_full = NG == 4 ? 2*lds_full + (size_t)dm.lds_shared : lds_full;
     if( pass == 0 ) lds_full = out->lds_bytes;
-    else if( 128/( ( out->lds_bytes+1279 )/1280 ) <= 128/( ( lds_full+1279 )/1280 ) ){
+    else if( 128/( ( wg+1279 )/1280 ) <= 128/( ( wg_full+1279 )/1280 ) ){
       /* no instance gained: stay with full rows */
       dm.ma_packed = 0; dm.ma_size = 9*max_rigid*max_rigid; out->lds_bytes = lds_full;
     }
@@ -748,7 +762,7 @@ extern "C" int rkfd_devmodel_build_w(const rkfdModel *m, int max_rigid, const in
                NL, ND, NC, nlevel, npool, nfloat, maxact, nside, npurow, dm.pu_alias, (int)M, stage, (size_t)14*NL + pool, dm.vert_rigid, out->lds_bytes );
   }
   out->dm.ma_packed = dm.ma_packed; out->dm.ma_size = dm.ma_size;
-  out->dm.lds_instance = (int)out->lds_bytes;
+  out->dm.lds_instance = (int)out->lds_bytes; out->dm.lds_shared = dm.lds_shared;
   if( NG == 4 ){
     /* two instances per wavefront: everything that is one lane per item must fit the 32 lanes of an instance */
     if( NL > 32 || ND > 32 || dm.maxact > 32 || max_rigid > 16 || dm.vert_rigid || vol_np > 0 )

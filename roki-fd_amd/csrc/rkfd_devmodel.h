@@ -89,6 +89,10 @@ typedef struct {
   const int *sched;
   int ngroup;            /* lane groups (links) per sweep iteration the schedule was built for: 8, or 4 for two instances per wavefront */
   int lds_instance;      /* bytes of LDS one instance owns (the second instance of a wavefront starts that far in) */
+  int lds_shared;        /* two instances per wavefront: bytes of the world's static tables (candidate info, link info, child / pool
+                            table, face offsets, path table) kept ONCE per wavefront behind the two instances' blocks; 0: every
+                            instance keeps its own (one instance per wavefront; worlds with breakable joints, whose link info and
+                            path tops are per instance) */
   int npool;             /* links whose articulated inertia must be staged in LDS for a gathering parent */
   int nfloat;            /* float joints (each owns a 6x6 Cholesky slot and a saved frame)          */
   const int *pslot;      /* [nlink] pool slot of the link, -1 when its Ia is handed over in registers */

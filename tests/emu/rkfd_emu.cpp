@@ -32,6 +32,8 @@ static unsigned long long g_xb[64];
 int rkfd_emu_lane(void){ return t_lane; }
 int rkfd_emu_half(void){ return t_tid/EMU_WL; }
 void rkfd_emu_sync(void){ g_bar->arrive_and_wait(); }
+static std::barrier<> *g_wavebar;            /* every thread that runs in this wavefront (both instances, or the only live one) */
+void rkfd_emu_sync_wave(void){ g_wavebar->arrive_and_wait(); }
 double rkfd_emu_g8sum(double x)
 {
   g_xd[t_tid] = x;
@@ -104,11 +106,15 @@ extern "C" int rkfd_emu_run(const rkfdModel *m, int max_rigid, rkfdDevState *st,
   if( rkfd_devmodel_build_w( m, max_rigid, 8/RKFD_W, &h, err, sizeof(err) ) < 0 ) return -1;
   /* the harness keeps the state arrays at the boundary convention (anchors in model link frames) */
   if( h.ncand > 0 ) rkfd_ref_to_device( &h, st->cv_ref, (size_t)st->batch*h.ncand );
-  std::vector<char> lds( RKFD_W*h.lds_bytes + 64 );
+  std::vector<char> lds( RKFD_W*h.lds_bytes + h.dm.lds_shared + 64 );
   int errflag = 0;
   for( int b=0; b<st->batch; b+=RKFD_W ){
     std::barrier<> bar0( EMU_WL ), bar1( EMU_WL );
     g_bars[0] = &bar0; if( RKFD_W > 1 ) g_bars[RKFD_W-1] = &bar1;
+    int nrun = 0;
+    for( int l=0; l<64; l++ ) nrun += b + l/EMU_WL < st->batch;
+    std::barrier<> wbar( nrun );
+    g_wavebar = &wbar;
     /* LDS is NOT cleared on the GPU: poison it (all ones: NaN as a double, -1 as an int), so that a read of storage nobody wrote
      * shows here instead of depending on what the previous kernel on the box left behind */
     std::memset( lds.data(), 0xFF, lds.size() );
@@ -124,11 +130,12 @@ extern "C" int rkfd_emu_run(const rkfdModel *m, int max_rigid, rkfdDevState *st,
         const bool live = bi < st->batch;
         if( !live ) bi -= 1;
         char *base = lds.data() + ( l/EMU_WL )*h.lds_bytes;
+        char *shared = lds.data() + RKFD_W*h.lds_bytes;      /* (the world's static tables, once per wavefront: rkfdDevModel.lds_shared) */
         /* the variant the C-ABI would launch: the one carrying the Vert QP only for worlds that need it */
-        if( h.dm.vol_np > 0 ) rkfd_instance<false, 2, false>( h.dm, *st, bi, base, mode, nsteps, &errflag, live );
-        else if( h.dm.vert_rigid ) rkfd_instance<false, 1, false>( h.dm, *st, bi, base, mode, nsteps, &errflag, live );
-        else if( h.dm.ma_packed ) rkfd_instance<false, 0, true>( h.dm, *st, bi, base, mode, nsteps, &errflag, live );
-        else rkfd_instance<false, 0, false>( h.dm, *st, bi, base, mode, nsteps, &errflag, live ); } );
+        if( h.dm.vol_np > 0 ) rkfd_instance<false, 2, false>( h.dm, *st, bi, base, mode, nsteps, &errflag, live, shared );
+        else if( h.dm.vert_rigid ) rkfd_instance<false, 1, false>( h.dm, *st, bi, base, mode, nsteps, &errflag, live, shared );
+        else if( h.dm.ma_packed ) rkfd_instance<false, 0, true>( h.dm, *st, bi, base, mode, nsteps, &errflag, live, shared );
+        else rkfd_instance<false, 0, false>( h.dm, *st, bi, base, mode, nsteps, &errflag, live, shared ); } );
     }
     for( auto &t : th ) t.join();
   }
