@@ -201,6 +201,8 @@ int rkfdNodeGetState(rkfdNode *n, double *dis, double *vel, double *acc);      /
  * on; Status and Gather wait for them) */
 int rkfdNodeSpecialize(rkfdNode *n);
 int rkfdNodeSetSplit(rkfdNode *n, int nsplit);
+int rkfdNodeSetStepsPerLaunch(rkfdNode *n, int steps);        /* rkfdBatchSetStepsPerLaunch on every device */
+int rkfdNodeTuneInstancesPerWave(rkfdNode *n, int nsteps);    /* rkfdBatchTuneInstancesPerWave on every device (each keeps what is faster there) */
 int rkfdNodeUpdateInit(rkfdNode *n);
 int rkfdNodeUpdate(rkfdNode *n, int nsteps);
 int rkfdNodeSnapshot(rkfdNode *n);

@@ -119,6 +119,7 @@ def lib():
     L.rkfdNodeSetState.argtypes = [vp, vp, vp]; L.rkfdNodeSetMotorInput.argtypes = [vp, vp]
     L.rkfdNodeGetState.argtypes = [vp, vp, vp, vp]
     L.rkfdNodeSetSplit.argtypes = [vp, C.c_int]; L.rkfdNodeUpdate.argtypes = [vp, C.c_int]
+    L.rkfdNodeSetStepsPerLaunch.argtypes = [vp, C.c_int]; L.rkfdNodeTuneInstancesPerWave.argtypes = [vp, C.c_int]
     L.rkfdNodeGather.argtypes = [vp, vp, vp]
     L.rkfdNodeGatherDev.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]; L.rkfdNodeGatherDev.restype = vp
     _lib = L
@@ -428,6 +429,12 @@ class Node:
 
     def set_split(self, nsplit):
         self._chk(self._L.rkfdNodeSetSplit(self._n, nsplit))
+
+    def set_steps_per_launch(self, n):
+        self._chk(self._L.rkfdNodeSetStepsPerLaunch(self._n, int(n)))
+
+    def tune_instances_per_wave(self, nsteps=8):
+        self._chk(self._L.rkfdNodeTuneInstancesPerWave(self._n, int(nsteps)))
 
     def update_init(self):
         self._chk(self._L.rkfdNodeUpdateInit(self._n))

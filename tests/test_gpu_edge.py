@@ -688,6 +688,10 @@ def test_node_level_matches_one_batch(R):
     n1.restore(); n1.update(nsteps)                    # a second rollout from the snapshot ends in the same states
     gd2, gv2 = n1.gather()
     assert (gd2 == d0).all() and (gv2 == v0).all()
+    # launch shaping from the node level: lane mapping by measurement on every device, steps per launch - the same bits
+    n1.restore(); n1.tune_instances_per_wave(4); n1.set_steps_per_launch(2); n1.update(nsteps)
+    gd3, gv3 = n1.gather()
+    assert n1.status() == 0 and (gd3 == d0).all() and (gv3 == v0).all()
     n1.close()
 
 
