@@ -930,3 +930,22 @@ def test_volume_plugin_accepts_worlds_with_large_shapes(R):
     ref.set_state(sc["dis"], sc["vel"]); ref.update_init(); ref.update(20)
     for x, y in zip(b.get_state(), ref.get_state()):
         assert _rel(x, y) < 1e-9          # (the shells add mass to nothing: shapes only)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["config4", "config5"])
+def test_steps_per_launch_do_not_change_results(R, cfg):
+    """rkfdBatchSetStepsPerLaunch: under split launches a call of n steps goes out as rounds of launches of at most k steps - a
+    launch shape, not arithmetic: 1, 5 (the default), 7 (a short last round) and n steps per launch end in the same bits"""
+    B, n = 96, 23
+    sc = R.scenarios.CONFIGS[cfg](batch=B)
+    out = []
+    for k in (1, 5, 7, n):
+        b = R.Batch(sc["world"], B, max_rigid=sc["max_rigid"])
+        b.specialize(); b.set_split(3); b.set_steps_per_launch(k)
+        b.set_state(sc["dis"], sc["vel"]); b.update_init(); b.update(n)
+        assert b.status() == 0
+        out.append(b.get_state() + b.get_contact() + b.get_pivot())
+    for o in out[1:]:
+        for x, y in zip(out[0], o):
+            assert np.array_equal(x, y)
