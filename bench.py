@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py - sim-steps/sec of the batched rkFDUpdate hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W [--workload config4|config3|config2|config5|config4v] [--batch B]
+  python bench.py --gpus N --steps K --warmup W [--workload config4|config3|config2|config5|config4v|config5v|config1_volume|config4_volume|...] [--batch B]
 
 A "step" is one rkFDUpdate (4 RKG stage evaluations + the committing evaluation) of every instance of the
 batch; state stays resident in HBM between steps.
@@ -32,8 +32,14 @@ the next step of another (+25 % at 4096 instances per GPU).
 `roofline.kernel_ms` is the average duration of ONE launch (HIP events on the stream it runs on),
 `roofline.achieved` the algorithmic bytes of one launch over that duration; the launches of a step overlap,
 `achieved_all_launches_of_a_step` relates the whole step's bytes to the step's duration.
-The step kernel is compiled for the workload's world before the timing starts (rkfdBatchSpecialize, about
-2 s; --no-specialize keeps the library's generic kernel; same results either way).
+A launch carries --steps-per-launch (default 5) steps of its part of the batch (rkfdBatchSetStepsPerLaunch): the state stays in
+LDS between them; roofline.steps_per_launch says what the timed launches really carried.
+The step kernel is the one compiled for the workload's world (rkfdBatchSpecialize: ahead of time by `make spec`, else hipRTC
+in about 2 s; --no-specialize keeps the library's generic kernel; same results either way), with one or two instances per
+wavefront, whichever is faster for that world: --ipw 0 (default) measures both before the timed region
+(rkfdBatchTuneInstancesPerWave; the two give the same bits) and reports the two times.
+Counter-derived fields (roofline.traffic, valu_issue) come from the newest profiles/rNN_* files and only when those carry the
+hash of this tree's device sources (else null + the reason).
 Prints ONE JSON line on rank 0.
 """
 import argparse
