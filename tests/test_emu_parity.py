@@ -377,7 +377,7 @@ def test_emulated_self_collision_matches_oracle(R, oracle_cls, solver):
     implementations whose vertex positions differ in the last bit (1e-16 m) differ by up to 1e-8 in acc.  Every step
     therefore starts from the oracle's state, and the tolerance is 1e-9 relative PLUS what a 2e-14 rad nudge of the state
     does to the oracle's own result."""
-    B, nsteps = 2, 10
+    B, nsteps = 2, 6
     sc = R.scenarios.arm_fold(batch=B, solver=R.SOLVER_MLCP if solver == "mlcp" else R.SOLVER_VERT)
     model = sc["world"].model
     eb = EmuBatch(sc["world"], B, max_rigid=sc["max_rigid"])
@@ -465,7 +465,7 @@ def test_emulated_breakable_float_joints(R, oracle_cls):
     assert events >= 2 and all(sum(l) == 2 for l in last)          # the third brick's joint broke DURING the run, the first brick's held
 
 
-@pytest.mark.parametrize("cfg,B,nsteps", [("config2", 3, 1), ("config3", 3, 2), ("config4", 3, 2), ("config1b", 2, 2), ("arm_press", 3, 2)])
+@pytest.mark.parametrize("cfg,B,nsteps", [("config2", 3, 1), ("config3", 3, 1), ("config4", 3, 1), ("config1b", 2, 2), ("arm_press", 3, 1)])
 def test_emulated_two_instances_per_wavefront(R, oracle_cls, cfg, B, nsteps):
     """RKFD_W = 2 (rkfd_devmodel.h): two instances share a wavefront, 32 lanes each, four sweep lane groups and the list
     schedule.  Results must be those of one instance per wavefront to the last bit (same operations per instance, the cross-lane
