@@ -271,8 +271,12 @@ def main():
     ipw_tuning = None
     if specialized and args.ipw == 0:
         # untimed: which mapping is faster for THIS world (both give the same bits); the state comes back as it was
-        chosen, ms = b.tune_instances_per_wave(min(H, 50) if H > 0 else 50)
-        ipw_tuning = {"ms_1": round(ms[0], 4), "ms_2": round(ms[1], 4) if ms[1] >= 0 else None, "chosen": chosen}
+        try:
+            chosen, ms = b.tune_instances_per_wave(min(H, 50) if H > 0 else 50)
+            ipw_tuning = {"ms_1": round(ms[0], 4), "ms_2": round(ms[1], 4) if ms[1] >= 0 else None, "chosen": chosen}
+        except R.RkfdError as e:              # an optimisation, not a correctness path: the kernel with one instance per wavefront stays
+            print("bench.py: %s" % e, file=sys.stderr)
+            ipw_tuning = {"error": str(e)}
         aot = aot and bool(R.lib().rkfdSpecializeLastFromStore())
         assert b.status(stream) == 0
     if H > 0:
